@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE (dev container only).
+
+    python -B tests/golden/make_golden.py
+
+The reference (ay-lab/mustache v1.3.3, read-only at /root/reference) has no tests or golden outputs of its own
+(SURVEY.md section 4), so parity is pinned on outputs of the reference itself: this script imports it (see
+_refimport.py for the three stand-ins the import needs), feeds it small deterministic synthetic inputs
+(mustache_amd/synth.py) and stores inputs + outputs + selected intermediates as compressed .npz files.
+Only data is stored -- no reference source text.  The fixtures travel to the GPU box; the reference does not.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from _refimport import load_reference  # noqa: E402
+from mustache_amd.synth import synth_coo  # noqa: E402
+
+OCTAVES = [1.6, 3.2]
+
+
+def subsample(a):
+    f = np.ascontiguousarray(a).ravel()
+    return f[::97].copy()
+
+
+def run_mustache_traced(ref, c, start, dpx, st, pt):
+    """Call ref.mustache and capture SciPy-call arguments/results and the function's final locals."""
+    import scipy.stats
+    cap = dict(gauss=[], maxf=[], fit=[], bh=[])
+    g0, m0, fit0, bh0 = ref.gaussian_filter, ref.maximum_filter, ref.expon.fit, ref.multipletests
+
+    def g(inp, sigma, **kw):
+        out = g0(inp, sigma, **kw)
+        cap["gauss"].append((float(sigma), float(kw["truncate"]), float(out.sum()), subsample(out)))
+        return out
+
+    def mf(inp, **kw):
+        out = m0(inp, **kw)
+        cap["maxf"].append((float(inp.sum()), subsample(inp), float(out.sum()), subsample(out)))
+        return out
+
+    def fit(data, *a, **kw):
+        r = fit0(data, *a, **kw)
+        cap["fit"].append((float(r[0]), float(r[1]), float(np.sum(data))))
+        return r
+
+    def bh(p, **kw):
+        r = bh0(p, **kw)
+        cap["bh"].append((np.array(p, copy=True), np.array(r[1], copy=True)))
+        return r
+
+    locs = {}
+
+    def tracer(frame, event, arg):
+        if frame.f_code.co_name != "mustache":
+            return None
+
+        def local(frame, event, arg):
+            if event == "return":
+                for k in ("nz", "pAll", "Scales", "vAll", "o", "so", "x", "y"):
+                    if k in frame.f_locals:
+                        locs[k] = np.array(frame.f_locals[k], copy=True)
+            return local
+        return local
+
+    ref.gaussian_filter, ref.maximum_filter, ref.multipletests = g, mf, bh
+    ref.expon.fit = fit
+    sys.settrace(tracer)
+    try:
+        loops = ref.mustache(c, "1", "1", 5000, [], start, start + c.shape[0], 0, dpx, OCTAVES, st, pt)
+    finally:
+        sys.settrace(None)
+        ref.gaussian_filter, ref.maximum_filter, ref.multipletests = g0, m0, bh0
+        ref.expon.fit = fit0
+    return loops, cap, locs
+
+
+def loops_array(loops):
+    if not loops:
+        return np.zeros((0, 4))
+    return np.array([[float(a), float(b), float(q), float(s)] for a, b, q, s in loops], dtype=np.float64)
+
+
+def dense(x, y, v, n):
+    c = np.zeros((n, n))
+    c[x, y] = v
+    return c
+
+
+def make_normalize(ref):
+    # branch A: window = int(2e6/res) = 40 bins; holes exercise cnt<30, an empty diagonal, a constant run
+    n, dpx, res = 600, 80, 50000
+    x, y, v = synth_coo(n, dpx, depth=120.0, seed=11)
+    d = y - x
+    keep = np.ones(len(v), bool)
+    keep &= ~((x >= 200) & (x < 290) & (d % 3 != 0))        # sparse stretch -> window counts < 30
+    keep &= d != 37                                           # an empty diagonal
+    x, y, v = x[keep], y[keep], v[keep].copy()
+    v[(d[keep] == 20) & (x >= 400) & (x < 480)] = 5.0        # constant run -> zero local variance
+    perm = np.random.default_rng(5).permutation(len(v))       # entry order matters for np.mean/np.std
+    x, y, v = x[perm], y[perm], v[perm]
+    vin = v.copy()
+    w = ref.normalize_sparse(x, y, v, res, dpx)
+    np.savez_compressed(os.path.join(HERE, "normalize_A.npz"), x=x.astype(np.int32), y=y.astype(np.int32),
+                        v_in=vin, v_out=v, weights=np.array(w), res=res, dpx=dpx)
+    # branch B: (n - dpx) * res <= 2e6
+    n, dpx, res = 300, 80, 5000
+    x, y, v = synth_coo(n, dpx, depth=120.0, seed=12)
+    perm = np.random.default_rng(6).permutation(len(v))
+    x, y, v = x[perm], y[perm], v[perm]
+    vin = v.copy()
+    w = ref.normalize_sparse(x, y, v, res, dpx)
+    np.savez_compressed(os.path.join(HERE, "normalize_B.npz"), x=x.astype(np.int32), y=y.astype(np.int32),
+                        v_in=vin, v_out=v, weights=np.array(w), res=res, dpx=dpx)
+    print("normalize fixtures done")
+
+
+def make_block(ref, name, n, dpx, seed, start, st, pt, depth=300.0, nloops=None, res=50000):
+    x, y, v = synth_coo(n, dpx, depth=depth, seed=seed, nloops=nloops)
+    ref.normalize_sparse(x, y, v, res, dpx)
+    c = dense(x, y, v, n)
+    cin = c.copy()
+    loops, cap, locs = run_mustache_traced(ref, c, start, dpx, st, pt)
+    out = dict(x=x.astype(np.int32), y=y.astype(np.int32), v=v, n=n, dpx=dpx, start=start, st=st, pt=pt,
+               loops=loops_array(loops), c_after_sum=float(c.sum()),
+               c_changed=int((c != cin).sum()))
+    out["g_sigma"] = np.array([g[0] for g in cap["gauss"]])
+    out["g_trunc"] = np.array([g[1] for g in cap["gauss"]])
+    out["g_sum"] = np.array([g[2] for g in cap["gauss"]])
+    out["g_sub"] = np.array([g[3] for g in cap["gauss"]])
+    out["d_sum"] = np.array([m[0] for m in cap["maxf"]])
+    out["d_sub"] = np.array([m[1] for m in cap["maxf"]])
+    out["m_sum"] = np.array([m[2] for m in cap["maxf"]])
+    out["m_sub"] = np.array([m[3] for m in cap["maxf"]])
+    out["fit"] = np.array(cap["fit"]).reshape(-1, 3)
+    if cap["bh"]:
+        out["bh_in"], out["bh_out"] = cap["bh"][0]
+    for k in ("nz", "pAll", "Scales", "vAll"):
+        if k in locs:
+            out["loc_" + k] = locs[k] if k != "nz" else np.packbits(locs[k])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "nz", int(locs["nz"].sum()) if "nz" in locs else None, "found",
+          int((locs["pAll"] != 2).sum()) if "pAll" in locs else None, "loops", len(loops),
+          "pzero", int((locs["pAll"] == 0).sum()) if "pAll" in locs else None)
+
+
+def make_edges(ref):
+    # < 50 tested pixels -> [] (mustache.py:701); 50 <= nz < 10000 -> [] (mustache.py:775)
+    n, dpx = 200, 60
+    x, y, v = synth_coo(n, dpx, depth=200.0, seed=21)
+    ref.normalize_sparse(x, y, v, 50000, dpx)
+    few = (x < 8) & (y - x >= 4) & (y < 13)
+    c1 = dense(x[few], y[few], v[few], n)
+    l1 = ref.mustache(c1.copy(), "1", "1", 5000, [], 0, n, 0, dpx, OCTAVES, 0.8, 0.1)
+    c2 = dense(x, y, v, n)
+    l2 = ref.mustache(c2.copy(), "1", "1", 5000, [], 0, n, 0, dpx, OCTAVES, 0.8, 0.1)
+    np.savez_compressed(os.path.join(HERE, "block_edges.npz"), x=x.astype(np.int32), y=y.astype(np.int32), v=v,
+                        few=few, n=n, dpx=dpx, nz1=int(np.logical_and(c1 != 0, np.triu(c1, 4)).sum()),
+                        nz2=int(np.logical_and(c2 != 0, np.triu(c2, 4)).sum()),
+                        loops1=loops_array(l1), loops2=loops_array(l2))
+    print("edges", len(l1), len(l2))
+
+
+class _InlineProcess:
+    """multiprocessing.Process stand-in that runs the target in-process (fixtures need determinism, not speed)."""
+
+    def __init__(self, target, args):
+        self._t, self._a = target, args
+
+    def start(self):
+        self._t(*self._a)
+
+    def join(self):
+        pass
+
+
+class _PlainManager:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def list(self):
+        return []
+
+
+def make_tiling(ref):
+    """(n, dpx) -> starts / ends / mask sizes as regulator + process_block compute them (mustache.py:896-910, :948-953)."""
+    rec = []
+    real = (ref.Process, ref.Manager, ref.mustache, ref.normalize_sparse, ref.read_pd)
+    calls = []
+
+    def fake_mustache(cc, ch, ch2, res, w, start, end, mask, dpx, octs, st, pt):
+        calls.append((start, end, mask, cc.shape[0]))
+        return []
+
+    ref.Process, ref.Manager = _InlineProcess, _PlainManager
+    ref.mustache = fake_mustache
+    ref.normalize_sparse = lambda *a, **k: []
+    cases = [(1500, 400), (2000, 400), (2001, 400), (3600, 400), (3601, 400), (9630, 400), (4001, 2000),
+             (12000, 2000), (8000, 1000), (4200, 200), (2399, 400)]
+    try:
+        for n, dpx in cases:
+            calls.clear()
+            xx = np.array([0, n - 1])
+            ref.read_pd = lambda *a, **k: (xx, xx.copy(), np.array([1.0, 1.0]))
+            ref.regulator("dummy.txt", False, False, "out", res=5000, distance_filter=dpx * 5000,
+                          chromosome="1", nprocesses=1)
+            rec.append((n, dpx, [c[0] for c in calls], [c[1] for c in calls], [c[2] for c in calls], calls[0][3]))
+    finally:
+        ref.Process, ref.Manager, ref.mustache, ref.normalize_sparse, ref.read_pd = real
+    np.savez_compressed(os.path.join(HERE, "tiling.npz"),
+                        n=np.array([r[0] for r in rec]), dpx=np.array([r[1] for r in rec]),
+                        chunk=np.array([r[5] for r in rec]),
+                        starts=np.array([np.array(r[2]) for r in rec], dtype=object),
+                        ends=np.array([np.array(r[3]) for r in rec], dtype=object),
+                        masks=np.array([np.array(r[4]) for r in rec], dtype=object))
+    print("tiling done", [(r[0], r[1], len(r[2])) for r in rec])
+
+
+def make_regulator(ref):
+    """End to end through the reference's text reader, normalisation, tiling and block loop (3 blocks)."""
+    n, dpx, res = 4200, 200, 10000
+    x, y, v = synth_coo(n, dpx, depth=300.0, seed=31)
+    # raw integer-ish counts and a bias file, as a 3-column RAWobserved-style text + KRnorm-style vector
+    rng = np.random.default_rng(9)
+    bias = rng.uniform(0.5, 1.5, n)
+    bias[rng.choice(n, 40, replace=False)] = np.nan
+    bias[rng.choice(n, 40, replace=False)] = 0.1
+    with tempfile.TemporaryDirectory() as td:
+        fpath = os.path.join(td, "chrS.RAWobserved")
+        bpath = os.path.join(td, "chrS.KRnorm")
+        with open(fpath, "w") as f:
+            for a, b, c in zip(x, y, v):
+                f.write("%d\t%d\t%r\n" % (a * res, b * res, float(c)))
+        with open(bpath, "w") as f:
+            for b in bias:
+                f.write("%r\n" % float(b) if not np.isnan(b) else "NaN\n")
+        real = (ref.Process, ref.Manager)
+        ref.Process, ref.Manager = _InlineProcess, _PlainManager
+        try:
+            rx, ry, rv = ref.read_pd(fpath, dpx * res, bpath, "S", res)
+            loops = ref.regulator(fpath, False, False, "out", res=res, pt=0.1, st=0.8, distance_filter=dpx * res,
+                                  bias=bpath, chromosome="S", nprocesses=1)
+        finally:
+            ref.Process, ref.Manager = real
+    rx, ry, rv = np.asarray(rx), np.asarray(ry), np.asarray(rv)
+    la = loops_array(loops)
+    la = la[np.lexsort((la[:, 1], la[:, 0]))]
+    np.savez_compressed(os.path.join(HERE, "regulator_3blocks.npz"), n=n, dpx=dpx, res=res, seed=31, depth=300.0,
+                        bias=bias, in_checksum=float(v.sum()), in_nnz=len(v),
+                        read_nnz=len(rv), read_vsum=float(rv.sum()), read_xsum=int(rx.sum()), read_ysum=int(ry.sum()),
+                        loops=la)
+    print("regulator loops", len(la))
+
+
+if __name__ == "__main__":
+    ref = load_reference("mustache")
+    which = sys.argv[1:] or ["norm", "blocks", "edges", "tiling", "regulator"]
+    if "norm" in which:
+        make_normalize(ref)
+    if "blocks" in which:
+        make_block(ref, "block_320", 320, 80, seed=1, start=1600, st=0.8, pt=0.2, nloops=30)
+        make_block(ref, "block_512", 512, 128, seed=2, start=0, st=0.7, pt=0.2, depth=200.0, nloops=40)
+    if "edges" in which:
+        make_edges(ref)
+    if "tiling" in which:
+        make_tiling(ref)
+    if "regulator" in which:
+        make_regulator(ref)

@@ -1,0 +1,133 @@
+/*
+ * mustache_hip.h -- C ABI of libmustache_hip.so, the MI355X (gfx950) implementation of the per-block
+ * scale-space loop-calling hot path of ay-lab/mustache.
+ *
+ * The reference has no FFI / plugin interface (it is pure Python over SciPy); its narrowest stable seam is the
+ * Python call  mustache(c, chromosome, chromosome2, res, pval_weights, start, end, mask_size, distance_in_px,
+ * octave_values, st, pt)  (reference mustache/mustache.py:697-698), invoked per dense block by process_block
+ * (:945-960) from regulator (:853-937).  This header is the set of entry points a binding for that seam needs;
+ * each one names the reference code it replaces.  INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is a device (HBM) pointer owned by the caller (e.g. a torch tensor's
+ *     data_ptr()); "host" pointers are ordinary host memory.  Nothing is allocated or freed behind the ABI
+ *     except small internal scratch that is cached per (device, stream).
+ *   - `stream` is a hipStream_t passed as void*; NULL = the default stream.  All work is enqueued
+ *     asynchronously on it; the functions do not synchronise unless stated.
+ *   - return value: 0 = ok, <0 = error (MST_E_*); mst_last_error() returns a thread-local message.
+ *     No C++ exception crosses the ABI.
+ *   - all arithmetic is IEEE float64 without fused multiply-add, in the evaluation order of the SciPy
+ *     kernels the reference calls, so DoG values are bit-identical to the reference's.
+ */
+#ifndef MUSTACHE_HIP_H
+#define MUSTACHE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MST_ABI_VERSION 1
+
+#define MST_OK 0
+#define MST_E_ARG (-1)      /* bad argument (null pointer, size, unsupported radius ...) */
+#define MST_E_HIP (-2)      /* a HIP runtime call failed; message has hipGetErrorString */
+#define MST_E_OVERFLOW (-3) /* an output buffer capacity was exceeded (caller re-runs with a larger one) */
+#define MST_E_NONFINITE (-4)/* non-finite DoG statistics (the reference raises ValueError in expon.fit) */
+
+#define MST_MAX_LEVELS 64   /* octaves * (s + 2) */
+#define MST_MAX_RADIUS 32
+#define MST_MAX_TESTED 48   /* octaves * (s - 1) */
+
+/* The Gaussian level table: what mustache.py:714-752 passes to scipy.ndimage.gaussian_filter, already reduced
+ * by the host to integer radii and normalised taps (scipy/ndimage/_filters.py:226-236, :314-316).
+ * Level index l = octave * levels_per_octave + (k - 1), k = 1 .. levels_per_octave. */
+typedef struct mst_levels {
+    int32_t n_octaves;
+    int32_t levels_per_octave;                           /* s + 2 = 12 in the reference (s = 10, mustache.py:711) */
+    int32_t radius[MST_MAX_LEVELS];
+    int32_t _pad;
+    double sigma[MST_MAX_LEVELS];
+    double taps[MST_MAX_LEVELS][MST_MAX_RADIUS + 1];     /* taps[l][0] = centre, taps[l][j] = weight at +-j */
+} mst_levels;
+
+/* One "found" pixel = an nz pixel whose (x, y, sigma) sieve fired at least once (mustache.py:760-768). */
+typedef struct mst_found {
+    uint32_t pixel;     /* row * CH + col inside the block */
+    uint32_t level;     /* 1 + octave * (s - 1) + (i - 3), i = the reference's loop index (mustache.py:744) */
+    double value;       /* vAll: the winning DoG response */
+} mst_found;
+
+int mst_abi_version(void);
+const char *mst_last_error(void);
+
+/* mustache.py:919-924 (regulator's COO -> dense block scatter) for B blocks at once.
+ * x, y, v: dev, upper-triangular COO in chromosome bin units; starts: host, B block origins.
+ * c: dev [B][CH][CH] float64, fully overwritten (zero + scatter).  Entries with start <= x, y < start + CH go
+ * into block b at (x - start, y - start), exactly like `cc[xc, yc] = vc`.  Duplicate (x, y) entries must not
+ * occur (the reference takes the last one; readers never produce duplicates). */
+int mst_scatter_blocks(const int64_t *x, const int64_t *y, const double *v, int64_t nnz,
+                       const int64_t *starts, int32_t B, int32_t CH, double *c, void *stream);
+
+/* mustache.py:699-706 (prologue of mustache()): nz = (c != 0) & (col - row >= 4) taken before the fills,
+ * then c[col-row <= 4] = 2 and, if intra != 0, c[col-row >= dpx+1] = 2.  In place on c.
+ * nz: dev [B][CH][CH] uint8 (1 = tested pixel); nz_count: dev [B] uint32, overwritten with sum(nz). */
+int mst_block_prologue(double *c, uint8_t *nz, uint32_t *nz_count, int32_t B, int32_t CH, int32_t dpx,
+                       int32_t intra, void *stream);
+
+/* scipy.ndimage.gaussian_filter(c, sigma, truncate=t, order=0) as called at mustache.py:719/725/734/751, for a
+ * batch of B images of H x W float64: axis 0 then axis 1, mode='reflect', symmetric pair-sum order.
+ * taps: host, radius+1 doubles (centre first).  tmp: dev scratch, same size as `in`.  Bring-up / parity kernel
+ * and the building block of the general (any radius) path. */
+int mst_gauss_blur(const double *in, double *out, double *tmp, int32_t B, int32_t H, int32_t W,
+                   const double *taps, int32_t radius, void *stream);
+
+/* mustache.py:714-772, the whole sigma loop of mustache() fused for B prologue'd blocks:
+ * the 2 x 12 Gaussian blurs, the 11 DoG levels per octave, their zero-padded 3x3 maxima, the 5-term
+ * (x, y, sigma) sieve with `best` carried across levels and octaves, and the per-level min / sum of |D| over nz
+ * that scipy.stats.expon.fit needs (:755).
+ *   c, nz       : dev, from mst_block_prologue
+ *   lv          : host
+ *   found       : dev [B][found_cap] records, unordered within a block
+ *   found_count : dev [B] uint32, overwritten; a count > found_cap means records were dropped -> caller
+ *                 must re-run with a larger capacity (mst_found_pvalues reports MST_E_OVERFLOW)
+ *   level_stats : dev [B][MST_MAX_TESTED][2] float64, overwritten: {min |D_c| over nz, sum |D_c| over nz} per
+ *                 tested level (deterministic reduction order)
+ *   skip_empty  : !=0 -> tiles that contain no nz pixel are not computed (identical outputs, less work)
+ *   workspace   : dev scratch of at least mst_scale_space_workspace_bytes(B, CH, lv) bytes
+ */
+int mst_scale_space(const double *c, const uint8_t *nz, int32_t B, int32_t CH, const mst_levels *lv,
+                    mst_found *found, uint32_t found_cap, uint32_t *found_count, double *level_stats,
+                    int32_t skip_empty, void *workspace, uint64_t workspace_bytes, void *stream);
+
+/* Bytes of device scratch mst_scale_space needs for (B, CH, lv): the level table plus per-tile partial
+ * statistics.  Returns 0 on bad arguments. */
+uint64_t mst_scale_space_workspace_bytes(int32_t B, int32_t CH, const mst_levels *lv);
+
+/* mustache.py:755-756 for the found pixels only (deferred p-value; bit-for-bit the same quantity):
+ * loc = min|D|, scale = mean|D| - loc per tested level, p = 1 - (-expm1(-(value - loc)/scale)).
+ * pval: dev [B][found_cap] float64.  fit: dev [B][MST_MAX_TESTED][2] float64 out = {loc, scale}.
+ * Synchronises the stream and returns MST_E_OVERFLOW / MST_E_NONFINITE when a block overflowed its record
+ * capacity or produced non-finite statistics. */
+int mst_found_pvalues(const mst_found *found, uint32_t found_cap, const uint32_t *found_count,
+                      const uint32_t *nz_count, const double *level_stats, int32_t B, int32_t n_tested,
+                      double *pval, double *fit, void *stream);
+
+/* mustache.py:800-811 + :824 inputs for a list of candidate pixels of ONE block b:
+ * cnt1[i] = sum nz[x-s:x+s+1, y-s:y+s+1], cnt2[i] = same with 2s (Python slice semantics: a window whose start
+ * is negative is empty -> 0; windows are clipped at the far edge), cval[i] = c[x, y].
+ * pixel, half: dev [n] (half = ceil(scale)); outputs dev [n]. */
+int mst_candidate_features(const double *c, const uint8_t *nz, int32_t CH, int32_t b, const uint32_t *pixel,
+                           const int32_t *half, int32_t n, uint32_t *cnt1, uint32_t *cnt2, double *cval,
+                           void *stream);
+
+/* mustache.py:816-823: gather diagonals of block b for the diagonal-mean filter.
+ * diag_k: dev [n] offsets k >= 0; out: dev [n][CH] float64, row i = c[r, r+k] for r < CH-k, zero padded. */
+int mst_gather_diagonals(const double *c, int32_t CH, int32_t b, const int32_t *diag_k, int32_t n, double *out,
+                         void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUSTACHE_HIP_H */

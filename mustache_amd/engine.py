@@ -1,0 +1,168 @@
+"""Device-side driver of the scale-space hot path: torch tensors for HBM + streams, HIP kernels through the C ABI.
+
+PyTorch is plumbing here (device memory, streams); every number is produced by libmustache_hip.so.  A missing
+library or a missing GPU is an error -- there is no CPU path in this package.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .levels import LevelTable
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("mustache_amd needs a ROCm GPU (MI355X/gfx950); no CPU fallback exists")
+    return _lib.load()
+
+
+class BlockBatch:
+    """Results of the sigma loop for B blocks, plus the device buffers the tail needs.
+
+    found[b] = dict(pixel uint32 [m] ascending, level uint32 [m] (1-based tested level), value float64 [m],
+                    pval float64 [m])  on the host;  nz_count[b];  fit[b] = (loc[n_tested], scale[n_tested]).
+    """
+
+    def __init__(self, engine, c, nz, CH, B, nz_count, found, fit):
+        self.engine, self.c, self.nz, self.CH, self.B = engine, c, nz, CH, B
+        self.nz_count, self.found, self.fit = nz_count, found, fit
+
+    # ---- tail helpers: tiny gathers so dense blocks never leave the device ------------------------------------
+    def candidate_features(self, b, pixel, half):
+        """(cnt1, cnt2, cval) for candidate pixels of block b (reference mustache.py:800-807, :824)."""
+        lib = self.engine.lib
+        n = int(len(pixel))
+        if n == 0:
+            return np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0)
+        dev = self.c.device
+        d_pix = torch.from_numpy(np.ascontiguousarray(pixel, dtype=np.uint32).view(np.int32)).to(dev)
+        d_half = torch.from_numpy(np.ascontiguousarray(half, dtype=np.int32)).to(dev)
+        cnt1 = torch.empty(n, dtype=torch.int32, device=dev)
+        cnt2 = torch.empty(n, dtype=torch.int32, device=dev)
+        cval = torch.empty(n, dtype=torch.float64, device=dev)
+        _lib.check(lib.mst_candidate_features(_ptr(self.c), _ptr(self.nz), self.CH, b, _ptr(d_pix), _ptr(d_half),
+                                              n, _ptr(cnt1), _ptr(cnt2), _ptr(cval), _stream()))
+        return (cnt1.cpu().numpy().view(np.uint32), cnt2.cpu().numpy().view(np.uint32), cval.cpu().numpy())
+
+    def diagonals(self, b, ks):
+        """Rows = diagonals c[r, r+k] of block b, zero padded to CH (reference mustache.py:816-820)."""
+        lib = self.engine.lib
+        n = int(len(ks))
+        if n == 0:
+            return np.zeros((0, self.CH))
+        dev = self.c.device
+        d_k = torch.from_numpy(np.ascontiguousarray(ks, dtype=np.int32)).to(dev)
+        out = torch.empty((n, self.CH), dtype=torch.float64, device=dev)
+        _lib.check(lib.mst_gather_diagonals(_ptr(self.c), self.CH, b, _ptr(d_k), n, _ptr(out), _stream()))
+        return out.cpu().numpy()
+
+
+class ScaleSpaceEngine:
+    """Owns the level table and runs rows 2-7 of SURVEY.md section 8a on the GPU."""
+
+    def __init__(self, octave_values=(1.6, 3.2), s=10, device=None):
+        self.lib = require_gpu()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.levels = LevelTable(octave_values, s)
+        self._lv_struct = self.levels.as_struct()
+
+    # ---- row 2: COO -> dense blocks ---------------------------------------------------------------------------
+    def scatter_blocks(self, x, y, v, starts, CH):
+        """x, y int64 / v float64 device tensors (upper-triangular COO, bin units) -> [B, CH, CH] float64."""
+        B = len(starts)
+        c = torch.empty((B, CH, CH), dtype=torch.float64, device=self.device)
+        st = (ctypes.c_int64 * B)(*[int(s) for s in starts])
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mst_scatter_blocks(_ptr(x), _ptr(y), _ptr(v), int(v.numel()), st, B, CH, _ptr(c),
+                                                   _stream()))
+        return c
+
+    # ---- row 4 bring-up: one Gaussian level ----------------------------------------------------------------------
+    def gauss_blur(self, img, taps):
+        """img [B, H, W] float64 device tensor; taps = centre-first half kernel (radius = len-1)."""
+        img = img.contiguous()
+        B, H, W = img.shape
+        out = torch.empty_like(img)
+        tmp = torch.empty_like(img)
+        arr = (ctypes.c_double * len(taps))(*[float(t) for t in taps])
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mst_gauss_blur(_ptr(img), _ptr(out), _ptr(tmp), B, H, W, arr, len(taps) - 1, _stream()))
+        return out
+
+    # ---- rows 3-7 -------------------------------------------------------------------------------------------------
+    def prologue(self, c, dpx, intra=True):
+        B, CH, _ = c.shape
+        nz = torch.empty((B, CH, CH), dtype=torch.uint8, device=self.device)
+        nz_count = torch.empty(B, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mst_block_prologue(_ptr(c), _ptr(nz), _ptr(nz_count), B, CH, int(dpx),
+                                                   1 if intra else 0, _stream()))
+        return nz, nz_count
+
+    def sigma_loop(self, c, nz, nz_count, skip_empty=True, found_cap=None, download=True):
+        """The fused kernel + p-values.  Returns (found_dev, pval_dev, count_dev, fit_dev) or host copies."""
+        B, CH, _ = c.shape
+        nt = self.levels.n_tested
+        if found_cap is None:
+            found_cap = max(4096, (CH * CH) // 32)
+        lv = ctypes.byref(self._lv_struct)
+        ws_bytes = int(self.lib.mst_scale_space_workspace_bytes(B, CH, lv))
+        with torch.cuda.device(self.device):
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+            stats = torch.empty((B, _lib.MST_MAX_TESTED, 2), dtype=torch.float64, device=self.device)
+            fit = torch.empty((B, _lib.MST_MAX_TESTED, 2), dtype=torch.float64, device=self.device)
+            count = torch.empty(B, dtype=torch.int32, device=self.device)
+            while True:
+                found = torch.empty((B, found_cap, 2), dtype=torch.int64, device=self.device)  # 16-byte records
+                pval = torch.empty((B, found_cap), dtype=torch.float64, device=self.device)
+                _lib.check(self.lib.mst_scale_space(_ptr(c), _ptr(nz), B, CH, lv, _ptr(found), found_cap,
+                                                    _ptr(count), _ptr(stats), 1 if skip_empty else 0, _ptr(ws),
+                                                    ws_bytes, _stream()))
+                try:
+                    _lib.check(self.lib.mst_found_pvalues(_ptr(found), found_cap, _ptr(count), _ptr(nz_count),
+                                                          _ptr(stats), B, nt, _ptr(pval), _ptr(fit), _stream()))
+                    break
+                except _lib.MstOverflow:
+                    found_cap *= 4          # rare: a block with an unusually dense set of local maxima
+        if not download:
+            return found, pval, count, fit, found_cap
+        return self._download(found, pval, count, fit, nt)
+
+    @staticmethod
+    def _download(found, pval, count, fit, nt):
+        cnt = count.cpu().numpy().astype(np.int64)
+        fit_h = fit.cpu().numpy()
+        B = len(cnt)
+        mx = int(cnt.max()) if B else 0
+        rec = found[:, :mx].cpu().numpy()          # [B, mx, 2] int64 = {pixel u32 | level u32, value bits}
+        pv = pval[:, :mx].cpu().numpy()
+        out, fits = [], []
+        for b in range(B):
+            m = int(cnt[b])
+            word = rec[b, :m, 0].view(np.uint64)
+            pixel = (word & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+            level = (word >> np.uint64(32)).astype(np.uint32)
+            value = rec[b, :m, 1].view(np.float64)
+            order = np.argsort(pixel, kind="stable")      # row-major = the reference's nz order
+            out.append(dict(pixel=pixel[order], level=level[order], value=value[order].copy(),
+                            pval=pv[b, :m][order].copy()))
+            fits.append((fit_h[b, :nt, 0].copy(), fit_h[b, :nt, 1].copy()))
+        return out, fits
+
+    def run_blocks(self, c, dpx, intra=True, skip_empty=True):
+        """c: [B, CH, CH] float64 device tensor holding raw (normalised, un-filled) blocks; mutated in place
+        like the reference mutates its block (mustache.py:703-706)."""
+        nz, nz_count = self.prologue(c, dpx, intra)
+        found, fits = self.sigma_loop(c, nz, nz_count, skip_empty=skip_empty)
+        B, CH, _ = c.shape
+        return BlockBatch(self, c, nz, CH, B, nz_count.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)

@@ -1,0 +1,373 @@
+#!/usr/bin/env python3
+"""Drop-in host side for the reference's per-chromosome run (ay-lab/mustache v1.3.3, mustache/mustache.py).
+
+Same function names, argument meaning and return types as the reference for everything on the hot path:
+
+    mustache(c, chromosome, chromosome2, res, pval_weights, start, end, mask_size, distance_in_px,
+             octave_values, st, pt)                      <- mustache.py:697-850
+    process_block(...)                                   <- mustache.py:945-960
+    normalize_sparse(x, y, v, resolution, distance_in_px) <- mustache.py:622-686
+    regulator(f, norm_method, CHRM_SIZE, outdir, ...)    <- mustache.py:853-942
+    read_pd / read_bias / get_sep / is_chr / parseBP / parse_args / main  (text input, CLI)
+
+but the arithmetic runs in HIP kernels on an MI355X (mustache_amd/csrc, C ABI in include/mustache_hip.h).
+Where the reference forks one OS process per block, this host keeps all blocks of a chromosome resident in HBM
+and launches each kernel once over the whole batch.
+"""
+import argparse
+import math
+import os
+import sys
+import time
+from collections import defaultdict
+
+import numpy as np
+
+from .tail import block_tail
+
+_ENGINES = {}
+
+
+def _engine(octave_values):
+    from .engine import ScaleSpaceEngine
+    key = tuple(float(o) for o in octave_values)
+    eng = _ENGINES.get(key)
+    if eng is None:
+        eng = _ENGINES[key] = ScaleSpaceEngine(key)
+    return eng
+
+
+# --------------------------------------------------------------------------------------------------------------
+# per-block entry point (reference mustache.py:697-850)
+# --------------------------------------------------------------------------------------------------------------
+def mustache(c, chromosome, chromosome2, res, pval_weights, start, end, mask_size, distance_in_px, octave_values,
+             st, pt):
+    """Loops of one dense block.  `c` is a square float64 array; like the reference, it is modified in place
+    (diagonals <= 4 and > distance_in_px are set to 2).  `res`, `pval_weights`, `end` and `mask_size` are
+    accepted and ignored, exactly as in the reference body.  Returns [[x+start, y+start, fdr, sigma], ...]."""
+    import torch
+    eng = _engine(octave_values)
+    c = np.asarray(c)
+    if c.ndim != 2 or c.shape[0] != c.shape[1] or c.dtype != np.float64:
+        raise ValueError("mustache(): c must be a square float64 array")
+    dev = torch.from_numpy(np.ascontiguousarray(c)).to(eng.device).unsqueeze(0)
+    batch = eng.run_blocks(dev, distance_in_px, intra=(chromosome == chromosome2))
+    c[...] = batch.c[0].cpu().numpy()
+    return block_tail(batch, 0, start, pt, st, intra=(chromosome == chromosome2))
+
+
+def process_block(i, start, end, overlap_size, cc, chromosome, chromosome2, res, pval_weights, distance_in_px,
+                  octave_values, o, st, pt):
+    """reference mustache.py:945-960: run one block and append the loops that survive the overlap mask to `o`."""
+    mask_size = block_mask_size(i, start, end, overlap_size)
+    loops = mustache(cc, chromosome, chromosome2, res, pval_weights, start[i], end[i], mask_size, distance_in_px,
+                     octave_values, st, pt)
+    for loop in loops:
+        if loop[0] >= start[i] + mask_size or loop[1] >= start[i] + mask_size:
+            o.append([loop[0], loop[1], loop[2], loop[3]])
+
+
+# --------------------------------------------------------------------------------------------------------------
+# tiling (reference mustache.py:896-910, :948-953)
+# --------------------------------------------------------------------------------------------------------------
+def block_tiling(n, distance_in_px):
+    """(CHUNK_SIZE, start[], end[]) exactly as regulator computes them."""
+    chunk = max(2 * distance_in_px, 2000)
+    if n <= chunk:
+        return chunk, [0], [n]
+    start, end = [0], [chunk]
+    while end[-1] < n:
+        start.append(end[-1] - distance_in_px)
+        end.append(start[-1] + chunk)
+    end[-1] = n
+    start[-1] = end[-1] - chunk
+    return chunk, start, end
+
+
+def block_mask_size(i, start, end, overlap_size):
+    if i == 0:
+        return -1
+    if i == len(start) - 1:
+        return end[i - 1] - start[i]
+    return overlap_size
+
+
+# --------------------------------------------------------------------------------------------------------------
+# text readers (reference mustache.py:191-297) -- host I/O, pandas like the reference
+# --------------------------------------------------------------------------------------------------------------
+def parseBP(s):
+    """'5kb' / '1mb' / '5000' -> base pairs; False when unparsable (reference mustache.py:29-49)."""
+    if not s:
+        return False
+    if s.isnumeric():
+        return int(s)
+    s = s.lower()
+    for unit, mult in (("kb", 1000), ("mb", 1000000)):
+        if unit in s:
+            head = s.split(unit)[0]
+            return int(head) * mult if head.isnumeric() else False
+    return False
+
+
+def is_chr(s, c):
+    return str(c).replace('chr', '') == str(s).replace('chr', '')
+
+
+def get_sep(f):
+    """Guess the column separator from the first line (reference mustache.py:199-215)."""
+    with open(f) as fh:
+        for line in fh:
+            if "\t" in line:
+                return '\t'
+            if " " in line.strip():
+                return ' '
+            if "," in line:
+                return ','
+            if len(line.split(' ')) == 1:
+                return ' '
+            break
+    raise FileNotFoundError
+
+
+def read_bias(f, chromosome, res):
+    """bin -> bias factor; NaN or < 0.2 become +inf so the contact is dropped (reference mustache.py:218-251)."""
+    d = defaultdict(lambda: 1.0)
+    if not f:
+        return False
+    sep = get_sep(f)
+    with open(f) as fh:
+        for pos, line in enumerate(fh):
+            cols = line.strip().split(sep)
+            if len(cols) == 3:
+                if is_chr(cols[0], chromosome):
+                    val = float(cols[2])
+                    d[float(cols[1]) // res] = val if (not np.isnan(val) and val >= 0.2) else np.inf
+            elif len(cols) == 1:
+                val = float(cols[0])
+                d[pos] = val if (not np.isnan(val) and val >= 0.2) else np.inf
+    return d
+
+
+def read_pd(f, distance_in_bp, bias, chromosome, res):
+    """3-column (pos1 pos2 count) or 5-column (chr1 pos1 chr2 pos2 count) text -> upper-triangular COO in bin
+    units, counts divided by bias[x]*bias[y], non-positive rows dropped (reference mustache.py:254-297)."""
+    import pandas as pd
+    sep = get_sep(f)
+    df = pd.read_csv(f, sep=sep, header=None)
+    df.dropna(inplace=True)
+    if df.shape[1] == 5:
+        df = df[np.vectorize(is_chr)(df[0], chromosome)]
+        if df.shape[0] == 0:
+            print('Could\'t read any interaction for this chromosome!')
+            return
+        df = df[np.vectorize(is_chr)(df[2], chromosome)]
+        a, b, cnt = 1, 3, 4
+    elif df.shape[1] == 3:
+        a, b, cnt = 0, 1, 2
+    else:
+        raise ValueError("contact text file must have 3 or 5 columns")
+    df = df.loc[np.abs(df[a] - df[b]) <= ((distance_in_bp / res + 1) * res), :].copy()
+    df[a] //= res
+    df[b] //= res
+    bias = read_bias(bias, chromosome, res)
+    if bias:
+        df[cnt] = np.divide(df[cnt], np.vectorize(bias.get)(df[a], 1))
+        df[cnt] = np.divide(df[cnt], np.vectorize(bias.get)(df[b], 1))
+    df = df.loc[df[cnt] > 0, :]
+    x = np.min(df.loc[:, [a, b]], axis=1)
+    y = np.max(df.loc[:, [a, b]], axis=1)
+    return x, y, np.array(df[cnt])
+
+
+# --------------------------------------------------------------------------------------------------------------
+# normalisation (reference mustache.py:622-686) -- on the GPU, diagonal-major band layout
+# --------------------------------------------------------------------------------------------------------------
+def normalize_sparse(x, y, v, resolution, distance_in_px):
+    """Per-diagonal sliding-window z-score, in place on `v` (host arrays in, host array out), computed on the GPU.
+    Returns the per-diagonal weight list like the reference (unused downstream)."""
+    from .normalize import normalize_sparse_device
+    return normalize_sparse_device(x, y, v, resolution, distance_in_px)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# per-chromosome driver (reference mustache.py:853-942)
+# --------------------------------------------------------------------------------------------------------------
+def call_loops_coo(x, y, v, res, distance_in_px, octave_values, st, pt, chromosome='n', chromosome2=None,
+                   verbose=True, normalized=False, timings=None):
+    """regulator's body after the reader: normalise, tile, run every block, de-duplicate the overlaps.
+    x, y, v are host arrays (the reference's COO).  Returns the reference's list of [x, y, fdr, sigma]."""
+    from .pipeline import ChromosomePipeline
+    pipe = ChromosomePipeline(octave_values)
+    return pipe.run(x, y, v, res, distance_in_px, st, pt, normalized=normalized, verbose=verbose, timings=timings)
+
+
+def regulator(f, norm_method, CHRM_SIZE, outdir, bed="", res=5000, sigma0=1.6, s=10, pt=0.1, st=0.88, octaves=2,
+              verbose=True, nprocesses=4, distance_filter=2000000, bias=False, chromosome='n', chromosome2=None):
+    """Loop calling for one chromosome (reference mustache.py:853-942).  `s` is accepted and ignored like in the
+    reference (s = 10 is hard-wired at :711); `nprocesses` is ignored: all blocks run as one GPU batch."""
+    if not chromosome2 or chromosome2 == 'n':
+        chromosome2 = chromosome
+    if (chromosome != chromosome2) and not (('.hic' in f) or ('.cool' in f) or ('.mcool' in f)):
+        print("Interchromosomal analysis is only supported for .hic and .cool input formats.")
+        raise FileNotFoundError
+    if chromosome != chromosome2:
+        raise NotImplementedError("inter-chromosomal mode is non-functional in the reference (mustache.py:939-942)")
+    octave_values = [sigma0 * (2 ** i) for i in range(octaves)]
+    distance_in_bp = distance_filter
+    if verbose:
+        print("Reading contact map...")
+    if f.endswith(".hic"):
+        from .readers import read_hic_file
+        x, y, v = read_hic_file(f, norm_method, CHRM_SIZE, distance_in_bp, chromosome, chromosome2, res)
+    elif f.endswith(".cool"):
+        from .readers import read_cooler
+        x, y, v, res = read_cooler(f, distance_in_bp, chromosome, chromosome2, norm_method)
+    elif f.endswith(".mcool"):
+        from .readers import read_mcooler
+        x, y, v = read_mcooler(f, distance_in_bp, chromosome, chromosome2, res, norm_method)
+    else:
+        r = read_pd(f, distance_in_bp, bias, chromosome, res)
+        if r is None:
+            return []
+        x, y, v = r
+    if len(v) == 0:
+        return []
+    distance_in_px = int(math.ceil(distance_in_bp // res))
+    return call_loops_coo(np.asarray(x), np.asarray(y), np.asarray(v, dtype=np.float64), res, distance_in_px,
+                          octave_values, st, pt, chromosome, chromosome2, verbose=verbose)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# CLI (reference mustache.py:52-178, :963-1111): same flags and defaults
+# --------------------------------------------------------------------------------------------------------------
+def parse_args(args):
+    p = argparse.ArgumentParser(description="Check the help flag")
+    p.add_argument("-f", "--file", dest="f_path", help="REQUIRED: Contact map", required=False)
+    p.add_argument("-d", "--distance", dest="distFilter",
+                   help="REQUIRED: Maximum distance (in bp) allowed between loop loci", required=False)
+    p.add_argument("-o", "--outfile", dest="outdir", help="REQUIRED: Name of the output file.", required=True)
+    p.add_argument("-r", "--resolution", dest="resolution", help="REQUIRED: Resolution used for the contact maps",
+                   required=True)
+    p.add_argument("-bed", "--bed", dest="bed", help="BED file for HiC-Pro type input", default="", required=False)
+    p.add_argument("-m", "--matrix", dest="mat", help="MATRIX file for HiC-Pro type input", default="",
+                   required=False)
+    p.add_argument("-b", "--biases", dest="biasfile",
+                   help="RECOMMENDED: biases calculated by ICE or KR norm for each locus", required=False)
+    p.add_argument("-cz", "--chromosomeSize", default="", dest="chrSize_file",
+                   help="RECOMMENDED: .hic corresponding chromosome size file.", required=False)
+    p.add_argument("-norm", "--normalization", default=False, dest="norm_method",
+                   help="RECOMMENDED: Hi-C normalization method (KR, VC,...).", required=False)
+    p.add_argument("-st", "--sparsityThreshold", dest="st", type=float, default=0.88,
+                   help="OPTIONAL: sparsity threshold, default 0.88 (relax for sparse data, e.g. 0.8).")
+    p.add_argument("-pt", "--pThreshold", dest="pt", type=float, default=0.2,
+                   help="OPTIONAL: FDR threshold for the output. Default is 0.2")
+    p.add_argument("-sz", "--sigmaZero", dest="s_z", type=float, default=1.6,
+                   help="OPTIONAL: sigma0 of the scale space. DEFAULT is 1.6.")
+    p.add_argument("-oc", "--octaves", dest="octaves", default=2, type=int, help="OPTIONAL: octave count. DEFAULT 2.")
+    p.add_argument("-i", "--iterations", dest="s", default=10, type=int,
+                   help="OPTIONAL: accepted for compatibility; the reference ignores it as well.")
+    p.add_argument("-p", "--processes", dest="nprocesses", default=4, type=int,
+                   help="OPTIONAL: accepted for compatibility; blocks are batched on the GPU instead.")
+    p.add_argument("-ch", "--chromosome", dest="chromosome", nargs='+', default='n', required=False,
+                   help="REQUIRED: chromosome(s) to run on. Optional for cooler files.")
+    p.add_argument("-ch2", "--chromosome2", dest="chromosome2", nargs='+', default='n', required=False,
+                   help="Optional: second chromosome (inter-chromosomal mode is non-functional upstream).")
+    p.add_argument("-v", "--verbose", dest="verbose", type=bool, default=True, help="OPTIONAL: verbosity")
+    return p.parse_args(args)
+
+
+def resolve_distance_filter(dist_arg, res, quiet=False):
+    """reference mustache.py:996-1015: default and clamps of -d."""
+    say = (lambda *a: None) if quiet else print
+    distFilter = parseBP(dist_arg)
+    if not distFilter:
+        if 200 * res >= 2000000:
+            distFilter = 200 * res
+            say("The distance limit is set to {}bp".format(200 * res))
+        elif 2000 * res <= 2000000:
+            distFilter = 2000 * res
+            say("The distance limit is set to {}bp".format(2000 * res))
+        else:
+            distFilter = 2000000
+            say("The distance limit is set to 2Mbp")
+    elif distFilter < 200 * res:
+        say("The distance limit is set to {}bp".format(200 * res))
+        distFilter = 200 * res
+    elif distFilter > 10000 * res:
+        say("The distance limit is set to {}bp".format(10000 * res))
+        distFilter = 10000 * res
+    elif distFilter > 10000000:
+        distFilter = 10000000
+        say("The distance limit is set to 10Mbp")
+    return distFilter
+
+
+def write_loops(path, chromosome, chromosome2, res, loops, first):
+    """reference mustache.py:1081-1103: header once, then one TSV row per loop."""
+    if first:
+        with open(path, 'w') as out_file:
+            out_file.write("BIN1_CHR\tBIN1_START\tBIN1_END\tBIN2_CHROMOSOME\tBIN2_START\tBIN2_END\tFDR\tDETECTION_SCALE\n")
+    with open(path, 'a') as out_file:
+        for lp in loops:
+            out_file.write(str(chromosome) + '\t' + str(lp[0] * res) + '\t' + str((lp[0] + 1) * res) + '\t' +
+                           str(chromosome2) + '\t' + str(lp[1] * res) + '\t' + str((lp[1] + 1) * res) + '\t' +
+                           str(lp[2]) + '\t' + str(lp[3]) + '\n')
+
+
+def main(argv=None):
+    start_time = time.time()
+    args = parse_args(sys.argv[1:] if argv is None else argv)
+    print("\n")
+    f = args.f_path
+    if args.bed and args.mat:
+        f = args.mat
+    if not f or not os.path.exists(f):
+        print("Error: Couldn't find the specified contact files")
+        return
+    res = parseBP(args.resolution)
+    if not res:
+        print("Error: Invalid resolution")
+        return
+    if not args.chromosome or args.chromosome == 'n':
+        if f.endswith(".cool") or f.endswith(".mcool") or f.endswith(".hic"):
+            from .readers import list_chromosomes
+            chr_list = list_chromosomes(f, res)
+        else:
+            print("Error: Please enter the chromosome name.")
+            return
+    else:
+        chr_list = list(args.chromosome)
+    if (args.chromosome2 and args.chromosome2 != 'n') and (len(chr_list) != len(args.chromosome2)):
+        print("Error: the same number of chromosome1 and chromosome2 should be provided.")
+        return
+    chr_list2 = list(args.chromosome2) if isinstance(args.chromosome2, list) else list(chr_list)
+    distFilter = resolve_distance_filter(args.distFilter, res)
+
+    chrSize_in_bp = False
+    if args.chrSize_file:
+        import pandas as pd
+        csz = pd.read_csv(args.chrSize_file, header=None, sep='\t')
+        chrSize_in_bp = {"chr" + str(csz.iloc[i, 0]).replace('chr', ''): csz.iloc[i, 1] for i in range(csz.shape[0])}
+
+    for i, (chromosome, chromosome2) in enumerate(zip(chr_list, chr_list2)):
+        CHRM_SIZE = chrSize_in_bp["chr" + str(chromosome).replace('chr', '')] if chrSize_in_bp else False
+        biasf = False
+        if args.biasfile:
+            if os.path.exists(args.biasfile):
+                biasf = args.biasfile
+            else:
+                print("Error: Couldn't find specified bias file")
+                return
+        o = regulator(f, args.norm_method, CHRM_SIZE, args.outdir, bed=args.bed, res=res, sigma0=args.s_z, s=args.s,
+                      verbose=args.verbose, pt=args.pt, st=args.st, distance_filter=distFilter,
+                      nprocesses=args.nprocesses, bias=biasf, chromosome=chromosome, chromosome2=chromosome2,
+                      octaves=args.octaves)
+        print("{0} loops found for chrmosome={1}, fdr<{2} in {3}sec".format(
+            len(o), chromosome, args.pt, "%.2f" % (time.time() - start_time)))
+        if i == 0 or o:
+            write_loops(args.outdir, chromosome, chromosome2, res, o, first=(i == 0))
+        start_time = time.time()
+
+
+if __name__ == '__main__':
+    main()

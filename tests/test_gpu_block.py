@@ -1,0 +1,136 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and the golden
+fixtures produced by the reference.  Integer / index results must be identical; DoG-derived floats are bit-exact
+by construction (same operation order, no FMA); p-values are compared at 1e-9 relative (north_star asks 1e-5)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+OCT = [1.6, 3.2]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=True)
+
+
+def _dense(g):
+    n = int(g["n"])
+    c = np.zeros((n, n))
+    c[g["x"], g["y"]] = g["v"]
+    return c
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from mustache_amd.engine import ScaleSpaceEngine
+    return ScaleSpaceEngine(OCT)
+
+
+def test_library_loaded_is_in_tree():
+    from mustache_amd import _lib
+    lib = _lib.load()
+    assert lib.mst_abi_version() == 1
+    assert os.path.dirname(_lib.LIB_PATH).endswith("mustache_amd")
+
+
+@pytest.mark.parametrize("shape", [(1, 300, 517), (3, 64, 40), (1, 9, 2000)])
+def test_gauss_blur_bit_exact(eng, shape):
+    import torch
+    import oracle
+    rng = np.random.default_rng(3)
+    img = rng.normal(size=shape) * 3 + 1
+    dev = torch.from_numpy(img).cuda()
+    for lv in oracle.level_table(OCT + [6.4])[::5]:
+        if lv["radius"] > 32:
+            continue
+        out = eng.gauss_blur(dev, lv["weights"][lv["radius"]:]).cpu().numpy()
+        for b in range(shape[0]):
+            exp = oracle.blur_scipy(img[b], lv["sigma"], lv["truncate"])
+            assert np.array_equal(out[b], exp), "sigma=%r radius=%d" % (lv["sigma"], lv["radius"])
+
+
+def _run_block(eng, c, dpx, skip_empty=True):
+    import torch
+    dev = torch.from_numpy(c).cuda().unsqueeze(0)
+    nz, nzc = eng.prologue(dev, dpx, True)
+    found, fits = eng.sigma_loop(dev, nz, nzc, skip_empty=skip_empty)
+    return dev, nz, int(nzc.cpu().numpy()[0]), found[0], fits[0]
+
+
+@pytest.mark.parametrize("name", ["block_320.npz", "block_512.npz"])
+@pytest.mark.parametrize("skip_empty", [True, False])
+def test_sigma_loop_vs_reference_fixture(eng, golden_dir, name, skip_empty):
+    g = _load(golden_dir, name)
+    c = _dense(g)
+    n, dpx = int(g["n"]), int(g["dpx"])
+    dev, nz_d, nzc, found, fit = _run_block(eng, c.copy(), dpx, skip_empty)
+    nz = np.unpackbits(g["loc_nz"]).astype(bool)[:n * n].reshape(n, n)
+    assert np.array_equal(nz_d[0].cpu().numpy().astype(bool), nz)
+    assert nzc == int(nz.sum())
+    assert float(dev[0].sum().cpu()) == float(g["c_after_sum"]) or np.isclose(float(dev[0].sum().cpu()), float(g["c_after_sum"]), rtol=1e-13)
+    # found set, best DoG value and recorded scale: bit-exact against the reference's locals
+    pall, vall, scl = g["loc_pAll"], g["loc_vAll"], g["loc_Scales"]
+    nz_idx = np.flatnonzero(nz.ravel())
+    ref_found = pall != 2
+    assert np.array_equal(found["pixel"].astype(np.int64), nz_idx[ref_found])
+    assert np.array_equal(found["value"], vall[ref_found])
+    sig = np.asarray(eng.levels.tested_sigma)
+    assert np.array_equal(sig[found["level"].astype(int) - 1], scl[ref_found])
+    # expon.fit: loc is a min (exact); scale is a mean (different but deterministic summation order)
+    assert np.array_equal(fit[0], g["fit"][:, 0])
+    np.testing.assert_allclose(fit[1], g["fit"][:, 1], rtol=1e-12)
+    # p-values (before BH) against the reference's multipletests input
+    np.testing.assert_allclose(found["pval"], g["bh_in"], rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("name", ["block_320.npz", "block_512.npz"])
+def test_mustache_dropin_vs_reference_fixture(golden_dir, name):
+    from mustache_amd.mustache import mustache
+    g = _load(golden_dir, name)
+    c = _dense(g)
+    n, dpx, start = int(g["n"]), int(g["dpx"]), int(g["start"])
+    loops = mustache(c, "1", "1", 5000, [], start, start + n, 0, dpx, OCT, float(g["st"]), float(g["pt"]))
+    assert c.sum() == float(g["c_after_sum"]), "block must be mutated in place like the reference does"
+    exp = g["loops"]
+    assert len(loops) == len(exp) > 0
+    got = np.array([[float(a), float(b), q, s] for a, b, q, s in loops])
+    assert np.array_equal(got[:, :2], exp[:, :2]), "loop coordinates must be identical, in the reference's order"
+    assert np.array_equal(got[:, 3], exp[:, 3])
+    np.testing.assert_allclose(got[:, 2], exp[:, 2], rtol=1e-9)
+    assert isinstance(loops[0][0], np.int64) and isinstance(loops[0][2], np.float64)
+
+
+def test_edge_blocks(golden_dir):
+    from mustache_amd.mustache import mustache
+    g = _load(golden_dir, "block_edges.npz")
+    n, dpx = int(g["n"]), int(g["dpx"])
+    few = g["few"]
+    c1 = np.zeros((n, n))
+    c1[g["x"][few], g["y"][few]] = g["v"][few]
+    assert mustache(c1, "1", "1", 5000, [], 0, n, 0, dpx, OCT, 0.8, 0.1) == []
+    c2 = np.zeros((n, n))
+    c2[g["x"], g["y"]] = g["v"]
+    assert mustache(c2, "1", "1", 5000, [], 0, n, 0, dpx, OCT, 0.8, 0.1) == []
+    c3 = np.zeros((n, n))          # empty block
+    assert mustache(c3, "1", "1", 5000, [], 0, n, 0, dpx, OCT, 0.8, 0.1) == []
+
+
+@pytest.mark.parametrize("n,dpx,seed", [(2000, 400, 0)])
+def test_full_size_block_vs_oracle(eng, n, dpx, seed):
+    """BASELINE config 2: one dense 2000x2000 near-diagonal block at the 5 kb shape, HIP vs the oracle end to end."""
+    import oracle
+    from mustache_amd.mustache import mustache
+    from mustache_amd.synth import synth_coo
+    x, y, v = synth_coo(n + 1600, dpx, depth=300.0, seed=seed)
+    oracle.normalize_sparse(x, y, v, 5000, dpx)
+    sel = (x >= 1600) & (y >= 1600)
+    c = np.zeros((n, n))
+    c[x[sel] - 1600, y[sel] - 1600] = v[sel]
+    exp, mid = oracle.mustache_block(c.copy(), 1600, dpx, OCT, 0.8, 0.1, return_intermediate=True)
+    got = mustache(c, "1", "1", 5000, [], 1600, 1600 + n, 0, dpx, OCT, 0.8, 0.1)
+    assert len(exp) > 5
+    assert [(int(a), int(b)) for a, b, _, _ in got] == [(int(a), int(b)) for a, b, _, _ in exp]
+    assert [s for _, _, _, s in got] == [s for _, _, _, s in exp]
+    np.testing.assert_allclose([q for _, _, q, _ in got], [q for _, _, q, _ in exp], rtol=1e-9)

@@ -127,6 +127,34 @@ int mst_candidate_features(const double *c, const uint8_t *nz, int32_t CH, int32
 int mst_gather_diagonals(const double *c, int32_t CH, int32_t b, const int32_t *diag_k, int32_t n, double *out,
                          void *stream);
 
+/* ---- diagonal-major band layout ---------------------------------------------------------------------------------
+ * band[d * n + i] = value of pixel (i, i + d), d = 0 .. dpx+1, i = 0 .. n-1; 0.0 = no contact.  dev, float64. */
+
+/* COO -> band: the per-diagonal `vals[x[indices]] = v[indices]` of mustache.py:633-635 for all diagonals at once.
+ * band is zero-filled first; entries with |y - x| > dpx + 1 are ignored; x, y may come in either order. */
+int mst_band_from_coo(const int64_t *x, const int64_t *y, const double *v, int64_t nnz, int64_t n, int32_t dpx,
+                      double *band, void *stream);
+
+/* band -> COO order: v[e] = band[|y-x|][min(x, y)]  (the `v[indices] = vals[x[indices]]` write-back, :669). */
+int mst_band_to_coo(const double *band, const int64_t *x, const int64_t *y, int64_t nnz, int64_t n, int32_t dpx,
+                    double *v, void *stream);
+
+/* normalize_sparse (mustache.py:622-686) on the band, out of place (band_in != band_out).
+ *   local != 0 : branch A (:628-669), taken by the caller when (n - dpx) * res > 2e6; `window` = int(2e6 / res).
+ *                Per diagonal d <= dpx+1: vals = v + 0.001; counts / sum / sum of squares over the zero-padded
+ *                window [i - window/2, i - window/2 + window - 1] (np.convolve 'same'); local variance and mean
+ *                with the global fallback below 30 samples or when non-finite; z = (vals - mean)/sqrt(var),
+ *                non-finite -> 0, times 1 + log30(1 + global mean).
+ *   local == 0 : branch B (:671-685): (v - mean)/std for d < min(dpx, n), other diagonals pass through.
+ * diag_stats: dev [dpx+2][4] out = {global mean, global std, weight 1 + log30(1 + mean), entry count} per diagonal. */
+int mst_normalize_band(const double *band_in, double *band_out, int64_t n, int32_t dpx, int32_t window,
+                       int32_t local, double *diag_stats, void *stream);
+
+/* mustache.py:919-924 + :699-706 fused, for B blocks: dense filled blocks and the nz mask straight from the band
+ * (intra-chromosomal).  starts: host [B]; c: dev [B][CH][CH]; nz: dev [B][CH][CH] uint8; nz_count: dev [B]. */
+int mst_blocks_from_band(const double *band, int64_t n, int32_t dpx, const int64_t *starts, int32_t B, int32_t CH,
+                         double *c, uint8_t *nz, uint32_t *nz_count, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

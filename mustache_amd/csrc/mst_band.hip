@@ -1,0 +1,329 @@
+// Diagonal-major band layout and the diagonal-distance normalisation (gfx950).
+//
+// A chromosome's near-diagonal contacts live in HBM as   band[d * n + i] = value of pixel (i, i + d),
+// d = 0 .. dpx+1, i = 0 .. n-1, 0.0 = no contact.  Every diagonal is a contiguous row, so the per-diagonal
+// statistics and sliding windows of the reference's normalize_sparse (mustache/mustache.py:622-686) become
+// coalesced streams, and cutting dense blocks out of it (mustache.py:919-924 + the prologue :699-706) is a
+// tile transpose through LDS instead of a host-side boolean mask per block.
+//
+//   mst_band_from_coo     COO (x, y, v) -> band            (what `vals[x[indices]] = v[indices]` does per diagonal)
+//   mst_normalize_band    mustache.py:628-685, both branches
+//   mst_band_to_coo       gather the normalised values back into COO order (drop-in `v` in place semantics)
+//   mst_blocks_from_band  mustache.py:919-924 + :699-706 fused: filled dense blocks + nz mask straight from the band
+//
+// Reproducibility note: the reference's window sums come from np.convolve -> BLAS ddot, whose
+// accumulation order depends on the host's BLAS build, so bit-equality with "the" reference does not exist for
+// this stage.  We sum every window directly (no running/prefix sums), in a fixed order, which stays within a few
+// ulp of any such order; tests hold the result to 1e-9 relative on z-scores and require identical loop sets.
+#include <cmath>
+#include "mst_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__global__ void __launch_bounds__(kThreads)
+band_scatter_kernel(const int64_t *__restrict__ x, const int64_t *__restrict__ y, const double *__restrict__ v,
+                    int64_t nnz, int64_t n, int dpx, double *__restrict__ band) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride) {
+        const int64_t a = x[e], b = y[e];
+        const int64_t lo = a < b ? a : b, d = a < b ? b - a : a - b;
+        if (d <= dpx + 1 && lo >= 0 && lo + d < n) band[d * n + lo] = v[e];
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+band_gather_kernel(const double *__restrict__ band, const int64_t *__restrict__ x, const int64_t *__restrict__ y,
+                   int64_t nnz, int64_t n, int dpx, double *__restrict__ v) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride) {
+        const int64_t a = x[e], b = y[e];
+        const int64_t lo = a < b ? a : b, d = a < b ? b - a : a - b;
+        if (d <= dpx + 1 && lo >= 0 && lo + d < n) v[e] = band[d * n + lo];
+    }
+}
+
+// fixed-order block reduction of (a, b): strided per-thread partials, then a binary tree in LDS
+__device__ __forceinline__ void block_reduce2(double &a, double &b, double *sa, double *sb) {
+    const int tid = threadIdx.x;
+    sa[tid] = a;
+    sb[tid] = b;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            sa[tid] = sa[tid] + sa[tid + s];
+            sb[tid] = sb[tid] + sb[tid + s];
+        }
+        __syncthreads();
+    }
+    a = sa[0];
+    b = sb[0];
+    __syncthreads();
+}
+
+// One workgroup per diagonal: count, mean and population std of the raw entries (np.mean / np.std at
+// mustache.py:638-643, :677-682; NaN -> mean 0, std 1), and the weight 1 + log30(1 + mean) (:667).
+// diag_stats[d] = {mean, std, weight, count}
+__global__ void __launch_bounds__(kThreads)
+diag_stats_kernel(const double *__restrict__ band, int64_t n, double *__restrict__ diag_stats) {
+    __shared__ double sa[kThreads], sb[kThreads];
+    const int d = blockIdx.x;
+    const int64_t L = n - d;
+    const double *row = band + (int64_t)d * n;
+    double cnt = 0.0, sum = 0.0;
+    for (int64_t i = threadIdx.x; i < L; i += kThreads) {
+        const double v = row[i];
+        if (v != 0.0) {
+            cnt = cnt + 1.0;
+            sum = sum + v;
+        }
+    }
+    block_reduce2(cnt, sum, sa, sb);
+    double mean = sum / cnt;            // 0/0 -> NaN like np.mean of an empty selection
+    double ssq = 0.0, dummy = 0.0;
+    for (int64_t i = threadIdx.x; i < L; i += kThreads) {
+        const double v = row[i];
+        if (v != 0.0) {
+            const double t = v - mean;
+            ssq = ssq + t * t;
+        }
+    }
+    block_reduce2(ssq, dummy, sa, sb);
+    double sd = sqrt(ssq / cnt);
+    if (mean != mean) mean = 0.0;       // math.isnan(mean) -> 0   (:640-641)
+    if (sd != sd) sd = 1.0;             // math.isnan(std)  -> 1   (:642-643)
+    if (threadIdx.x == 0) {
+        diag_stats[4 * d + 0] = mean;
+        diag_stats[4 * d + 1] = sd;
+        diag_stats[4 * d + 2] = 1.0 + log(1.0 + mean) / log(30.0);
+        diag_stats[4 * d + 3] = cnt;
+    }
+}
+
+// Branch A (mustache.py:632-669): sliding-window z-score.  One workgroup = SEG consecutive positions of one
+// diagonal; the SEG + W samples it needs (+0.001 shift applied, and their squares) are staged in LDS once and every
+// window is summed directly from there.
+constexpr int kSeg = 1024;
+
+__global__ void __launch_bounds__(kThreads)
+normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ band_out, int64_t n, int W,
+                       const double *__restrict__ diag_stats) {
+    extern __shared__ __align__(16) double lds[];
+    const int d = blockIdx.y;
+    const int64_t L = n - d;
+    const int64_t seg0 = (int64_t)blockIdx.x * kSeg;
+    if (seg0 >= L) return;
+    const int left = W / 2;                 // np.convolve(..., 'same'): window = [i - W/2, i - W/2 + W - 1]
+    const int tile = kSeg + W;
+    double *val = lds, *sq = lds + tile;
+    const double *row = band_in + (int64_t)d * n;
+    const int64_t base = seg0 - left;       // position of tile element 0
+    for (int t = threadIdx.x; t < tile; t += kThreads) {
+        const int64_t i = base + t;
+        double v = 0.0;
+        if (i >= 0 && i < L) {
+            const double r = row[i];
+            if (r != 0.0) v = r + 0.001;    // vals[x] = v + 0.001   (:635)
+        }
+        val[t] = v;
+        sq[t] = v * v;                      // vals ** 2             (:649)
+    }
+    __syncthreads();
+    const double mean = diag_stats[4 * d + 0], sd = diag_stats[4 * d + 1], wgt = diag_stats[4 * d + 2];
+    const double std2 = sd * sd;
+    double *orow = band_out + (int64_t)d * n;
+    for (int k = threadIdx.x; k < kSeg; k += kThreads) {
+        const int64_t i = seg0 + k;
+        if (i >= L) break;
+        const double x = val[k + left];
+        double z = 0.0;
+        if (x != 0.0) {
+            double s1 = 0.0, s2 = 0.0;
+            int c = 0;
+            // two-level summation (16-sample partials, then the partials): keeps the rounding error of a
+            // 2000-sample window near that of a pairwise / multi-accumulator BLAS dot
+            int j = 0;
+            for (; j + 16 <= W; j += 16) {
+                double p1 = 0.0, p2 = 0.0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const double a = val[k + j + u];
+                    c += (a != 0.0) ? 1 : 0;
+                    p1 = p1 + a;
+                    p2 = p2 + sq[k + j + u];
+                }
+                s1 = s1 + p1;
+                s2 = s2 + p2;
+            }
+            {
+                double p1 = 0.0, p2 = 0.0;
+                for (; j < W; ++j) {
+                    const double a = val[k + j];
+                    c += (a != 0.0) ? 1 : 0;
+                    p1 = p1 + a;
+                    p2 = p2 + sq[k + j];
+                }
+                s1 = s1 + p1;
+                s2 = s2 + p2;
+            }
+            const double cnt = (double)c;
+            double var = (s2 - s1 * s1 / cnt) / (cnt - 1.0);        // (:650)
+            if (!isfinite(var)) var = std2;                          // (:653-654)
+            double mu = s1 / cnt;                                    // (:656)
+            if (c < 30) {                                            // (:657-658)
+                mu = mean;
+                var = std2;
+            }
+            if (!isfinite(mu)) mu = mean;                            // (:660-661)
+            z = (x - mu) / sqrt(var);                                // (:663-665)
+            if (!isfinite(z)) z = 0.0;                               // (:666)
+            z = z * wgt;                                             // (:667)
+        }
+        orow[i] = z;
+    }
+}
+
+// Branch B (mustache.py:671-685): plain per-diagonal z-score for d < min(dpx, n); other diagonals pass through
+// (after the nan_to_num at :673).
+__global__ void __launch_bounds__(kThreads)
+normalize_global_kernel(const double *__restrict__ band_in, double *__restrict__ band_out, int64_t n, int dlimit,
+                        const double *__restrict__ diag_stats) {
+    const int d = blockIdx.y;
+    const int64_t L = n - d;
+    const double mean = diag_stats[4 * d + 0], sd = diag_stats[4 * d + 1];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double v = i < L ? band_in[(int64_t)d * n + i] : 0.0;
+        if (!isfinite(v)) v = 0.0;
+        if (v != 0.0 && d < dlimit) {
+            v = (v - mean) / sd;
+            if (!isfinite(v)) v = 0.0;
+        }
+        band_out[(int64_t)d * n + i] = v;
+    }
+}
+
+// Dense blocks from the band: one workgroup = one 64x64 pixel tile of one block.
+constexpr int kT = 64;
+
+__global__ void __launch_bounds__(kThreads)
+blocks_from_band_kernel(const double *__restrict__ band, int64_t n, int dpx, const int64_t *__restrict__ starts,
+                        int CH, double *__restrict__ c, uint8_t *__restrict__ nz, uint32_t *__restrict__ nz_count) {
+    __shared__ double tile[(2 * kT - 1) * (kT + 1)];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * kT, c0 = blockIdx.x * kT;
+    const int64_t start = starts[b];
+    double *cb = c + (size_t)b * CH * CH;
+    uint8_t *nb = nz + (size_t)b * CH * CH;
+    const int off_lo = c0 - r0 - (kT - 1), off_hi = c0 - r0 + (kT - 1);   // range of col - row inside the tile
+    const int tid = threadIdx.x;
+    const bool has_data = off_hi >= 0 && off_lo <= dpx + 1;
+    if (has_data) {
+        // tile[(d - off_lo) * (kT+1) + ii] = band[d][start + r0 + ii]; coalesced along ii
+        for (int idx = tid; idx < (2 * kT - 1) * kT; idx += kThreads) {
+            const int dd = idx / kT, ii = idx - dd * kT;
+            const int d = off_lo + dd;
+            const int64_t i = start + r0 + ii;
+            double v = 0.0;
+            if (d >= 0 && d <= dpx + 1 && i >= 0 && i + d < n && r0 + ii < CH) v = band[(int64_t)d * n + i];
+            tile[dd * (kT + 1) + ii] = v;
+        }
+    }
+    __syncthreads();
+    uint32_t local = 0;
+    for (int idx = tid; idx < kT * kT; idx += kThreads) {
+        const int rr = idx / kT, cc = idx - rr * kT;
+        const int row = r0 + rr, col = c0 + cc;
+        if (row >= CH || col >= CH) continue;
+        const int off = col - row;
+        double raw = 0.0;
+        if (has_data && off >= 0 && off <= dpx + 1) raw = tile[(off - off_lo) * (kT + 1) + rr];
+        const bool t = raw != 0.0 && off >= 4;                                   // (:699)
+        const double val = (off <= 4 || off >= dpx + 1) ? 2.0 : raw;             // (:703-706)
+        cb[(size_t)row * CH + col] = val;
+        nb[(size_t)row * CH + col] = t ? 1 : 0;
+        local += t ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
+    if ((tid & 63) == 0 && local) atomicAdd(nz_count + b, local);
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" int mst_band_from_coo(const int64_t *x, const int64_t *y, const double *v, int64_t nnz, int64_t n,
+                                 int32_t dpx, double *band, void *stream) {
+    if (!band || n <= 0 || dpx < 0 || nnz < 0 || (nnz > 0 && (!x || !y || !v)))
+        return mst::fail(MST_E_ARG, "mst_band_from_coo: bad argument");
+    hipStream_t s = mst::as_stream(stream);
+    MST_HIP(hipMemsetAsync(band, 0, sizeof(double) * (size_t)(dpx + 2) * n, s));
+    if (nnz == 0) return MST_OK;
+    int64_t want = (nnz + kThreads - 1) / kThreads;
+    band_scatter_kernel<<<(int)(want < 65536 ? want : 65536), kThreads, 0, s>>>(x, y, v, nnz, n, dpx, band);
+    MST_LAUNCH_CHECK();
+    return MST_OK;
+}
+
+extern "C" int mst_band_to_coo(const double *band, const int64_t *x, const int64_t *y, int64_t nnz, int64_t n,
+                               int32_t dpx, double *v, void *stream) {
+    if (!band || n <= 0 || dpx < 0 || nnz < 0 || (nnz > 0 && (!x || !y || !v)))
+        return mst::fail(MST_E_ARG, "mst_band_to_coo: bad argument");
+    if (nnz == 0) return MST_OK;
+    int64_t want = (nnz + kThreads - 1) / kThreads;
+    band_gather_kernel<<<(int)(want < 65536 ? want : 65536), kThreads, 0, mst::as_stream(stream)>>>(band, x, y, nnz,
+                                                                                                   n, dpx, v);
+    MST_LAUNCH_CHECK();
+    return MST_OK;
+}
+
+extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64_t n, int32_t dpx, int32_t window,
+                                  int32_t local, double *diag_stats, void *stream) {
+    if (!band_in || !band_out || !diag_stats || band_in == band_out || n <= 0 || dpx < 0 || dpx + 2 > 65535)
+        return mst::fail(MST_E_ARG, "mst_normalize_band: bad argument (out of place, dpx + 2 <= 65535)");
+    hipStream_t s = mst::as_stream(stream);
+    const int nd = dpx + 2;
+    diag_stats_kernel<<<nd, kThreads, 0, s>>>(band_in, n, diag_stats);
+    MST_LAUNCH_CHECK();
+    if (local) {
+        if (window < 2 || (size_t)(kSeg + window) * 16 > 160 * 1024)
+            return mst::fail(MST_E_ARG, "mst_normalize_band: window %d outside [2, %d]", window,
+                             160 * 1024 / 16 - kSeg);
+        const size_t lds = sizeof(double) * 2 * (size_t)(kSeg + window);
+        static bool attr_set = false;
+        if (!attr_set) {
+            MST_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&normalize_local_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        // rows are written for i < n - d only; clear the tails so the output band is fully defined
+        MST_HIP(hipMemsetAsync(band_out, 0, sizeof(double) * (size_t)nd * n, s));
+        dim3 grid((unsigned)((n + kSeg - 1) / kSeg), nd);
+        normalize_local_kernel<<<grid, kThreads, lds, s>>>(band_in, band_out, n, window, diag_stats);
+    } else {
+        const int dlimit = (int64_t)dpx < n ? dpx : (int)n;     // range(min(distance_in_px, n))   (:674-675)
+        int64_t want = (n + kThreads - 1) / kThreads;
+        dim3 grid((unsigned)(want < 1024 ? want : 1024), nd);
+        normalize_global_kernel<<<grid, kThreads, 0, s>>>(band_in, band_out, n, dlimit, diag_stats);
+    }
+    MST_LAUNCH_CHECK();
+    return MST_OK;
+}
+
+extern "C" int mst_blocks_from_band(const double *band, int64_t n, int32_t dpx, const int64_t *starts, int32_t B,
+                                    int32_t CH, double *c, uint8_t *nz, uint32_t *nz_count, void *stream) {
+    if (!band || !starts || !c || !nz || !nz_count || n <= 0 || dpx < 0 || B <= 0 || B > 65535 || CH <= 0)
+        return mst::fail(MST_E_ARG, "mst_blocks_from_band: bad argument");
+    hipStream_t s = mst::as_stream(stream);
+    int64_t *d_starts = nullptr;
+    MST_HIP(hipMallocAsync((void **)&d_starts, sizeof(int64_t) * B, s));
+    MST_HIP(hipMemcpyAsync(d_starts, starts, sizeof(int64_t) * B, hipMemcpyHostToDevice, s));
+    MST_HIP(hipMemsetAsync(nz_count, 0, sizeof(uint32_t) * B, s));
+    const int t = (CH + kT - 1) / kT;
+    blocks_from_band_kernel<<<dim3(t, t, B), kThreads, 0, s>>>(band, n, dpx, d_starts, CH, c, nz, nz_count);
+    MST_LAUNCH_CHECK();
+    MST_HIP(hipFreeAsync(d_starts, s));
+    return MST_OK;
+}

@@ -1,0 +1,60 @@
+"""Diagonal-distance normalisation on the GPU (reference mustache/mustache.py:622-686).
+
+Device layout: the diagonal-major band (see csrc/mst_band.hip).  `normalize_band` works on device tensors and is
+what the pipeline uses; `normalize_sparse_device` is the drop-in with the reference's host-array signature."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import _ptr, _stream, require_gpu
+
+
+def band_from_coo(x, y, v, n, dpx):
+    """x, y int64 / v float64 device tensors -> band [dpx+2, n] float64 (device)."""
+    lib = require_gpu()
+    band = torch.empty((dpx + 2, n), dtype=torch.float64, device=v.device)
+    with torch.cuda.device(v.device):
+        _lib.check(lib.mst_band_from_coo(_ptr(x), _ptr(y), _ptr(v), int(v.numel()), int(n), int(dpx), _ptr(band),
+                                         _stream()))
+    return band
+
+
+def band_to_coo(band, x, y, v_out, n, dpx):
+    lib = require_gpu()
+    with torch.cuda.device(band.device):
+        _lib.check(lib.mst_band_to_coo(_ptr(band), _ptr(x), _ptr(y), int(v_out.numel()), int(n), int(dpx),
+                                       _ptr(v_out), _stream()))
+    return v_out
+
+
+def normalize_band(band, n, dpx, resolution):
+    """Returns (normalised band, diag_stats [dpx+2, 4] = mean, std, weight, count).  Branch selection and window
+    size follow mustache.py:628, :631."""
+    lib = require_gpu()
+    local = (n - dpx) * resolution > 2000000
+    window = int(2000000 / resolution)
+    out = torch.empty_like(band)
+    stats = torch.empty((dpx + 2, 4), dtype=torch.float64, device=band.device)
+    with torch.cuda.device(band.device):
+        _lib.check(lib.mst_normalize_band(_ptr(band), _ptr(out), int(n), int(dpx), window, 1 if local else 0,
+                                          _ptr(stats), _stream()))
+    return out, stats, local
+
+
+def normalize_sparse_device(x, y, v, resolution, distance_in_px):
+    """Host COO in, `v` overwritten in place, weights returned -- the reference's call shape."""
+    require_gpu()
+    xh = np.ascontiguousarray(np.asarray(x), dtype=np.int64)
+    yh = np.ascontiguousarray(np.asarray(y), dtype=np.int64)
+    n = int(max(xh.max(), yh.max())) + 1
+    dev = torch.device("cuda:%d" % torch.cuda.current_device())
+    xd, yd = torch.from_numpy(xh).to(dev), torch.from_numpy(yh).to(dev)
+    vd = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(dev)
+    band = band_from_coo(xd, yd, vd, n, distance_in_px)
+    out, stats, local = normalize_band(band, n, distance_in_px, resolution)
+    band_to_coo(out, xd, yd, vd, n, distance_in_px)
+    v[...] = vd.cpu().numpy()
+    st = stats.cpu().numpy()
+    return [float(w) for w in st[:, 2]] if local else []

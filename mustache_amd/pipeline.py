@@ -1,0 +1,103 @@
+"""Per-chromosome pipeline on one GPU (or one rank's share of it): the body of the reference's regulator()
+(mustache/mustache.py:892-937) with every block resident in HBM.
+
+  COO (host) -> device -> band -> normalize_band -> [batches of blocks] blocks_from_band -> fused sigma loop
+  -> found records -> host tail per block -> overlap mask -> (gather across ranks)
+"""
+import ctypes
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import ScaleSpaceEngine, BlockBatch, _ptr, _stream
+from .normalize import band_from_coo, normalize_band
+from .sharding import shard_blocks, gather_loops, world
+from .tail import block_tail
+
+
+def block_tiling(n, distance_in_px):
+    from .mustache import block_tiling as _bt
+    return _bt(n, distance_in_px)
+
+
+def block_mask_size(i, start, end, overlap):
+    from .mustache import block_mask_size as _bm
+    return _bm(i, start, end, overlap)
+
+
+class ChromosomePipeline:
+    def __init__(self, octave_values=(1.6, 3.2), device=None, max_batch_bytes=48 << 30):
+        self.engine = ScaleSpaceEngine(octave_values, device=device)
+        self.device = self.engine.device
+        self.max_batch_bytes = max_batch_bytes
+
+    # ---- device stages --------------------------------------------------------------------------------------------
+    def blocks_from_band(self, band, n, dpx, starts, CH):
+        B = len(starts)
+        c = torch.empty((B, CH, CH), dtype=torch.float64, device=self.device)
+        nz = torch.empty((B, CH, CH), dtype=torch.uint8, device=self.device)
+        nzc = torch.empty(B, dtype=torch.int32, device=self.device)
+        st = (ctypes.c_int64 * B)(*[int(s) for s in starts])
+        with torch.cuda.device(self.device):
+            _lib.check(self.engine.lib.mst_blocks_from_band(_ptr(band), int(n), int(dpx), st, B, CH, _ptr(c),
+                                                            _ptr(nz), _ptr(nzc), _stream()))
+        return c, nz, nzc
+
+    def batches(self, idx, CH):
+        per_block = CH * CH * 9 + max(4096, CH * CH // 32) * 24
+        bs = max(1, int(self.max_batch_bytes // per_block))
+        return [idx[i:i + bs] for i in range(0, len(idx), bs)]
+
+    def run_band(self, band, n, dpx, st, pt, skip_empty=True, distributed=True, timings=None):
+        """band: normalised band on the device.  Returns this chromosome's loops (all ranks, after the gather)."""
+        CH, start, end = block_tiling(n, dpx)
+        rank, ws = world() if distributed else (0, 1)
+        mine = shard_blocks(len(start), rank, ws)
+        loops = []
+        t_dev = t_tail = 0.0
+        for group in self.batches(mine, CH):
+            t0 = time.time()
+            c, nz, nzc = self.blocks_from_band(band, n, dpx, [start[i] for i in group], CH)
+            found, fits = self.engine.sigma_loop(c, nz, nzc, skip_empty=skip_empty)
+            batch = BlockBatch(self.engine, c, nz, CH, len(group),
+                               nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
+            t1 = time.time()
+            for j, i in enumerate(group):
+                mask = block_mask_size(i, start, end, dpx)
+                for lp in block_tail(batch, j, start[i], pt, st, intra=True):
+                    if lp[0] >= start[i] + mask or lp[1] >= start[i] + mask:      # mustache.py:957-959
+                        loops.append([lp[0], lp[1], lp[2], lp[3]])
+            t_dev += t1 - t0
+            t_tail += time.time() - t1
+            del c, nz, batch
+        if timings is not None:
+            timings.update(scale_space_s=t_dev, tail_s=t_tail, blocks=len(mine), chunk=CH,
+                           mpix=len(mine) * CH * CH / 1e6)
+        return gather_loops(loops, device=self.device) if (distributed and ws > 1) else loops
+
+    def run(self, x, y, v, res, dpx, st, pt, normalized=False, verbose=False, skip_empty=True, distributed=True,
+            timings=None):
+        """x, y, v: the reference's host COO.  Every rank reads the same chromosome; normalisation is replicated
+        (cheap on the GPU), blocks are sharded."""
+        x = np.ascontiguousarray(np.asarray(x), dtype=np.int64)
+        y = np.ascontiguousarray(np.asarray(y), dtype=np.int64)
+        v = np.ascontiguousarray(np.asarray(v), dtype=np.float64)
+        n = int(max(x.max(), y.max())) + 1                                       # mustache.py:894
+        t0 = time.time()
+        xd, yd, vd = (torch.from_numpy(a).to(self.device) for a in (x, y, v))
+        band = band_from_coo(xd, yd, vd, n, dpx)
+        del xd, yd, vd
+        if not normalized:
+            if verbose:
+                print("Normalizing contact map...")
+            band, _, _ = normalize_band(band, n, dpx, res)
+        torch.cuda.synchronize(self.device)
+        t1 = time.time()
+        if verbose:
+            print("Loop calling...")
+        loops = self.run_band(band, n, dpx, st, pt, skip_empty=skip_empty, distributed=distributed, timings=timings)
+        if timings is not None:
+            timings["normalize_s"] = t1 - t0
+        return loops

@@ -1,0 +1,47 @@
+"""Multi-GPU sharding of the per-chromosome run: one process per GPU, blocks dealt round-robin, ONE gather of the
+candidate-loop records at the end (reference: one multiprocessing.Process per block + a Manager().list(),
+mustache/mustache.py:913-937).  Blocks share nothing, so there is no data-path collective; the gather payload is a
+few hundred records per rank.  Backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_blocks(nblocks, rank, world_size):
+    """Indices of the blocks rank `rank` owns: i = rank, rank + world, ... (neighbouring blocks differ in nz count
+    only slowly along the chromosome, so round-robin balances the load)."""
+    return list(range(rank, nblocks, world_size))
+
+
+def gather_loops(loops, device=None, group=None):
+    """All ranks pass their list of [x, y, fdr, sigma]; every rank gets the concatenation in rank order
+    (rank 0 writes the TSV).  Two collectives: all_gather of the counts, all_gather of the padded records."""
+    rank, ws = world()
+    if ws == 1:
+        return list(loops)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+    rec = np.zeros((len(loops), 4), dtype=np.float64)
+    for i, lp in enumerate(loops):
+        rec[i] = (float(lp[0]), float(lp[1]), float(lp[2]), float(lp[3]))   # bin indices < 2^53: exact
+    cnt = torch.tensor([len(loops)], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(cnt) for _ in range(ws)]
+    dist.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    mx = max(max(counts), 1)
+    pad = torch.zeros((mx, 4), dtype=torch.float64, device=device)
+    if len(loops):
+        pad[:len(loops)] = torch.from_numpy(rec).to(device)
+    parts = [torch.zeros_like(pad) for _ in range(ws)]
+    dist.all_gather(parts, pad, group=group)
+    out = []
+    for r in range(ws):
+        arr = parts[r][:counts[r]].cpu().numpy()
+        out.extend([[np.int64(a), np.int64(b), np.float64(q), np.float64(s)] for a, b, q, s in arr])
+    return out

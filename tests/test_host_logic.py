@@ -1,0 +1,140 @@
+"""CPU-side tests (no GPU): C-ABI library loads and exports every declared symbol; host logic (tiling, CLI
+helpers, readers, tail, sharding) against the oracle and the reference-generated fixtures."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+OCT = [1.6, 3.2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mustache_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mustache_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|uint64_t|const char \*)\s*\*?\s*(mst_[a-z_0-9]+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 14
+    lib = _lib.load()                      # raises if any bound symbol is missing
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.exported_symbols())
+    assert lib.mst_abi_version() == 1
+
+
+def test_level_table_matches_oracle():
+    import oracle
+    from mustache_amd.levels import LevelTable
+    lt = LevelTable(OCT)
+    lv = oracle.level_table(OCT)
+    assert lt.radius == [l["radius"] for l in lv]
+    assert lt.sigma == [l["sigma"] for l in lv]
+    for a, b in zip(lt.taps, lv):
+        assert np.array_equal(a, b["weights"][b["radius"]:])
+    assert lt.n_tested == 18 and lt.tested_sigma[0] == lv[2]["sigma"] and lt.tested_sigma[-1] == lv[22]["sigma"]
+    with pytest.raises(ValueError):
+        LevelTable([1.6, 3.2, 6.4, 12.8])   # radius > 28: not supported by the kernel, must fail loudly
+
+
+def test_tiling_matches_reference(golden_dir):
+    from mustache_amd.mustache import block_tiling, block_mask_size
+    g = np.load(os.path.join(golden_dir, "tiling.npz"), allow_pickle=True)
+    for i in range(len(g["n"])):
+        n, dpx = int(g["n"][i]), int(g["dpx"][i])
+        chunk, start, end = block_tiling(n, dpx)
+        assert chunk == int(g["chunk"][i]) and start == list(g["starts"][i]) and end == list(g["ends"][i])
+        assert [block_mask_size(b, start, end, dpx) for b in range(len(start))] == list(g["masks"][i])
+
+
+def test_cli_helpers():
+    from mustache_amd.mustache import parseBP, resolve_distance_filter, parse_args, is_chr
+    assert parseBP("5kb") == 5000 and parseBP("1mb") == 1000000 and parseBP("2500") == 2500
+    assert parseBP("kb") is False and parseBP("") is False and parseBP("5xb") is False
+    assert resolve_distance_filter(None, 5000, quiet=True) == 2000000      # mustache.py:1004-1006
+    assert resolve_distance_filter(None, 1000, quiet=True) == 2000000      # 2000 * res
+    assert resolve_distance_filter(None, 25000, quiet=True) == 5000000     # 200 * res
+    assert resolve_distance_filter("100kb", 5000, quiet=True) == 1000000   # clamp to 200 * res
+    assert resolve_distance_filter("90mb", 5000, quiet=True) == 50000000   # clamp to 10000 * res
+    a = parse_args(["-f", "x", "-r", "5kb", "-o", "o.tsv", "-ch", "21"])
+    assert (a.pt, a.st, a.s_z, a.octaves, a.nprocesses) == (0.2, 0.88, 1.6, 2, 4) and a.chromosome == ["21"]
+    assert is_chr("chr21", "21") and is_chr(21, "chr21") and not is_chr("chr2", "21")
+
+
+def test_text_reader(tmp_path):
+    from mustache_amd.mustache import read_pd, read_bias
+    res = 5000
+    f = tmp_path / "c.txt"
+    f.write_text("0\t5000\t10\n5000\t20000\t4\n10000\t10000\t7\n0\t3000000\t9\n15000\t20000\t3\n")
+    b = tmp_path / "b.txt"
+    b.write_text("chr1\t0\t1.0\nchr1\t5000\t2.0\nchr1\t10000\tNaN\nchr1\t15000\t0.1\nchr1\t20000\t0.5\nchr2\t0\t9\n")
+    bias = read_bias(str(b), "1", res)
+    assert bias[0] == 1.0 and bias[1] == 2.0 and np.isinf(bias[2]) and np.isinf(bias[3]) and bias[4] == 0.5
+    assert bias[77] == 1.0
+    x, y, v = read_pd(str(f), 2000000, str(b), "1", res)
+    # row 3 (diagonal at the NaN bin) and row 5 (bias < 0.2) vanish; row 4 is beyond the distance limit
+    assert list(x) == [0, 1] and list(y) == [1, 4] and list(v) == [5.0, 4.0]
+    f5 = tmp_path / "c5.txt"
+    f5.write_text("chr1 0 chr1 5000 10\nchr2 0 chr2 5000 3\nchr1 20000 chr1 5000 4\n")
+    x, y, v = read_pd(str(f5), 2000000, False, "1", res)
+    assert list(x) == [0, 1] and list(y) == [1, 4] and list(v) == [10, 4]
+
+
+class _FakeBatch:
+    """BlockBatch stand-in whose gathers come from host arrays: checks the host tail logic without a GPU."""
+
+    def __init__(self, c, nz, found, levels):
+        from types import SimpleNamespace
+        self.c_h, self.nz_h, self.CH, self.B = c, nz, c.shape[0], 1
+        self.nz_count = [int(nz.sum())]
+        self.found = [found]
+        self.engine = SimpleNamespace(levels=levels)
+
+    def candidate_features(self, b, pixel, half):
+        CH = self.CH
+        c1, c2, cv = [], [], []
+        for p, h in zip(pixel, half):
+            x, y = int(p) // CH, int(p) % CH
+            c1.append(int(np.sum(self.nz_h[x - h:x + h + 1, y - h:y + h + 1])))
+            c2.append(int(np.sum(self.nz_h[x - 2 * h:x + 2 * h + 1, y - 2 * h:y + 2 * h + 1])))
+            cv.append(self.c_h[x, y])
+        return np.array(c1, np.uint32), np.array(c2, np.uint32), np.array(cv)
+
+    def diagonals(self, b, ks):
+        out = np.zeros((len(ks), self.CH))
+        for i, k in enumerate(ks):
+            d = np.diagonal(self.c_h, int(k))
+            out[i, :len(d)] = d
+        return out
+
+
+@pytest.mark.parametrize("name", ["block_320.npz", "block_512.npz"])
+def test_host_tail_vs_reference_fixture(golden_dir, name):
+    import oracle
+    from mustache_amd.levels import LevelTable
+    from mustache_amd.tail import block_tail, benjamini_hochberg
+    g = np.load(os.path.join(golden_dir, name), allow_pickle=True)
+    n, dpx = int(g["n"]), int(g["dpx"])
+    c = np.zeros((n, n))
+    c[g["x"], g["y"]] = g["v"]
+    nz = oracle.block_prologue(c, dpx)
+    ss = oracle.scale_space_levels(c, nz, OCT)
+    fm = ss.pval != 2
+    found = dict(pixel=np.flatnonzero(nz.ravel())[fm].astype(np.uint32), level=ss.level[fm].astype(np.uint32),
+                 value=ss.best[fm], pval=ss.pval[fm])
+    assert np.array_equal(benjamini_hochberg(found["pval"]), g["bh_out"])
+    loops = block_tail(_FakeBatch(c, nz, found, LevelTable(OCT)), 0, int(g["start"]), float(g["pt"]), float(g["st"]))
+    got = np.array([[float(a), float(b), q, s] for a, b, q, s in loops]).reshape(-1, 4)
+    assert np.array_equal(got, g["loops"]), "host tail must reproduce the reference's loops bit for bit, in order"
+
+
+def test_components_match_scipy_label():
+    from scipy.ndimage import label
+    from mustache_amd.tail import _components
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        m = rng.random((40, 40)) < 0.18
+        px, py = np.nonzero(m)
+        order, labels, n = _components(px, py)
+        ref, nref = label(m, structure=np.ones((3, 3)))
+        assert n == nref
+        assert np.array_equal(ref[px[order], py[order]] - 1, labels)

@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- scale-space Mpix/s of the HIP hot path on synthetic banded contact maps (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): the synthetic HFFc6-like chr1 at 1 kb of SURVEY.md section 8d -- n = 248,957 bins,
+distance limit 2,000 bins, 124 overlapping dense blocks of 4000 x 4000 float64 (1,984 Mpix).  One "step" = one
+pass of rows 2-7 of SURVEY.md section 8a over ALL blocks of the chromosome:
+    normalised band resident in HBM -> dense filled blocks + nz mask -> fused sigma-stack / DoG / 3x3 max / sieve /
+    level statistics kernel -> p-values of the found pixels -> compacted found records on the host.
+With N ranks the 124 blocks are dealt round-robin (strong scaling, no data-path collective); the step time is the
+MAX over ranks between two barriers.  `value` = 1,984 Mpix / step time, whole job.
+
+Also reported on the same JSON line:
+  roofline      the fused kernel against the level-streaming HBM model of BASELINE.md (592 B per pixel), timed with
+                HIP events on the launch stream; plus the FP64-VALU view, because the fused kernel keeps all 24
+                levels on chip and is compute-bound
+  cpu_baseline  the CPU oracle (SciPy calls, the reference's own arithmetic) on ONE block of the same workload
+  band_skip     the same step with empty tiles skipped (identical results; reported separately, not as `value`)
+  chr21_5kb     the 5 kb shape (6 blocks of 2000 x 2000) for the second half of the metric's name
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BYTES_PER_PIXEL = 592.0          # BASELINE.md section 3 / SURVEY.md 8d: level-streaming algorithmic traffic, fp64
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6          # FMA-counted vector FP64 peak (256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--small", action="store_true", help="debug: 12 blocks instead of 124")
+    return ap.parse_args()
+
+
+def make_band(n, dpx, depth, nloops, seed, res, device):
+    """Synthetic chromosome -> normalised band on `device` (input preparation, not timed)."""
+    import torch
+    from mustache_amd.synth import band_counts
+    from mustache_amd.normalize import normalize_band
+    cols = 16384
+    raw = torch.empty((dpx + 2, n), dtype=torch.float64, device=device)
+    for i0 in range(0, n, cols):                      # generated in column slabs to bound temporaries
+        i1 = min(n, i0 + cols)
+        raw[:, i0:i1] = band_counts(n, dpx, depth, nloops, seed, i0=i0, i1=i1, device=device)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    band, _, _ = normalize_band(raw, n, dpx, res)
+    torch.cuda.synchronize()
+    return band, time.time() - t0
+
+
+class Workload:
+    def __init__(self, name, n, dpx, res, depth, nloops, seed, device, rank, world):
+        from mustache_amd.pipeline import ChromosomePipeline, block_tiling
+        from mustache_amd.sharding import shard_blocks
+        self.name, self.n, self.dpx, self.res = name, n, dpx, res
+        self.pipe = ChromosomePipeline((1.6, 3.2), device=device)
+        self.band, self.normalize_s = make_band(n, dpx, depth, nloops, seed, res, device)
+        self.CH, self.start, self.end = block_tiling(n, dpx)
+        self.mine = shard_blocks(len(self.start), rank, world)
+        self.total_mpix = len(self.start) * self.CH * self.CH / 1e6
+        self.kernel_ms = []
+
+    def step(self, skip_empty=False, download=True):
+        """rows 2-7 for this rank's blocks; returns (found records per block, kernel event pair)."""
+        import torch
+        pipe = self.pipe
+        out = []
+        for group in pipe.batches(self.mine, self.CH):
+            c, nz, nzc = pipe.blocks_from_band(self.band, self.n, self.dpx, [self.start[i] for i in group], self.CH)
+            res = pipe.engine.sigma_loop(c, nz, nzc, skip_empty=skip_empty, download=download, timing=self.kernel_ms)
+            out.append(res)
+        return out
+
+
+def cpu_baseline(w, block_index):
+    """The oracle (reference arithmetic: SciPy gaussian_filter / maximum_filter / expm1) on one block, 1 core."""
+    import numpy as np
+    import oracle
+    s = w.start[block_index]
+    CH, dpx = w.CH, w.dpx
+    slab = w.band[:, s:s + CH].cpu().numpy()
+    c = np.zeros((CH, CH))
+    r = np.arange(CH)
+    for d in range(dpx + 2):
+        L = CH - d
+        c[r[:L], r[:L] + d] = slab[d, :L]
+    t0 = time.time()
+    nz = oracle.block_prologue(c, dpx)
+    ss = oracle.scale_space_levels(c, nz, [1.6, 3.2], blur="scipy")
+    dt = time.time() - t0
+    return dt, int((ss.pval != 2).sum()), int(nz.sum())
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n = 248957 if not args.small else 4000 + 11 * 2000
+    w = Workload("chr1@1kb synthetic (n=%d, dpx=2000, %s blocks of 4000x4000 fp64)", n, 2000, 1000, 400.0,
+                 8000 if not args.small else 800, 1, device, rank, world)
+    w.name = w.name % (n, len(w.start))
+
+    def timed(skip_empty, steps, warmup):
+        for _ in range(warmup):
+            w.step(skip_empty)
+        w.kernel_ms.clear()
+        barrier()
+        t0 = time.time()
+        for _ in range(steps):
+            last = w.step(skip_empty)
+        barrier()
+        dt = time.time() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kms = [a.elapsed_time(b) for a, b in w.kernel_ms]
+        return float(t.item()), kms, last
+
+    dt, kms, last = timed(False, args.steps, args.warmup)
+    ms_per_step = dt / args.steps * 1e3
+    value = w.total_mpix / (dt / args.steps)
+
+    # roofline of the dominant kernel (rank 0's launches): algorithmic bytes per launch / event-timed duration
+    launches_per_step = max(1, len(kms) // args.steps)
+    k_ms = sum(kms) / len(kms)
+    px_per_launch = len(w.mine) * w.CH * w.CH / launches_per_step
+    achieved_gbs = px_per_launch * BYTES_PER_PIXEL / (k_ms * 1e-3) / 1e9
+    flops_px = 1152.0                       # non-fusable fp64 flops per pixel of the 24 blurs
+    roof = {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "scale_space_kernel<Tile<64,14>>", "kernel_ms": round(k_ms, 3),
+            "pixels_per_launch": int(px_per_launch), "bytes_per_pixel_model": BYTES_PER_PIXEL,
+            "fp64_view": {"blur_flops_per_pixel": flops_px,
+                          "achieved_tflops": round(px_per_launch * flops_px / (k_ms * 1e-3) / 1e12, 2),
+                          "peak_tflops_no_fma": FP64_PEAK_TFLOPS / 2,
+                          "note": "taps cannot be fused into FMAs (bit-exactness with SciPy), so the usable peak is "
+                                  "half the FMA-counted 78.6 TFLOP/s; halo/redundant work is not counted"}}
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            roof["traffic"] = json.load(open(pmc)).get("bytes_per_launch")
+        except Exception:
+            pass
+
+    # the same step with empty tiles skipped (separate speed-up, never folded into `value`)
+    dt_s, kms_s, _ = timed(True, max(1, args.steps // 2), 1)
+    band_skip = {"value": round(w.total_mpix / (dt_s / max(1, args.steps // 2)), 1), "unit": "Mpix/s",
+                 "speedup": round((dt / args.steps) / (dt_s / max(1, args.steps // 2)), 3),
+                 "kernel_ms": round(sum(kms_s) / len(kms_s), 3)}
+
+    out = {"metric": "scale-space Mpix/s (sigma-stack+local-max)", "value": round(value, 1), "unit": "Mpix/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": w.name, "blocks": len(w.start), "chunk": w.CH, "distance_px": w.dpx,
+                      "megapixels_per_step": round(w.total_mpix, 1), "sharding": "blocks round-robin over %d rank(s)" % world,
+                      "timed_region": "normalised band in HBM -> blocks -> fused sigma loop -> found records on host"},
+           "roofline": roof, "band_skip": band_skip,
+           "normalize_ms_untimed": round(w.normalize_s * 1e3, 1)}
+
+    if rank == 0 and world == 1:
+        # second half of the metric's name: chr21 @ 5 kb on 1 GPU (6 blocks of 2000 x 2000), same timed region
+        w5 = Workload("chr21@5kb synthetic", 9630, 400, 5000, 300.0, 300, 0, device, 0, 1)
+        for _ in range(3):
+            w5.step(False)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(10):
+            w5.step(False)
+        torch.cuda.synchronize()
+        out["chr21_5kb"] = {"value": round(w5.total_mpix / ((time.time() - t0) / 10), 1), "unit": "Mpix/s",
+                            "blocks": len(w5.start), "chunk": w5.CH}
+        del w5
+    if rank == 0 and world == 1 and not args.no_cpu:
+        bi = len(w.start) // 2
+        cpu_s, cpu_found, cpu_nz = cpu_baseline(w, bi)
+        found_gpu = None
+        for grp, res in zip(w.pipe.batches(w.mine, w.CH), last):
+            if bi in grp:
+                found_gpu = len(res[0][grp.index(bi)]["pixel"])
+        out["cpu_baseline"] = {"value": round(w.CH * w.CH / 1e6 / cpu_s, 4), "unit": "Mpix/s", "cores": 1,
+                               "kind": "port",
+                               "sample": "block %d of the same workload (one 4000x4000 block, %.1f s), rows 3-7 of the "
+                                         "oracle = the reference's SciPy calls, single process" % (bi, cpu_s),
+                               "found_pixels_cpu": cpu_found, "found_pixels_gpu": found_gpu,
+                               "cpu_model": _cpu_model(), "host_cores": os.cpu_count()}
+        out["speedup_vs_cpu_1core"] = round(value / out["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    main()

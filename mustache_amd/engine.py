@@ -75,6 +75,8 @@ class ScaleSpaceEngine:
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.levels = LevelTable(octave_values, s)
         self._lv_struct = self.levels.as_struct()
+        self._found_cap = {}
+        self._pin = {}
 
     # ---- row 2: COO -> dense blocks ---------------------------------------------------------------------------
     def scatter_blocks(self, x, y, v, starts, CH):
@@ -109,12 +111,14 @@ class ScaleSpaceEngine:
                                                    1 if intra else 0, _stream()))
         return nz, nz_count
 
-    def sigma_loop(self, c, nz, nz_count, skip_empty=True, found_cap=None, download=True):
-        """The fused kernel + p-values.  Returns (found_dev, pval_dev, count_dev, fit_dev) or host copies."""
+    def sigma_loop(self, c, nz, nz_count, skip_empty=True, found_cap=None, download=True, timing=None):
+        """The fused kernel + p-values.  Returns host records (download=True) or the device buffers.
+        `timing`: optional list; receives a (start, end) torch.cuda.Event pair bracketing the mst_scale_space launch
+        on the launch stream."""
         B, CH, _ = c.shape
         nt = self.levels.n_tested
         if found_cap is None:
-            found_cap = max(4096, (CH * CH) // 32)
+            found_cap = self._found_cap.get(CH, max(4096, (CH * CH) // 32))
         lv = ctypes.byref(self._lv_struct)
         ws_bytes = int(self.lib.mst_scale_space_workspace_bytes(B, CH, lv))
         with torch.cuda.device(self.device):
@@ -125,37 +129,69 @@ class ScaleSpaceEngine:
             while True:
                 found = torch.empty((B, found_cap, 2), dtype=torch.int64, device=self.device)  # 16-byte records
                 pval = torch.empty((B, found_cap), dtype=torch.float64, device=self.device)
+                if timing is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 _lib.check(self.lib.mst_scale_space(_ptr(c), _ptr(nz), B, CH, lv, _ptr(found), found_cap,
                                                     _ptr(count), _ptr(stats), 1 if skip_empty else 0, _ptr(ws),
                                                     ws_bytes, _stream()))
+                if timing is not None:
+                    e1.record()
                 try:
                     _lib.check(self.lib.mst_found_pvalues(_ptr(found), found_cap, _ptr(count), _ptr(nz_count),
                                                           _ptr(stats), B, nt, _ptr(pval), _ptr(fit), _stream()))
                     break
                 except _lib.MstOverflow:
                     found_cap *= 4          # rare: a block with an unusually dense set of local maxima
+                    self._found_cap[CH] = found_cap
+            if timing is not None:
+                timing.append((e0, e1))     # mst_found_pvalues synchronised the stream: the events are complete
         if not download:
             return found, pval, count, fit, found_cap
         return self._download(found, pval, count, fit, nt)
 
-    @staticmethod
-    def _download(found, pval, count, fit, nt):
-        cnt = count.cpu().numpy().astype(np.int64)
+    def _pinned(self, key, shape, dtype):
+        """Cached page-locked host staging buffers: D2H of the found records runs at PCIe rate, not pageable rate."""
+        need = int(np.prod(shape))
+        buf = self._pin.get(key)
+        if buf is None or buf.numel() < need or buf.dtype != dtype:
+            buf = self._pin[key] = torch.empty(max(need, 1), dtype=dtype, pin_memory=True)
+        return buf[:need].view(*shape)
+
+    def _download(self, found, pval, count, fit, nt):
+        """Order every block's records by pixel index (row-major = the reference's nz order) on the device, then
+        one pinned copy per array."""
+        cnt_d = count.to(torch.int64)
+        cnt = cnt_d.cpu().numpy()
         fit_h = fit.cpu().numpy()
         B = len(cnt)
         mx = int(cnt.max()) if B else 0
-        rec = found[:, :mx].cpu().numpy()          # [B, mx, 2] int64 = {pixel u32 | level u32, value bits}
-        pv = pval[:, :mx].cpu().numpy()
         out, fits = [], []
+        if mx > 0:
+            rec = found[:, :mx]
+            pix = rec[..., 0] & 0xFFFFFFFF
+            valid = torch.arange(mx, device=found.device)[None, :] < cnt_d[:, None]
+            order = torch.argsort(torch.where(valid, pix, torch.full_like(pix, 1 << 40)), dim=1)
+            rec_s = torch.gather(rec, 1, order[..., None].expand(-1, -1, 2))
+            pv_s = torch.gather(pval[:, :mx], 1, order)
+            rec_h = self._pinned("rec", (B, mx, 2), torch.int64)
+            pv_h = self._pinned("pv", (B, mx), torch.float64)
+            rec_h.copy_(rec_s, non_blocking=True)
+            pv_h.copy_(pv_s, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            rec_n, pv_n = rec_h.numpy(), pv_h.numpy()
         for b in range(B):
             m = int(cnt[b])
-            word = rec[b, :m, 0].view(np.uint64)
-            pixel = (word & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-            level = (word >> np.uint64(32)).astype(np.uint32)
-            value = rec[b, :m, 1].view(np.float64)
-            order = np.argsort(pixel, kind="stable")      # row-major = the reference's nz order
-            out.append(dict(pixel=pixel[order], level=level[order], value=value[order].copy(),
-                            pval=pv[b, :m][order].copy()))
+            if m:
+                word = rec_n[b, :m, 0].view(np.uint64)
+                pixel = (word & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+                level = (word >> np.uint64(32)).astype(np.uint32)
+                value = rec_n[b, :m, 1].view(np.float64).copy()
+                pv = pv_n[b, :m].copy()
+            else:
+                pixel = level = np.zeros(0, np.uint32)
+                value = pv = np.zeros(0)
+            out.append(dict(pixel=pixel, level=level, value=value, pval=pv))
             fits.append((fit_h[b, :nt, 0].copy(), fit_h[b, :nt, 1].copy()))
         return out, fits
 

@@ -10,23 +10,32 @@
 // 24 full-image blurs, 22 DoG images, 22 max images, ~10 boolean gathers per level: ~600 B of HBM traffic per
 // pixel if every level is materialised.
 //
-// What this kernel does instead: one workgroup owns a 62x62-pixel tile (64x64 with the 1-pixel ring the 3x3 max
-// needs).  It loads the tile of c with a 14-pixel reflect halo into LDS ONCE (~12 B/pixel of HBM reads), then
-// walks all 24 levels out of LDS:
-//   V pass  (axis 0): each thread produces 8 vertically consecutive samples of one column from a register window
-//                     of 8+2r taps (lanes run along columns -> conflict-free ds_read_b64), result -> LDS `vb`
-//   H pass  (axis 1): each thread produces 8 horizontally consecutive samples of one row (lanes run along rows, odd
-//                     LDS pitch -> conflict-free), result stays in registers
-//   DoG, 3x3 zero-padded max through a small LDS tile `db`, the 5-term sieve and the running best/level per pixel
-//   stay in registers across all levels and both octaves; per-level min / sum of |D_c| are reduced per workgroup.
-// Only the found pixels (~0.5 % of the block) and 2 x 18 partial statistics per tile are written back.
-// The kernel is therefore FP64-VALU bound (~1150 non-fusable flops per pixel for the blurs alone), not HBM bound.
+// What this kernel does instead: one 256-thread workgroup owns a 30 x 62 pixel tile (a 32 x 64 "region" with the
+// 1-pixel ring the 3x3 max needs).  It loads the tile of c with a 14-pixel reflect halo into LDS ONCE (~15 B/pixel
+// of HBM/L2 reads), then walks all 24 levels out of LDS:
+//   V pass  (axis 0): a thread produces 8 vertically consecutive samples of one column from a register window of
+//                     8+2r samples (c tile stored transposed -> the window is contiguous, read as ds_read_b128;
+//                     lanes run along columns with a pitch of 30 mod 32 doubles -> conflict-free), result -> LDS vb
+//   H pass  (axis 1): a thread produces 8 horizontally consecutive samples of one row (same access pattern on vb),
+//                     result stays in registers
+//   DoG in registers; zero-padded 3x3 max = horizontal 3-max in registers (2 edge samples through a 4 KB LDS strip)
+//   then vertical 3-max across lanes with DPP wave shifts (lanes of a wave are consecutive rows); the 5-term sieve
+//   and the running best/level per pixel live in registers across all levels and both octaves; per-level min / sum
+//   of |D_c| are reduced per workgroup in a fixed order.
+// Only the found pixels (~1 % of the block) and 2 x 18 partial statistics per tile are written back.
+// 77 KB of LDS per workgroup -> two independent workgroups per CU, so one's LDS window loads overlap the other's
+// FP64 work instead of every wave of the CU alternating between the two in barrier lock-step.
+// The kernel is FP64-VALU bound (~1150 non-fusable flops per pixel for the blurs alone), not HBM bound.
 //
 // Bit-exactness: the tap order is SciPy's C correlate1d on a symmetric kernel,
 //     t = x[c]*w0;  for j = r..1:  t += (x[c-j] + x[c+j]) * w[j]
 // axis 0 first, float64 intermediate, mode='reflect'; compiled with -ffp-contract=off so no FMA is formed.
 // The taps themselves come from the host (NumPy), see mustache_amd/levels.py.
+// Build flags for this file add -fno-honor-nans -mno-amdgpu-ieee: inputs are finite (checked through the level
+// statistics), and with IEEE mode off v_max_f64 needs no canonicalising pre-pass; no value-changing fast-math
+// flag (reassociation, contraction, reciprocal) is enabled.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include "mst_common.h"
 
@@ -40,24 +49,36 @@ struct DevLevels {
     double taps[MST_MAX_LEVELS][MST_MAX_RADIUS + 1];
 };
 
-template <int RG_, int RMAX_>
+constexpr int pitch_for(int need) {
+    // Window loads are 16-byte ds_read_b128 (full LDS rate; ds_read2_b64 runs at half).  With lanes striding whole
+    // rows, a pitch of 2 or 30 (mod 32) doubles keeps those loads 16-byte aligned AND bank-conflict free: the 16
+    // lanes of a b128 group then start at dword offsets 0, +-4, +-8, ... (mod 64), one 4-dword slot each.
+    int p = need;
+    while (p % 32 != 2 && p % 32 != 30) ++p;
+    return p;
+}
+
+template <int RGR_, int RGC_, int RMAX_>
 struct Tile {
-    static constexpr int RG = RG_;                // region edge: interior + 1-pixel ring for the 3x3 max
-    static constexpr int IT = RG_ - 2;            // interior (owned) pixels per edge
+    static constexpr int RGR = RGR_, RGC = RGC_;  // region rows / cols: interior + 1-pixel ring for the 3x3 max
+    static constexpr int ITR = RGR_ - 2, ITC = RGC_ - 2;   // interior (owned) pixels
     static constexpr int RMAX = RMAX_;            // largest blur radius this instantiation supports
     static constexpr int K = 8;                   // samples per thread along the filter axis
-    static constexpr int NT = RG * RG / K;        // threads per workgroup
+    static constexpr int NCG = RGC / K;           // column groups
+    static constexpr int NT = RGR * NCG;          // threads per workgroup
     static constexpr int NW = NT / 64;            // waves per workgroup
-    static constexpr int CT = RG + 2 * RMAX;      // edge of the c tile held in LDS
-    static constexpr int CTP = CT | 1;            // odd pitches: conflict-free for lanes along rows or columns
-    static constexpr int VP = (RG + 2 * RMAX) | 1;
-    static constexpr int DP = RG | 1;
-    static constexpr int CT_ELEMS = CT * CTP;
-    static constexpr int VB_ELEMS = RG * VP;
-    static constexpr int DB_ELEMS = RG * DP;
+    static constexpr int CTR = RGR + 2 * RMAX;    // c tile rows / cols held in LDS (stored TRANSPOSED: ct[col][row])
+    static constexpr int CTC = RGC + 2 * RMAX;
+    static constexpr int CTP = pitch_for(CTR);
+    static constexpr int VP = pitch_for(RGC + 2 * RMAX);
+    static constexpr int CT_ELEMS = CTC * CTP;
+    static constexpr int VB_ELEMS = RGR * VP;
+    static constexpr int DE_ELEMS = NCG * 2 * RGR;           // edge strip: [cg][left/right][row]
     static constexpr int ST_ELEMS = MST_MAX_TESTED * NW * 2;
-    static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)(CT_ELEMS + VB_ELEMS + DB_ELEMS + ST_ELEMS);
-    static_assert(NT % 64 == 0, "whole waves");
+    static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)(CT_ELEMS + VB_ELEMS + DE_ELEMS + ST_ELEMS);
+    static_assert(NT % 64 == 0 && RGR % K == 0 && RGC % K == 0, "whole waves, whole groups");
+    static_assert(64 % RGR == 0 || RGR % 64 == 0, "a wave holds whole runs of consecutive rows");
+    static_assert(CTP % 2 == 0 && VP % 2 == 0 && CT_ELEMS % 2 == 0 && VB_ELEMS % 2 == 0, "16-byte alignment");
 };
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
@@ -67,15 +88,84 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i < n ? i : p - 1 - i;
 }
 
-__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
+__device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }
 
-// Axis-0 pass for radius R over the (RG rows) x (RG + 2R columns) strip the axis-1 pass will need.
+// value held by the previous / next lane (lane 0 / 63 keep their own): DPP wave shifts, no LDS traffic
+__device__ __forceinline__ double lane_prev(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_next(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// K output samples from a register window of K + 2R input samples, SciPy's order per sample:
+//     t = x[c]*w0;  for j = R..1:  t += (x[c-j] + x[c+j]) * w[j]
+// The K accumulation chains are independent; the loops are written tap-major so the K adds / muls / adds of one
+// tap are adjacent in program order and the FP64 pipe always has K independent instructions to issue (a
+// sample-major order leaves one serial add->mul->add chain per sample and stalls on every instruction).
+template <int K, int R>
+__device__ __forceinline__ void fir_sym(const double (&win)[K + 2 * R], const double (&w)[R + 1], double (&t)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) t[k] = win[k + R] * w[0];
+#pragma unroll
+    for (int j = R; j >= 1; --j) {
+        double s[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) s[k] = win[k + R - j] + win[k + R + j];
+#pragma unroll
+        for (int k = 0; k < K; ++k) s[k] = s[k] * w[j];
+#pragma unroll
+        for (int k = 0; k < K; ++k) t[k] = t[k] + s[k];
+    }
+}
+
+// Outputs per register window: 8 for small radii; for the widest kernels the 8 outputs are produced as two windows
+// of 4 so window + accumulators + the per-pixel sieve state stay inside the 256-VGPR budget.
+template <int R>
+struct Chunk {
+    static constexpr int KC = (R >= 11) ? 4 : 8;
+};
+
+// N doubles (N even) from a 16-byte aligned LDS address as ds_read_b128.
+template <int N>
+__device__ __forceinline__ void load_window(const double *__restrict__ p, double (&win)[N]) {
+    static_assert(N % 2 == 0, "pairs");
+    const double2 *p2 = reinterpret_cast<const double2 *>(p);
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+        const double2 v = p2[i];
+        win[2 * i] = v.x;
+        win[2 * i + 1] = v.y;
+    }
+}
+
+// One FIR chunk: KC outputs whose first tap sits at p[off]; p is 16-byte aligned, off is 0 or 1.
+template <int KC, int R, int OFF>
+__device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const double (&w)[R + 1], double (&t)[KC]) {
+    constexpr int WN = (KC + 2 * R + OFF + 1) & ~1;
+    double raw[WN];
+    load_window<WN>(p, raw);
+    double win[KC + 2 * R];
+#pragma unroll
+    for (int i = 0; i < KC + 2 * R; ++i) win[i] = raw[i + OFF];
+    fir_sym<KC, R>(win, w, t);
+}
+
+// Axis-0 pass for radius R over the (RGR rows) x (RGC + 2R columns) strip the axis-1 pass will need.  The c tile is
+// stored transposed (ct[col][row]), so a thread's window of consecutive rows is contiguous in LDS.
 template <class T, int R>
 __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__restrict__ vb,
                                       const double *__restrict__ wg, int tid) {
-    constexpr int K = T::K;
-    constexpr int NC = T::RG + 2 * R;
-    constexpr int NITEM = (T::RG / K) * NC;
+    constexpr int K = T::K, KC = Chunk<R>::KC;
+    constexpr int NC = T::RGC + 2 * R;
+    constexpr int NITEM = (T::RGR / K) * NC;
+    constexpr int OFF = (T::RMAX - R) & 1;           // parity of the first tap's row index (row0, h*KC are even)
     double w[R + 1];
 #pragma unroll
     for (int j = 0; j <= R; ++j) w[j] = wg[j];
@@ -83,17 +173,14 @@ __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__r
         const int rgp = it / NC;
         const int col = it - rgp * NC;
         const int row0 = rgp * K;
-        const double *p = ct + (row0 + T::RMAX - R) * T::CTP + (T::RMAX - R) + col;
-        double win[K + 2 * R];
-#pragma unroll
-        for (int i = 0; i < K + 2 * R; ++i) win[i] = p[i * T::CTP];
+        const double *p = ct + ((T::RMAX - R) + col) * T::CTP + (row0 + T::RMAX - R - OFF);
         double *q = vb + row0 * T::VP + col;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            double t = win[k + R] * w[0];
+        for (int h = 0; h < K / KC; ++h) {
+            double t[KC];
+            fir_chunk<KC, R, OFF>(p + h * KC, w, t);
 #pragma unroll
-            for (int j = R; j >= 1; --j) t = t + (win[k + R - j] + win[k + R + j]) * w[j];
-            q[k * T::VP] = t;
+            for (int k = 0; k < KC; ++k) q[(h * KC + k) * T::VP] = t[k];
         }
     }
 }
@@ -102,20 +189,17 @@ __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__r
 template <class T, int R>
 __device__ __forceinline__ void hpass(const double *__restrict__ vb, const double *__restrict__ wg, int rr, int cg,
                                       double (&g)[T::K]) {
-    constexpr int K = T::K;
+    constexpr int K = T::K, KC = Chunk<R>::KC;
     double w[R + 1];
 #pragma unroll
     for (int j = 0; j <= R; ++j) w[j] = wg[j];
     const double *p = vb + rr * T::VP + cg * K;
-    double win[K + 2 * R];
 #pragma unroll
-    for (int i = 0; i < K + 2 * R; ++i) win[i] = p[i];
+    for (int h = 0; h < K / KC; ++h) {
+        double t[KC];
+        fir_chunk<KC, R, 0>(p + h * KC, w, t);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        double t = win[k + R] * w[0];
-#pragma unroll
-        for (int j = R; j >= 1; --j) t = t + (win[k + R - j] + win[k + R + j]) * w[j];
-        g[k] = t;
+        for (int k = 0; k < KC; ++k) g[h * KC + k] = t[k];
     }
 }
 
@@ -148,31 +232,31 @@ template <class T>
 __global__ void __launch_bounds__(T::NT)
 scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz, int CH,
                    const DevLevels *__restrict__ lv, mst_found *__restrict__ found, uint32_t found_cap,
-                   uint32_t *__restrict__ found_count, double *__restrict__ partial, int tiles_per_dim,
-                   int n_tested, int skip_empty) {
-    constexpr int K = T::K, RG = T::RG, IT = T::IT, RMAX = T::RMAX;
+                   uint32_t *__restrict__ found_count, double *__restrict__ partial, int tiles_x, int tiles_y,
+                   int n_tested, int skip_empty, int variant) {
+    constexpr int K = T::K, RGR = T::RGR, RGC = T::RGC, RMAX = T::RMAX;
     extern __shared__ __align__(16) double lds[];
     double *ct = lds;
     double *vb = ct + T::CT_ELEMS;
-    double *db = vb + T::VB_ELEMS;
-    double *st = db + T::DB_ELEMS;
+    double *de = vb + T::VB_ELEMS;
+    double *st = de + T::DE_ELEMS;
 
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-    const int ntiles = tiles_per_dim * tiles_per_dim;
+    const int ntiles = tiles_x * tiles_y;
     // XCD-aware order: hardware places workgroup i on XCD i % 8 (gridDim.x is a multiple of 8), so give each XCD a
-    // contiguous run of tiles -- neighbouring tiles share their halo rows through that XCD's L2.
+    // contiguous run of tiles -- neighbouring tiles share their halo through that XCD's L2.
     const int per_xcd = gridDim.x >> 3;
     const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (tile >= ntiles) return;
-    const int ty = tile / tiles_per_dim, tx = tile - ty * tiles_per_dim;
-    const int y0 = ty * IT - 1, x0 = tx * IT - 1;  // block coordinates of region (0, 0)
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int y0 = ty * T::ITR - 1, x0 = tx * T::ITC - 1;  // block coordinates of region (0, 0)
 
-    const int rr = tid % RG;  // region row owned in the H pass (lane index when RG == 64)
-    const int cg = tid / RG;  // column group
+    const int rr = tid % RGR;  // region row owned in the H pass; consecutive lanes = consecutive rows
+    const int cg = tid / RGR;  // column group
     const int gy = y0 + rr;
     const bool row_in = gy >= 0 && gy < CH;
-    const bool row_own = row_in && rr >= 1 && rr <= IT;
+    const bool row_own = row_in && rr >= 1 && rr <= T::ITR;
     const double *cb = c + (size_t)b * CH * CH;
     const uint8_t *nb = nz + (size_t)b * CH * CH;
     double *part = partial + ((size_t)b * ntiles + tile) * n_tested * 2;
@@ -184,7 +268,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
         const int gx = x0 + rc;
         const bool col_in = gx >= 0 && gx < CH;
         if (row_in && col_in) in_mask |= 1u << k;
-        if (row_own && col_in && rc >= 1 && rc <= IT && nb[(size_t)gy * CH + gx]) nz_mask |= 1u << k;
+        if (row_own && col_in && rc >= 1 && rc <= T::ITC && nb[(size_t)gy * CH + gx]) nz_mask |= 1u << k;
     }
     const int any_nz = __syncthreads_or(nz_mask != 0);
     if (!any_nz && skip_empty) {
@@ -195,25 +279,30 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
         return;
     }
 
-    // ---- stage the c tile (reflect halo) in LDS: the only bulk HBM read of the kernel
-    for (int idx = tid; idx < T::CT * T::CT; idx += T::NT) {
-        const int i = idx / T::CT, j = idx - i * T::CT;
+    // ---- stage the c tile (reflect halo) in LDS, transposed: the only bulk HBM/L2 read of the kernel
+    for (int idx = tid; idx < T::CTR * T::CTC; idx += T::NT) {
+        const int i = idx / T::CTC, j = idx - i * T::CTC;
         const int sy = reflect_idx(y0 - RMAX + i, CH);
         const int sx = reflect_idx(x0 - RMAX + j, CH);
-        ct[i * T::CTP + j] = cb[(size_t)sy * CH + sx];
+        ct[j * T::CTP + i] = cb[(size_t)sy * CH + sx];
     }
     __syncthreads();
 
-    double gprev[K], Mp[K], Dc[K], Mc[K], best[K];
+    // per-pixel rolling state across levels.  For the tested level c the sieve needs
+    //   D_c == M_c (ec),  D_{c-1} == M_{c-1} (ep),  D_c > M_{c-1} (gp),  and against the incoming level D_c > M_{c+1};
+    // the first three are decided when their level arrives and kept as one bit per pixel.
+    double gprev[K], Dc[K], Mc[K], best[K];
     uint32_t lvl[K];
-    uint32_t ep = 0, ec = 0;
+    uint32_t ep = 0, ec = 0, gp = 0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        gprev[k] = Mp[k] = Dc[k] = Mc[k] = best[k] = 0.0;
+        gprev[k] = Dc[k] = Mc[k] = best[k] = 0.0;
         lvl[k] = 0;
     }
-    const int rr_m = rr > 0 ? rr - 1 : 0, rr_p = rr < RG - 1 ? rr + 1 : RG - 1;
     const int wave = tid >> 6, lane = tid & 63;
+    double *de_mine = de + (cg * 2) * RGR + rr;                                   // [cg][0 = left edge, 1 = right edge][rr]
+    const double *de_left = de + ((cg > 0 ? cg - 1 : 0) * 2 + 1) * RGR + rr;      // left neighbour's right edge
+    const double *de_right = de + ((cg < T::NCG - 1 ? cg + 1 : cg) * 2) * RGR + rr;  // right neighbour's left edge
 
     const int n_oct = lv->n_octaves, lpo = lv->levels_per_octave;
     int tested = 0;
@@ -229,41 +318,42 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
                 for (int k = 0; k < K; ++k) {
                     d[k] = gprev[k] - g[k];
                     if (!((in_mask >> k) & 1u)) d[k] = 0.0;  // maximum_filter pads with zeros outside the block
-                    db[rr * T::DP + cg * K + k] = d[k];
                 }
+                de_mine[0] = d[0];
+                de_mine[RGR] = d[K - 1];
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) gprev[k] = g[k];
-            __syncthreads();
+            __syncthreads();   // edge strip visible; every H-pass read of vb is done before the next V pass writes it
             if (kl < 2) continue;
+            if (variant & 1) continue;     // [timing ablation] blur + DoG only
 
-            // zero-padded 3x3 max at the owned pixels: column maxima over 3 rows, then over 3 columns
-            double cm[K + 2];
+            // zero-padded 3x3 max at the owned pixels: 3-max along the row in registers, then across rows via lane shifts
+            const double dl = de_left[0], dr = de_right[0];
+            double hm[K];
 #pragma unroll
-            for (int j = 0; j < K + 2; ++j) {
-                int col = cg * K + j - 1;
-                col = col < 0 ? 0 : (col > RG - 1 ? RG - 1 : col);
-                const double a = db[rr_m * T::DP + col];
-                const double bb = db[rr * T::DP + col];
-                const double cc = db[rr_p * T::DP + col];
-                cm[j] = dmax(dmax(a, bb), cc);
+            for (int k = 0; k < K; ++k) {
+                const double a = k == 0 ? dl : d[k - 1];
+                const double bb = k == K - 1 ? dr : d[k + 1];
+                hm[k] = dmax(dmax(a, d[k]), bb);
             }
-            uint32_t en = 0;
+            uint32_t en = 0, gn = 0;   // en: D_new == M_new;  gn: D_new > M_prev (M of the level before it)
             double m[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                m[k] = dmax(dmax(cm[k], cm[k + 1]), cm[k + 2]);
+                m[k] = dmax(dmax(lane_prev(hm[k]), hm[k]), lane_next(hm[k]));
                 if (d[k] == m[k]) en |= 1u << k;
+                if (d[k] > Mc[k]) gn |= 1u << k;
             }
             if (kl >= 4) {
-                // tested level = D_{kl-2}: previous = D_{kl-3} (ep, Mp), current (Dc, Mc, ec), next = this one (d, m, en)
+                // tested level = D_{kl-2}: previous = D_{kl-3} (ep), current (Dc, ec, gp), next = this one (m, en)
                 double lmin = INFINITY, lsum = 0.0;
                 const uint32_t code = (uint32_t)tested + 1u;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const bool tz = (nz_mask >> k) & 1u;
                     const bool upd = tz && (Dc[k] > best[k]) && ((ec >> k) & 1u) && (((ep | en) >> k) & 1u) &&
-                                     (Dc[k] > Mp[k]) && (Dc[k] > m[k]);
+                                     ((gp >> k) & 1u) && (Dc[k] > m[k]);
                     if (upd) {
                         best[k] = Dc[k];
                         lvl[k] = code;
@@ -275,6 +365,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
                     }
                 }
                 // fixed-order butterfly inside the wave, then one slot per (level, wave): deterministic
+                if (!(variant & 2))
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) {
                     const double omin = __shfl_xor(lmin, off, 64);
@@ -290,20 +381,47 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
             }
             ep = ec;
             ec = en;
+            gp = gn;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                Mp[k] = Mc[k];
                 Mc[k] = m[k];
                 Dc[k] = d[k];
             }
         }
     }
 
-    // ---- found pixels -> per-block record list (unordered; the host sorts by pixel index)
+    // ---- found pixels -> per-block record list.  One atomicAdd per WORKGROUP reserves its slots (a returning atomic
+    // per pixel serialises ~150k same-address operations per block at the L2); inside the reservation the order is
+    // wave, then k, then lane.  The list is sorted by pixel index before it reaches the host.
+    uint32_t my_total = 0;
+    uint32_t before[K];                 // records of this wave that precede mine for the same k
+    uint32_t kbase[K];                  // records of this wave for smaller k
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const unsigned long long bal = __ballot(lvl[k] != 0);
+        before[k] = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        kbase[k] = my_total;
+        my_total += (uint32_t)__builtin_popcountll(bal);      // wave-uniform
+    }
+    uint32_t *cnt_lds = reinterpret_cast<uint32_t *>(de);      // edge strip is dead now
+    __syncthreads();
+    if (lane == 0) cnt_lds[wave] = my_total;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < T::NW; ++w) {
+            const uint32_t n = cnt_lds[w];
+            cnt_lds[w] = tot;
+            tot += n;
+        }
+        cnt_lds[T::NW] = tot ? atomicAdd(found_count + b, tot) : 0u;
+    }
+    __syncthreads();
+    const uint32_t wave_base = cnt_lds[T::NW] + cnt_lds[wave];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (lvl[k]) {
-            const uint32_t pos = atomicAdd(found_count + b, 1u);
+            const uint32_t pos = wave_base + kbase[k] + before[k];
             if (pos < found_cap) {
                 mst_found rec;
                 rec.pixel = (uint32_t)gy * (uint32_t)CH + (uint32_t)(x0 + cg * K + k);
@@ -374,11 +492,15 @@ int check_levels(const mst_levels *lv, int *max_radius, int *n_tested) {
     return MST_OK;
 }
 
-using TileDefault = Tile<64, 14>;   // the reference's default octaves (radius <= 14): 155 KB LDS, 512 threads
-using TileWide = Tile<32, 28>;      // -sz / -oc variants up to radius 28: smaller tile, same code
+using TileDefault = Tile<32, 64, 14>;   // the reference's default octaves (radius <= 14): 77 KB LDS, 256 threads, 2 per CU
+using TileWide = Tile<32, 32, 28>;      // -sz / -oc variants up to radius 28: smaller tile, same code
 
 template <class T>
-int tiles_per_dim(int CH) { return (CH + T::IT - 1) / T::IT; }
+int tiles_x(int CH) { return (CH + T::ITC - 1) / T::ITC; }
+template <class T>
+int tiles_y(int CH) { return (CH + T::ITR - 1) / T::ITR; }
+template <class T>
+int tiles_total(int CH) { return tiles_x<T>(CH) * tiles_y<T>(CH); }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -387,8 +509,8 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 extern "C" uint64_t mst_scale_space_workspace_bytes(int32_t B, int32_t CH, const mst_levels *lv) {
     int mr = 0, nt = 0;
     if (B <= 0 || CH <= 0 || check_levels(lv, &mr, &nt) != MST_OK) return 0;
-    const int tpd = mr <= TileDefault::RMAX ? tiles_per_dim<TileDefault>(CH) : tiles_per_dim<TileWide>(CH);
-    return align_up(sizeof(DevLevels), 256) + sizeof(double) * 2 * (size_t)B * tpd * tpd * nt;
+    const int nt_tiles = mr <= TileDefault::RMAX ? tiles_total<TileDefault>(CH) : tiles_total<TileWide>(CH);
+    return align_up(sizeof(DevLevels), 256) + sizeof(double) * 2 * (size_t)B * nt_tiles * nt;
 }
 
 template <class T>
@@ -401,11 +523,13 @@ static int launch_scale_space(const double *c, const uint8_t *nz, int B, int CH,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES));
         attr_set = true;
     }
-    const int tpd = tiles_per_dim<T>(CH);
-    const int ntiles = tpd * tpd;
+    const int tx = tiles_x<T>(CH), ty = tiles_y<T>(CH);
+    const int ntiles = tx * ty;
     const int gx = (ntiles + 7) / 8 * 8;
+    const char *venv = getenv("MST_ABLATE");          // timing ablations for profiling only (results invalid)
+    const int variant = venv ? atoi(venv) : 0;
     scale_space_kernel<T><<<dim3(gx, B), T::NT, T::LDS_BYTES, s>>>(c, nz, CH, d_lv, found, found_cap, found_count,
-                                                                 partial, tpd, n_tested, skip_empty);
+                                                                 partial, tx, ty, n_tested, skip_empty, variant);
     MST_LAUNCH_CHECK();
     return MST_OK;
 }
@@ -443,11 +567,11 @@ extern "C" int mst_scale_space(const double *c, const uint8_t *nz, int32_t B, in
     if (mr <= TileDefault::RMAX) {
         rc = launch_scale_space<TileDefault>(c, nz, B, CH, d_lv, found, found_cap, found_count, partial, nt,
                                              skip_empty, s);
-        ntiles = tiles_per_dim<TileDefault>(CH) * tiles_per_dim<TileDefault>(CH);
+        ntiles = tiles_total<TileDefault>(CH);
     } else {
         rc = launch_scale_space<TileWide>(c, nz, B, CH, d_lv, found, found_cap, found_count, partial, nt,
                                           skip_empty, s);
-        ntiles = tiles_per_dim<TileWide>(CH) * tiles_per_dim<TileWide>(CH);
+        ntiles = tiles_total<TileWide>(CH);
     }
     if (rc != MST_OK) return rc;
     stats_reduce_kernel<<<dim3(nt, B), 256, 0, s>>>(partial, ntiles, nt, level_stats);

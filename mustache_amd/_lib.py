@@ -11,7 +11,8 @@ MST_ABI_VERSION = 1
 MST_OK, MST_E_ARG, MST_E_HIP, MST_E_OVERFLOW, MST_E_NONFINITE = 0, -1, -2, -3, -4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmustache_hip.so")
+# MUSTACHE_HIP_LIB: developer override to A/B alternative builds of the same ABI (still an in-tree HIP library)
+LIB_PATH = os.environ.get("MUSTACHE_HIP_LIB") or os.path.join(_HERE, "libmustache_hip.so")
 
 
 class MstLevels(ctypes.Structure):

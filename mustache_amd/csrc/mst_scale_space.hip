@@ -58,12 +58,13 @@ constexpr int pitch_for(int need) {
     return p;
 }
 
-template <int RGR_, int RGC_, int RMAX_>
+template <int RGR_, int RGC_, int RMAX_, int K_ = 8, int MINW_ = 1>
 struct Tile {
     static constexpr int RGR = RGR_, RGC = RGC_;  // region rows / cols: interior + 1-pixel ring for the 3x3 max
     static constexpr int ITR = RGR_ - 2, ITC = RGC_ - 2;   // interior (owned) pixels
     static constexpr int RMAX = RMAX_;            // largest blur radius this instantiation supports
-    static constexpr int K = 8;                   // samples per thread along the filter axis
+    static constexpr int K = K_;                  // samples per thread along the filter axis
+    static constexpr int MINW = MINW_;            // waves per SIMD the register allocation must allow
     static constexpr int NCG = RGC / K;           // column groups
     static constexpr int NT = RGR * NCG;          // threads per workgroup
     static constexpr int NW = NT / 64;            // waves per workgroup
@@ -127,51 +128,91 @@ __device__ __forceinline__ void fir_sym(const double (&win)[K + 2 * R], const do
 
 // Outputs per register window: 8 for small radii; for the widest kernels the 8 outputs are produced as two windows
 // of 4 so window + accumulators + the per-pixel sieve state stay inside the 256-VGPR budget.
-template <int R>
+template <int K, int R>
 struct Chunk {
-    static constexpr int KC = (R >= 11) ? 4 : 8;
+    static constexpr int KC = (K >= 8 && R < 11) ? 8 : (K >= 4 ? 4 : K);
 };
 
-// N doubles (N even) from a 16-byte aligned LDS address as ds_read_b128.
-template <int N>
-__device__ __forceinline__ void load_window(const double *__restrict__ p, double (&win)[N]) {
-    static_assert(N % 2 == 0, "pairs");
-    const double2 *p2 = reinterpret_cast<const double2 *>(p);
-#pragma unroll
-    for (int i = 0; i < N / 2; ++i) {
-        const double2 v = p2[i];
-        win[2 * i] = v.x;
-        win[2 * i + 1] = v.y;
-    }
-}
-
-// One FIR chunk: KC outputs whose first tap sits at p[off]; p is 16-byte aligned, off is 0 or 1.
+// One FIR chunk: KC outputs whose first tap sits at p[OFF]; p is 16-byte aligned, OFF is 0 or 1.
+//   element e of the window = p[e + OFF], e in [0, KC + 2R);   output k:  centre e = R + k, taps e = R + k -+ j.
+// SciPy's order per output:  t = x[c]*w0;  for j = R..1:  t += (x[c-j] + x[c+j]) * w[j].
+// The window is streamed: 16-byte pairs are loaded (ds_read_b128) in the order the taps first touch them -- the centre
+// run, then alternately from the left end inwards and from the right end inwards -- so only ~2*KC samples plus the
+// loads in flight are live at a time instead of all KC + 2R, and the LDS latency hides under the FP64 work.
+// For each tap the KC adds / muls / accumulates are adjacent in program order: KC independent chains keep the FP64
+// pipe issuing (a sample-major order is one serial add->mul->add chain).
 template <int KC, int R, int OFF>
 __device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const double (&w)[R + 1], double (&t)[KC]) {
-    constexpr int WN = (KC + 2 * R + OFF + 1) & ~1;
-    double raw[WN];
-    load_window<WN>(p, raw);
-    double win[KC + 2 * R];
+    constexpr int NP = (KC + 2 * R + OFF + 1) / 2;                       // 16-byte pairs spanned by the window
+    constexpr int QC0 = (R + OFF) >> 1, QC1 = (R + KC - 1 + OFF) >> 1;   // pairs holding the centre run
+    const double2 *p2 = reinterpret_cast<const double2 *>(p);
+    double x[2 * NP];
+#if defined(MST_ABL_NOLDS)   /* timing ablation: no LDS window loads (values opaque to the optimiser) */
+#define MST_LD(q_)                                        \
+    {                                                     \
+        double a_ = w[0], b_ = w[R];                      \
+        asm volatile("" : "+v"(a_), "+v"(b_));            \
+        x[2 * (q_)] = a_;                                 \
+        x[2 * (q_) + 1] = b_;                             \
+    }
+#else
+#define MST_LD(q_)                     \
+    {                                  \
+        const double2 v_ = p2[q_];     \
+        x[2 * (q_)] = v_.x;            \
+        x[2 * (q_) + 1] = v_.y;        \
+    }
+#endif
 #pragma unroll
-    for (int i = 0; i < KC + 2 * R; ++i) win[i] = raw[i + OFF];
-    fir_sym<KC, R>(win, w, t);
+    for (int q = QC0; q <= QC1; ++q) MST_LD(q)
+    int lq_hi = -1, rq_lo = NP;         // left pairs <= lq_hi and right pairs >= rq_lo are loaded (folds at compile time)
+#pragma unroll
+    for (int k = 0; k < KC; ++k) t[k] = x[R + k + OFF] * w[0];
+#pragma unroll
+    for (int j = R; j >= 1; --j) {
+        const int lq1 = (R - j + KC - 1 + OFF) >> 1, rq0 = (R + j + OFF) >> 1;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (q > lq_hi && q <= lq1 && q < QC0) MST_LD(q)
+            if (q < rq_lo && q >= rq0 && q > QC1) MST_LD(q)
+        }
+        lq_hi = lq1 > lq_hi ? lq1 : lq_hi;
+        rq_lo = rq0 < rq_lo ? rq0 : rq_lo;
+#if defined(MST_ABL_NOMATH)  /* timing ablation: loads only, one add per loaded pair */
+        if (j & 1) t[j % KC] = t[j % KC] + (x[R - j + OFF] + x[R + KC - 1 + j + OFF]);
+#else
+        double s[KC];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) s[k] = x[R + k - j + OFF] + x[R + k + j + OFF];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) s[k] = s[k] * w[j];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) t[k] = t[k] + s[k];
+#endif
+    }
+#undef MST_LD
 }
 
 // Axis-0 pass for radius R over the (RGR rows) x (RGC + 2R columns) strip the axis-1 pass will need.  The c tile is
 // stored transposed (ct[col][row]), so a thread's window of consecutive rows is contiguous in LDS.
+// Work split: the first NT items are (8-row group, column) pairs over the first NT*8/RGR columns -- exactly one per
+// thread; the remaining 2R-ish columns are cut into 4-row pieces so that the longest thread does 8 + 4 outputs
+// instead of 8 + 8 (the strip is 1.1-1.5 x NT*8 outputs, so whole extra 8-row items would leave most lanes idle for
+// a full second round).
 template <class T, int R>
 __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__restrict__ vb,
                                       const double *__restrict__ wg, int tid) {
-    constexpr int K = T::K, KC = Chunk<R>::KC;
-    constexpr int NC = T::RGC + 2 * R;
-    constexpr int NITEM = (T::RGR / K) * NC;
+    constexpr int K = T::K, KC = Chunk<T::K, R>::KC;
+    constexpr int NC = T::RGC + 2 * R;               // columns to produce
+    constexpr int NRG = T::RGR / K;                  // 8-row groups
+    constexpr int MAINC = T::NT / NRG < NC ? T::NT / NRG : NC;   // columns covered by one full-length item per thread
     constexpr int OFF = (T::RMAX - R) & 1;           // parity of the first tap's row index (row0, h*KC are even)
     double w[R + 1];
 #pragma unroll
     for (int j = 0; j <= R; ++j) w[j] = wg[j];
-    for (int it = tid; it < NITEM; it += T::NT) {
-        const int rgp = it / NC;
-        const int col = it - rgp * NC;
+    if (tid < NRG * MAINC) {
+        const int rgp = tid / MAINC;
+        const int col = tid - rgp * MAINC;
         const int row0 = rgp * K;
         const double *p = ct + ((T::RMAX - R) + col) * T::CTP + (row0 + T::RMAX - R - OFF);
         double *q = vb + row0 * T::VP + col;
@@ -183,13 +224,28 @@ __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__r
             for (int k = 0; k < KC; ++k) q[(h * KC + k) * T::VP] = t[k];
         }
     }
+    if constexpr (MAINC < NC) {
+        constexpr int XC = NC - MAINC;               // leftover columns
+        constexpr int XRG = T::RGR / 4;              // 4-row pieces per column
+        for (int it = tid; it < XRG * XC; it += T::NT) {
+            const int rgp = it / XC;
+            const int col = MAINC + (it - rgp * XC);
+            const int row0 = rgp * 4;
+            const double *p = ct + ((T::RMAX - R) + col) * T::CTP + (row0 + T::RMAX - R - OFF);
+            double t[4];
+            fir_chunk<4, R, OFF>(p, w, t);
+            double *q = vb + row0 * T::VP + col;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k * T::VP] = t[k];
+        }
+    }
 }
 
 // Axis-1 pass: thread (row rr, column group cg) -> g[0..K) = G at region columns cg*K .. cg*K+K-1.
 template <class T, int R>
 __device__ __forceinline__ void hpass(const double *__restrict__ vb, const double *__restrict__ wg, int rr, int cg,
                                       double (&g)[T::K]) {
-    constexpr int K = T::K, KC = Chunk<R>::KC;
+    constexpr int K = T::K, KC = Chunk<T::K, R>::KC;
     double w[R + 1];
 #pragma unroll
     for (int j = 0; j <= R; ++j) w[j] = wg[j];
@@ -229,7 +285,7 @@ __device__ __forceinline__ void blur_dispatch(int r, const double *ct, double *v
 }
 
 template <class T>
-__global__ void __launch_bounds__(T::NT)
+__global__ void __launch_bounds__(T::NT, T::MINW)
 scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz, int CH,
                    const DevLevels *__restrict__ lv, mst_found *__restrict__ found, uint32_t found_cap,
                    uint32_t *__restrict__ found_count, double *__restrict__ partial, int tiles_x, int tiles_y,
@@ -279,12 +335,21 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
         return;
     }
 
-    // ---- stage the c tile (reflect halo) in LDS, transposed: the only bulk HBM/L2 read of the kernel
-    for (int idx = tid; idx < T::CTR * T::CTC; idx += T::NT) {
-        const int i = idx / T::CTC, j = idx - i * T::CTC;
-        const int sy = reflect_idx(y0 - RMAX + i, CH);
-        const int sx = reflect_idx(x0 - RMAX + j, CH);
-        ct[j * T::CTP + i] = cb[(size_t)sy * CH + sx];
+    // ---- stage the c tile (reflect halo) in LDS, transposed: the only bulk HBM/L2 read of the kernel.
+    // A wave takes whole rows (row reflection is wave-uniform); each lane's column reflections are computed once.
+    {
+        constexpr int CPL = (T::CTC + 63) / 64;          // columns per lane
+        int sx[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) sx[q] = reflect_idx(x0 - RMAX + (tid & 63) + 64 * q, CH);
+        for (int i = tid >> 6; i < T::CTR; i += T::NW) {
+            const double *src = cb + (size_t)reflect_idx(y0 - RMAX + i, CH) * CH;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const int j = (tid & 63) + 64 * q;
+                if (j < T::CTC) ct[j * T::CTP + i] = src[sx[q]];
+            }
+        }
     }
     __syncthreads();
 
@@ -492,7 +557,14 @@ int check_levels(const mst_levels *lv, int *max_radius, int *n_tested) {
     return MST_OK;
 }
 
+#ifndef MST_TILE_K
+#define MST_TILE_K 8
+#endif
+#if MST_TILE_K == 4
+using TileDefault = Tile<32, 64, 14, 4, 4>;   // 512 threads x 4 pixels, 128 VGPRs -> 4 waves per SIMD
+#else
 using TileDefault = Tile<32, 64, 14>;   // the reference's default octaves (radius <= 14): 77 KB LDS, 256 threads, 2 per CU
+#endif
 using TileWide = Tile<32, 32, 28>;      // -sz / -oc variants up to radius 28: smaller tile, same code
 
 template <class T>

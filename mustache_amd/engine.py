@@ -111,7 +111,7 @@ class ScaleSpaceEngine:
                                                    1 if intra else 0, _stream()))
         return nz, nz_count
 
-    def sigma_loop(self, c, nz, nz_count, skip_empty=True, found_cap=None, download=True, timing=None):
+    def sigma_loop(self, c, nz, nz_count, skip_empty=True, found_cap=None, download=True, timing=None, sort=True):
         """The fused kernel + p-values.  Returns host records (download=True) or the device buffers.
         `timing`: optional list; receives a (start, end) torch.cuda.Event pair bracketing the mst_scale_space launch
         on the launch stream."""
@@ -148,7 +148,7 @@ class ScaleSpaceEngine:
                 timing.append((e0, e1))     # mst_found_pvalues synchronised the stream: the events are complete
         if not download:
             return found, pval, count, fit, found_cap
-        return self._download(found, pval, count, fit, nt)
+        return self._download(found, pval, count, fit, nt, sort=sort)
 
     def _pinned(self, key, shape, dtype):
         """Cached page-locked host staging buffers: D2H of the found records runs at PCIe rate, not pageable rate."""
@@ -158,9 +158,10 @@ class ScaleSpaceEngine:
             buf = self._pin[key] = torch.empty(max(need, 1), dtype=dtype, pin_memory=True)
         return buf[:need].view(*shape)
 
-    def _download(self, found, pval, count, fit, nt):
-        """Order every block's records by pixel index (row-major = the reference's nz order) on the device, then
-        one pinned copy per array."""
+    def _download(self, found, pval, count, fit, nt, sort=True):
+        """Found records -> host.  The kernel appends records per workgroup, so their order inside a block is
+        arbitrary; with sort=True they are ordered by pixel index on the device first (row-major = the reference's nz
+        order, which the tail's look-ups rely on).  Transfers go through cached pinned buffers."""
         cnt_d = count.to(torch.int64)
         cnt = cnt_d.cpu().numpy()
         fit_h = fit.cpu().numpy()
@@ -169,29 +170,36 @@ class ScaleSpaceEngine:
         out, fits = [], []
         if mx > 0:
             rec = found[:, :mx]
-            pix = rec[..., 0] & 0xFFFFFFFF
-            valid = torch.arange(mx, device=found.device)[None, :] < cnt_d[:, None]
-            order = torch.argsort(torch.where(valid, pix, torch.full_like(pix, 1 << 40)), dim=1)
-            rec_s = torch.gather(rec, 1, order[..., None].expand(-1, -1, 2))
-            pv_s = torch.gather(pval[:, :mx], 1, order)
-            rec_h = self._pinned("rec", (B, mx, 2), torch.int64)
+            word = rec[..., 0]
+            pv = pval[:, :mx]
+            if sort:
+                pix = word & 0xFFFFFFFF
+                valid = torch.arange(mx, device=found.device)[None, :] < cnt_d[:, None]
+                order = torch.argsort(torch.where(valid, pix, torch.full_like(pix, 1 << 40)), dim=1)
+                rec = torch.gather(rec, 1, order[..., None].expand(-1, -1, 2))
+                word = rec[..., 0]
+                pv = torch.gather(pv, 1, order)
+            pix_h = self._pinned("pix", (B, mx), torch.int32)
+            lvl_h = self._pinned("lvl", (B, mx), torch.uint8)
+            val_h = self._pinned("val", (B, mx), torch.int64)
             pv_h = self._pinned("pv", (B, mx), torch.float64)
-            rec_h.copy_(rec_s, non_blocking=True)
-            pv_h.copy_(pv_s, non_blocking=True)
+            pix_h.copy_((word & 0xFFFFFFFF).to(torch.int32), non_blocking=True)
+            lvl_h.copy_((word >> 32).to(torch.uint8), non_blocking=True)
+            val_h.copy_(rec[..., 1], non_blocking=True)
+            pv_h.copy_(pv, non_blocking=True)
             torch.cuda.current_stream().synchronize()
-            rec_n, pv_n = rec_h.numpy(), pv_h.numpy()
+            # per-block views into fresh host arrays (one bulk copy each; the pinned buffers are reused next call)
+            pix_n = pix_h.numpy().view(np.uint32).copy()
+            lvl_n = lvl_h.numpy().copy()
+            val_n = val_h.numpy().view(np.float64).copy()
+            pv_n = pv_h.numpy().copy()
         for b in range(B):
             m = int(cnt[b])
             if m:
-                word = rec_n[b, :m, 0].view(np.uint64)
-                pixel = (word & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-                level = (word >> np.uint64(32)).astype(np.uint32)
-                value = rec_n[b, :m, 1].view(np.float64).copy()
-                pv = pv_n[b, :m].copy()
+                out.append(dict(pixel=pix_n[b, :m], level=lvl_n[b, :m], value=val_n[b, :m], pval=pv_n[b, :m]))
             else:
-                pixel = level = np.zeros(0, np.uint32)
-                value = pv = np.zeros(0)
-            out.append(dict(pixel=pixel, level=level, value=value, pval=pv))
+                out.append(dict(pixel=np.zeros(0, np.uint32), level=np.zeros(0, np.uint8), value=np.zeros(0),
+                                pval=np.zeros(0)))
             fits.append((fit_h[b, :nt, 0].copy(), fit_h[b, :nt, 1].copy()))
         return out, fits
 

@@ -29,7 +29,7 @@ groups = collections.defaultdict(list)
 for r in ss:
     groups[(int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]))].append(
         (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-lines += ["", "## Fused kernel `scale_space_kernel<Tile<64,14>>` per launch shape", "",
+lines += ["", "## Fused kernel `scale_space_kernel<Tile<32,64,14>>` per launch shape", "",
           "| tiles/block (padded) | blocks | launches | durations ms |", "|---|---|---|---|"]
 for (gx, gy), d in sorted(groups.items(), reverse=True):
     lines.append("| %d | %d | %d | %s |" % (gx, gy, len(d), ", ".join("%.3f" % x for x in d[:8])))

@@ -155,6 +155,29 @@ int mst_normalize_band(const double *band_in, double *band_out, int64_t n, int32
 int mst_blocks_from_band(const double *band, int64_t n, int32_t dpx, const int64_t *starts, int32_t B, int32_t CH,
                          double *c, uint8_t *nz, uint32_t *nz_count, void *stream);
 
+/* ---- two-sample (differential) caller, reference mustache/diff_mustache.py:260-569 ------------------------------------
+ * The per-sample sigma loops are mst_scale_space on both samples' blocks.  The entry points below add what
+ * diff_mustache() computes on the difference image.  NB (reference behaviour, kept): the difference image's DoG is
+ * assigned once per octave (diff_mustache.py:336) and never advanced inside the level loop, so every tested level of an
+ * octave uses D_2 = G_2 - G_3 of that octave; the host produces G_2 and G_3 with mst_gauss_blur. */
+
+/* diff_mustache.py:262-276 on already filled blocks: nzb = nz1 & nz2; cd = nzb ? c1 - c2 : 0; nzb_count[b] = sum. */
+int mst_diff_image(const double *c1, const double *c2, const uint8_t *nz1, const uint8_t *nz2, int32_t B, int32_t CH,
+                   double *cd, uint8_t *nzb, uint32_t *nzb_count, void *stream);
+
+/* scipy.stats.norm.fit((a - b)[mask]) per image (diff_mustache.py:371): fit[i] = {mean, sqrt(mean((x - mean)^2))},
+ * i < B images of npx pixels; fixed summation order.  workspace: dev, >= 2048 * B bytes. */
+int mst_masked_normfit(const double *a, const double *b, const uint8_t *mask, const uint32_t *mask_count, int32_t B,
+                       int64_t npx, double *fit, void *workspace, uint64_t workspace_bytes, void *stream);
+
+/* diff_mustache.py:372-385 for the found pixels of one sample: ppair = 2 * min(cdf, 1 - cdf), cdf = ndtr((x-loc)/scale),
+ * x = (g2 - g3)[octave of the record's level][pair b][pixel]; non-finite cdf -> 1.
+ * found / found_count / ppair are the arrays of a 2B-block mst_scale_space launch (sample 1 = blocks [0, B), sample 2 =
+ * [B, 2B)); sample_offset = 0 or B selects the sample.  g2, g3: dev [n_octaves][B][CH][CH]; fit: dev [n_octaves][B][2]. */
+int mst_pair_pvalues(const mst_found *found, uint32_t found_cap, const uint32_t *found_count, const double *g2,
+                     const double *g3, const double *fit, int32_t B, int32_t CH, int32_t n_octaves,
+                     int32_t tested_per_octave, int32_t sample_offset, double *ppair, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,317 @@
+#!/usr/bin/env python3
+"""Drop-in host side for the reference's two-sample caller (ay-lab/mustache v1.3.3, mustache/diff_mustache.py).
+
+    diff_mustache(c1, c2, chromosome, chromosome2, res, start, end, mask_size, distance_in_px, octave_values,
+                  st, pt, pt2)                           <- diff_mustache.py:260-569
+    process_block(...)                                   <- diff_mustache.py:694-717
+    regulator(f1, f2, ...)                               <- diff_mustache.py:572-690
+    main()                                               <- diff_mustache.py:720-906   (.loop1/.diffloop1/.loop2/.diffloop2)
+
+Both samples' sigma loops run as one 2-block launch of the fused HIP kernel; the difference image is scored on the
+device (mst_diff_image / mst_gauss_blur / mst_masked_normfit / mst_pair_pvalues).  Behaviour that looks odd but is the
+reference's is kept and marked: the difference DoG is the octave's D_2 for every tested level (:336 vs :363), the
+bias of sample 1 is never applied by main() (:824-827), and -d is clamped to 2000 * res (:770-778).
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+from .mustache import (_engine, block_tiling, block_mask_size, parseBP, read_pd)
+from .tail import fdr_candidates, diag_mean_filter, cluster_representatives, loops_from_reps
+
+
+def _pair_tail(batch, b1, b2, start, pt, pt2, st, intra):
+    """diff_mustache.py:428-569 on the records of blocks b1 (sample 1) and b2 (sample 2)."""
+    empty = ([], [], [], [])
+    if batch.nz_count[b1] < 50 or batch.nz_count[b2] < 50:                 # (:266)
+        return empty
+    if batch.nz_count[b1] < 10000 or batch.nz_count[b2] < 10000:           # (:430)
+        return empty
+    q1, i1 = fdr_candidates(batch, b1, pt, st)                             # (:432-505)
+    q2, i2 = fdr_candidates(batch, b2, pt, st)
+    if i1.size == 0 or i2.size == 0:                                       # (:507)
+        return empty
+    if intra:                                                              # (:516-529)
+        i1 = diag_mean_filter(batch, b1, i1)
+        if i1.size == 0:
+            return empty
+        i2 = diag_mean_filter(batch, b2, i2)
+        if i2.size == 0:
+            return empty
+    out = []
+    for (b, q, idx, bo) in ((b1, q1, i1, b2), (b2, q2, i2, b1)):
+        reps = cluster_representatives(batch, b, q, idx)                   # (:531-561)
+        loops = loops_from_reps(batch, b, q, reps, start)
+        rec, other = batch.found[b], batch.found[bo]
+        # differential subset (:567-568): pair < pt2 and v_self > v_other, where v = 1 off-nz, vAll on nz (0 if not found)
+        pix = rec["pixel"][reps] if reps else np.zeros(0, np.uint32)
+        nz_other, _, _ = batch.candidate_features(bo, pix, np.zeros(len(pix), np.int64))
+        opix = other["pixel"].astype(np.int64)
+        diff = []
+        for j, r in enumerate(reps):
+            p = int(pix[j])
+            k = int(np.searchsorted(opix, p))
+            if k < len(opix) and opix[k] == p:
+                v_other = other["value"][k]
+            else:
+                v_other = 0.0 if nz_other[j] else 1.0
+            if rec["pair"][r] < pt2 and rec["value"][r] > v_other:
+                diff.append(loops[j])
+        out.extend([loops, diff])
+    return tuple(out)
+
+
+def diff_mustache(c1, c2, chromosome, chromosome2, res, start, end, mask_size, distance_in_px, octave_values, st, pt,
+                  pt2):
+    """(loops1, diff_loops1, loops2, diff_loops2) for one dense block pair; c1 and c2 are filled in place like the
+    reference does (:268-273)."""
+    import torch
+    eng = _engine(octave_values)
+    c1, c2 = np.asarray(c1), np.asarray(c2)
+    if c1.shape != c2.shape or c1.ndim != 2 or c1.shape[0] != c1.shape[1] or c1.dtype != np.float64 or c2.dtype != np.float64:
+        raise ValueError("diff_mustache(): c1 and c2 must be square float64 arrays of the same shape")
+    intra = chromosome == chromosome2
+    dev = torch.from_numpy(np.stack([c1, c2])).to(eng.device)
+    batch = eng.run_block_pairs(dev, distance_in_px, intra=intra)
+    if batch.nz_count[0] >= 50 and batch.nz_count[1] >= 50:               # the reference returns before filling (:266-273)
+        filled = batch.c.cpu().numpy()
+        c1[...] = filled[0]
+        c2[...] = filled[1]
+    return _pair_tail(batch, 0, 1, start, pt, pt2, st, intra)
+
+
+def process_block(i, start, end, overlap_size, cc1, cc2, chromosome, chromosome2, res, distance_in_px, octave_values, o,
+                  st, pt, pt2):
+    """diff_mustache.py:694-717: tags 1..4 = loops1, diff1, loops2, diff2, after the overlap mask."""
+    mask_size = block_mask_size(i, start, end, overlap_size)
+    res4 = diff_mustache(cc1, cc2, chromosome, chromosome2, res, start[i], end[i], mask_size, distance_in_px,
+                         octave_values, st, pt, pt2)
+    _append_tagged(o, res4, start[i], mask_size)
+
+
+def _append_tagged(o, res4, start_i, mask_size):
+    for tag, loops in enumerate(res4, start=1):
+        for loop in loops:
+            if loop[0] >= start_i + mask_size or loop[1] >= start_i + mask_size:
+                o.append([loop[0], loop[1], loop[2], loop[3], tag])
+
+
+def call_diff_loops_coo(coo1, coo2, res, distance_in_px, octave_values, st, pt, pt2, verbose=True):
+    """regulator's body after the readers (diff_mustache.py:628-685): normalise both samples on the GPU, cut the same
+    tiling out of both bands, run all block pairs."""
+    import torch
+    from .normalize import band_from_coo, normalize_band
+    from .pipeline import ChromosomePipeline
+    pipe = ChromosomePipeline(octave_values)
+    eng, dev = pipe.engine, pipe.device
+    ns, bands = [], []
+    for (x, y, v) in (coo1, coo2):
+        x = np.ascontiguousarray(np.asarray(x), dtype=np.int64)
+        y = np.ascontiguousarray(np.asarray(y), dtype=np.int64)
+        v = np.ascontiguousarray(np.asarray(v), dtype=np.float64)
+        ns.append(int(max(x.max(), y.max())) + 1)                          # (:630-631)
+        bands.append((x, y, v))
+    n = max(ns)                                                            # (:632)
+    dbands = []
+    for (x, y, v), n_s in zip(bands, ns):
+        xd, yd, vd = (torch.from_numpy(a).to(dev) for a in (x, y, v))
+        band = band_from_coo(xd, yd, vd, n_s, distance_in_px)              # each sample is normalised with ITS OWN n
+        band, _, _ = normalize_band(band, n_s, distance_in_px, res)       # (:634-635 -> mustache.py:623)
+        if n_s < n:                                                        # blocks are cut with the common n
+            pad = torch.zeros((distance_in_px + 2, n), dtype=torch.float64, device=dev)
+            pad[:, :n_s] = band
+            band = pad
+        dbands.append(band)
+    CH, start, end = block_tiling(n, distance_in_px)                       # (:637-651)
+    if verbose:
+        print("Loop calling...")
+    per_pair = 2 * (CH * CH * 9) + 5 * CH * CH * 8 + 2 * max(4096, CH * CH // 32) * 32
+    bs = max(1, int(pipe.max_batch_bytes // per_pair))
+    o = []
+    idx = list(range(len(start)))
+    for g0 in range(0, len(idx), bs):
+        grp = idx[g0:g0 + bs]
+        st_g = [start[i] for i in grp]
+        batch = _pairs_from_filled(eng, pipe, dbands, n, distance_in_px, st_g, CH)
+        P = len(grp)
+        for j, i in enumerate(grp):
+            mask = block_mask_size(i, start, end, distance_in_px)
+            _append_tagged(o, _pair_tail(batch, j, P + j, start[i], pt, pt2, st, True), start[i], mask)
+        del batch
+    return o
+
+
+def _pairs_from_filled(eng, pipe, dbands, n, dpx, starts, CH):
+    """Blocks + masks of both samples straight from their bands (filled, with nz), then sigma loop + pair p-values."""
+    import torch
+    from .engine import BlockBatch
+    c1, nz1, cnt1 = pipe.blocks_from_band(dbands[0], n, dpx, starts, CH)
+    c2, nz2, cnt2 = pipe.blocks_from_band(dbands[1], n, dpx, starts, CH)
+    c = torch.cat([c1, c2])
+    nz = torch.cat([nz1, nz2])
+    nzc = torch.cat([cnt1, cnt2])
+    del c1, c2, nz1, nz2
+    found, pval, count, fit, cap = eng.sigma_loop(c, nz, nzc, download=False)
+    ppair, nfit = eng.pair_pvalues(c, nz, found, cap, count)
+    recs, fits = eng._download(found, pval, count, fit, eng.levels.n_tested, sort=True, extra={"pair": ppair})
+    return BlockBatch(eng, c, nz, CH, c.shape[0], nzc.cpu().numpy().view(np.uint32).astype(np.int64), recs, fits)
+
+
+def regulator(f1, f2, norm_method, CHRM_SIZE, outdir, bed1="", bed2="", res=5000, sigma0=1.6, s=10, pt=0.1, pt2=0.1,
+              st=0.88, octaves=2, verbose=True, nprocesses=4, distance_filter=2000000, bias1=False, bias2=False,
+              chromosome='n', chromosome2=None):
+    """Two-sample loop calling for one chromosome (diff_mustache.py:572-690); returns [x, y, fdr, sigma, tag] rows."""
+    if not chromosome2 or chromosome2 == 'n':
+        chromosome2 = chromosome
+    if chromosome != chromosome2:
+        raise NotImplementedError("inter-chromosomal mode is non-functional in the reference (diff_mustache.py:687-690)")
+    octave_values = [sigma0 * (2 ** i) for i in range(octaves)]
+    distance_in_bp = distance_filter
+    if verbose:
+        print("Reading contact map...")
+    coos = []
+    for f, bias in ((f1, bias1), (f2, bias2)):
+        if f.endswith(".hic"):
+            from .readers import read_hic_file
+            coo = read_hic_file(f, norm_method, CHRM_SIZE, distance_in_bp, chromosome, chromosome2, res)
+        elif f.endswith(".cool"):
+            from .readers import read_cooler
+            x, y, v, r2 = read_cooler(f, distance_in_bp, chromosome, chromosome2, norm_method)
+            if coos and r2 != res:
+                raise ValueError('Both contact maps should have the same resolution.')
+            res, coo = r2, (x, y, v)
+        elif f.endswith(".mcool"):
+            from .readers import read_mcooler
+            coo = read_mcooler(f, distance_in_bp, chromosome, chromosome2, res, norm_method)
+        else:
+            coo = read_pd(f, distance_in_bp, bias, chromosome, res)
+        coos.append(coo)
+    if coos[0] is None or coos[1] is None or len(coos[0][2]) == 0 or len(coos[1][2]) == 0:
+        return []
+    if verbose:
+        print("Normalizing contact map...")
+    distance_in_px = int(math.ceil(distance_in_bp // res))
+    return call_diff_loops_coo(coos[0], coos[1], res, distance_in_px, octave_values, st, pt, pt2, verbose=verbose)
+
+
+def parse_args(args):
+    p = argparse.ArgumentParser(description="Check the help flag")
+    p.add_argument("-f1", "--file1", dest="f_path1", help="REQUIRED: Contact map 1", required=False)
+    p.add_argument("-f2", "--file2", dest="f_path2", help="REQUIRED: Contact map 2", required=False)
+    p.add_argument("-d", "--distance", dest="distFilter", help="Maximum distance (in bp) between loop loci", required=False)
+    p.add_argument("-o", "--outfile", dest="outdir", help="REQUIRED: prefix of the four output files", required=True)
+    p.add_argument("-r", "--resolution", dest="resolution", help="REQUIRED: resolution of the contact maps", required=True)
+    p.add_argument("-bed1", "--bed1", dest="bed1", default="", required=False)
+    p.add_argument("-m1", "--matrix1", dest="mat1", default="", required=False)
+    p.add_argument("-bed2", "--bed2", dest="bed2", default="", required=False)
+    p.add_argument("-m2", "--matrix2", dest="mat2", default="", required=False)
+    p.add_argument("-b1", "--biases1", dest="biasfile1", required=False)
+    p.add_argument("-b2", "--biases2", dest="biasfile2", required=False)
+    p.add_argument("-cz", "--chromosomeSize", default="", dest="chrSize_file", required=False)
+    p.add_argument("-norm", "--normalization", default=False, dest="norm_method", required=False)
+    p.add_argument("-st", "--sparsityThreshold", dest="st", type=float, default=0.88, required=False)
+    p.add_argument("-pt", "--pThreshold", dest="pt", type=float, default=0.2, required=False)
+    p.add_argument("-pt2", "--pThreshold2", dest="pt2", type=float, default=0.1, required=False)
+    p.add_argument("-sz", "--sigmaZero", dest="s_z", type=float, default=1.6, required=False)
+    p.add_argument("-oc", "--octaves", dest="octaves", default=2, type=int, required=False)
+    p.add_argument("-i", "--iterations", dest="s", default=10, type=int, required=False)
+    p.add_argument("-p", "--processes", dest="nprocesses", default=4, type=int, required=False)
+    p.add_argument("-ch", "--chromosome", dest="chromosome", nargs='+', default='n', required=False)
+    p.add_argument("-ch2", "--chromosome2", dest="chromosome2", nargs='+', default='n', required=False)
+    p.add_argument("-v", "--verbose", dest="verbose", type=bool, default=True, required=False)
+    return p.parse_args(args)
+
+
+def resolve_distance_filter(dist_arg, res):
+    """diff_mustache.py:759-778 (note the 2000*res upper clamp, unlike mustache.py)."""
+    d = parseBP(dist_arg)
+    if not d:
+        if 200 * res >= 2000000:
+            return 200 * res
+        if 2000 * res <= 2000000:
+            return 2000 * res
+        return 2000000
+    if d < 200 * res:
+        return 200 * res
+    if d > 2000 * res:
+        return 2000 * res
+    if d > 2000000:
+        return 2000000
+    return d
+
+
+HEADER = "BIN1_CHR\tBIN1_START\tBIN1_END\tBIN2_CHROMOSOME\tBIN2_START\tBIN2_END\tFDR\tDETECTION_SCALE\n"
+SUFFIX = {1: ".loop1", 2: ".diffloop1", 3: ".loop2", 4: ".diffloop2"}
+
+
+def main(argv=None):
+    t0 = time.time()
+    args = parse_args(sys.argv[1:] if argv is None else argv)
+    f1, f2 = args.f_path1, args.f_path2
+    if args.bed1 and args.mat1:
+        f1 = args.mat1
+    if args.bed2 and args.mat2:
+        f2 = args.mat2
+    if not f1 or not f2 or not os.path.exists(f1) or not os.path.exists(f2):
+        print("Error: Couldn't find the specified contact files")
+        return
+    res = parseBP(args.resolution)
+    if not res:
+        print("Error: Invalid resolution")
+        return
+    if not args.chromosome or args.chromosome == 'n':
+        if f1.endswith((".cool", ".mcool", ".hic")):
+            from .readers import list_chromosomes
+            chr_list = list_chromosomes(f1, res)
+        else:
+            print("Error: Please enter the chromosome name.")
+            return
+    else:
+        chr_list = list(args.chromosome)
+    chr_list2 = list(args.chromosome2) if isinstance(args.chromosome2, list) else list(chr_list)
+    if len(chr_list) != len(chr_list2):
+        print("Error: the same number of chromosome1 and chromosome2 should be provided.")
+        return
+    distFilter = resolve_distance_filter(args.distFilter, res)
+    for i, (chromosome, chromosome2) in enumerate(zip(chr_list, chr_list2)):
+        biasf1 = False        # reference quirk (:824-827): -b1 is checked for existence but never passed on
+        if args.biasfile1 and not os.path.exists(args.biasfile1):
+            print("Error: Couldn't find the specified bias file1")
+            return
+        biasf2 = False
+        if args.biasfile2:
+            if os.path.exists(args.biasfile2):
+                biasf2 = args.biasfile2
+            else:
+                print("Error: Couldn't find the specified bias file2")
+                return
+        o = regulator(f1, f2, args.norm_method, False, args.outdir, bed1=args.bed1, bed2=args.bed2, res=res,
+                      sigma0=args.s_z, s=args.s, verbose=args.verbose, pt=args.pt, pt2=args.pt2, st=args.st,
+                      distance_filter=distFilter, nprocesses=args.nprocesses, bias1=biasf1, bias2=biasf2,
+                      chromosome=chromosome, chromosome2=chromosome2, octaves=args.octaves)
+        if i == 0:
+            for suf in SUFFIX.values():
+                with open(args.outdir + suf, 'w') as fh:
+                    fh.write(HEADER)
+        counts = {1: 0, 2: 0, 3: 0, 4: 0}
+        files = {t: open(args.outdir + suf, 'a') for t, suf in SUFFIX.items()}
+        try:
+            for r in o:
+                counts[r[4]] += 1
+                files[r[4]].write(str(chromosome) + '\t' + str(r[0] * res) + '\t' + str((r[0] + 1) * res) + '\t' +
+                                  str(chromosome2) + '\t' + str(r[1] * res) + '\t' + str((r[1] + 1) * res) + '\t' +
+                                  str(r[2]) + '\t' + str(r[3]) + '\n')
+        finally:
+            for fh in files.values():
+                fh.close()
+        print(f"({counts[1]},{counts[3]}) loops and ({counts[2]},{counts[4]}) differential-loops found in "
+              f"chrmosome={chromosome} for detection-fdr<{args.pt} and difference-fdr<{args.pt2} in {time.time() - t0:.2f}sec")
+        t0 = time.time()
+
+
+if __name__ == '__main__':
+    main()

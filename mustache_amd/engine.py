@@ -158,7 +158,7 @@ class ScaleSpaceEngine:
             buf = self._pin[key] = torch.empty(max(need, 1), dtype=dtype, pin_memory=True)
         return buf[:need].view(*shape)
 
-    def _download(self, found, pval, count, fit, nt, sort=True):
+    def _download(self, found, pval, count, fit, nt, sort=True, extra=None):
         """Found records -> host.  The kernel appends records per workgroup, so their order inside a block is
         arbitrary; with sort=True they are ordered by pixel index on the device first (row-major = the reference's nz
         order, which the tail's look-ups rely on).  Transfers go through cached pinned buffers."""
@@ -179,6 +179,10 @@ class ScaleSpaceEngine:
                 rec = torch.gather(rec, 1, order[..., None].expand(-1, -1, 2))
                 word = rec[..., 0]
                 pv = torch.gather(pv, 1, order)
+            extra_h = {}
+            for name, t in (extra or {}).items():      # further per-record float64 arrays, same order as the records
+                t = t[:, :mx]
+                extra_h[name] = (torch.gather(t, 1, order) if sort else t).cpu().numpy()
             pix_h = self._pinned("pix", (B, mx), torch.int32)
             lvl_h = self._pinned("lvl", (B, mx), torch.uint8)
             val_h = self._pinned("val", (B, mx), torch.int64)
@@ -197,11 +201,58 @@ class ScaleSpaceEngine:
             m = int(cnt[b])
             if m:
                 out.append(dict(pixel=pix_n[b, :m], level=lvl_n[b, :m], value=val_n[b, :m], pval=pv_n[b, :m]))
+                for name, arr in extra_h.items():
+                    out[-1][name] = arr[b, :m]
             else:
                 out.append(dict(pixel=np.zeros(0, np.uint32), level=np.zeros(0, np.uint8), value=np.zeros(0),
                                 pval=np.zeros(0)))
+                for name in (extra or {}):
+                    out[-1][name] = np.zeros(0)
             fits.append((fit_h[b, :nt, 0].copy(), fit_h[b, :nt, 1].copy()))
         return out, fits
+
+    # ---- two-sample additions (reference diff_mustache.py:262-276, :371-385) --------------------------------------------
+    def pair_pvalues(self, c, nz, found, found_cap, count):
+        """c / nz: [2P, CH, CH] filled blocks and masks, sample 1 in [0, P), sample 2 in [P, 2P); found / count: the
+        device records of the 2P-block sigma loop.  Returns ppair [2P, found_cap] (device)."""
+        P2, CH, _ = c.shape
+        P = P2 // 2
+        lt = self.levels
+        n_oct, lpo, tpo = len(lt.octave_values), lt.levels_per_octave, lt.s - 1
+        dev = self.device
+        with torch.cuda.device(dev):
+            cd = torch.empty((P, CH, CH), dtype=torch.float64, device=dev)
+            nzb = torch.empty((P, CH, CH), dtype=torch.uint8, device=dev)
+            nzbc = torch.empty(P, dtype=torch.int32, device=dev)
+            _lib.check(self.lib.mst_diff_image(_ptr(c[:P]), _ptr(c[P:]), _ptr(nz[:P]), _ptr(nz[P:]), P, CH, _ptr(cd),
+                                               _ptr(nzb), _ptr(nzbc), _stream()))
+            g2 = torch.empty((n_oct, P, CH, CH), dtype=torch.float64, device=dev)
+            g3 = torch.empty((n_oct, P, CH, CH), dtype=torch.float64, device=dev)
+            fit = torch.empty((n_oct, P, 2), dtype=torch.float64, device=dev)
+            ws = torch.empty(2048 * P, dtype=torch.uint8, device=dev)
+            for o in range(n_oct):
+                # the reference's Lc of the difference image: G(sigma_2) - G(sigma_3) of the octave (diff_mustache.py:315-336)
+                g2[o] = self.gauss_blur(cd, lt.taps[o * lpo + 1])
+                g3[o] = self.gauss_blur(cd, lt.taps[o * lpo + 2])
+                _lib.check(self.lib.mst_masked_normfit(_ptr(g2[o]), _ptr(g3[o]), _ptr(nzb), _ptr(nzbc), P, CH * CH,
+                                                       _ptr(fit[o]), _ptr(ws), ws.numel(), _stream()))
+            ppair = torch.empty((P2, found_cap), dtype=torch.float64, device=dev)
+            for off in (0, P):
+                _lib.check(self.lib.mst_pair_pvalues(_ptr(found), found_cap, _ptr(count), _ptr(g2), _ptr(g3), _ptr(fit),
+                                                     P, CH, n_oct, tpo, off, _ptr(ppair), _stream()))
+        return ppair, fit
+
+    def run_block_pairs(self, c, dpx, intra=True, skip_empty=True):
+        """c: [2P, CH, CH] raw blocks (sample 1 first, then sample 2), mutated in place.  BlockBatch over all 2P blocks
+        whose records also carry `pair` (the differential p-value)."""
+        nz, nz_count = self.prologue(c, dpx, intra)
+        found, pval, count, fit, cap = self.sigma_loop(c, nz, nz_count, skip_empty=skip_empty, download=False)
+        ppair, nfit = self.pair_pvalues(c, nz, found, cap, count)
+        recs, fits = self._download(found, pval, count, fit, self.levels.n_tested, sort=True, extra={"pair": ppair})
+        B, CH, _ = c.shape
+        batch = BlockBatch(self, c, nz, CH, B, nz_count.cpu().numpy().view(np.uint32).astype(np.int64), recs, fits)
+        batch.norm_fit = nfit.cpu().numpy()
+        return batch
 
     def run_blocks(self, c, dpx, intra=True, skip_empty=True):
         """c: [B, CH, CH] float64 device tensor holding raw (normalised, un-filled) blocks; mutated in place

@@ -56,13 +56,10 @@ def _components(px, py):
     return order, labels, len(uniq)
 
 
-def block_tail(batch, b, start, pt, st, intra=True):
-    """Loops of block b as the reference's list of [x+start, y+start, fdr, sigma] (mustache.py:848)."""
+def fdr_candidates(batch, b, pt, st):
+    """BH over the found p-values of block b, selection q < pt and the sparsity filter (mustache.py:778-811).
+    Returns (q, idx): q per record, idx = indices (into the block's record arrays) of the surviving candidates."""
     CH = batch.CH
-    if batch.nz_count[b] < 50:                      # (:701)
-        return []
-    if batch.nz_count[b] < 10000:                   # (:775)  len(pFound) counts the nz pixels
-        return []
     if not pt <= 1:
         raise ValueError("pThreshold must be <= 1")
     rec = batch.found[b]
@@ -70,32 +67,44 @@ def block_tail(batch, b, start, pt, st, intra=True):
     q = benjamini_hochberg(rec["pval"])             # (:778-779)
     sel = np.nonzero(q < pt)[0]                     # (:789-797)  o < pt can only hold at found pixels (pt <= 1)
     if sel.size == 0:
-        return []
+        return q, sel
     pix = rec["pixel"][sel]
     x = (pix // CH).astype(np.int64)
-    y = (pix % CH).astype(np.int64)
     scale = sigma_t[rec["level"][sel].astype(np.int64) - 1]
     half = np.ceil(scale).astype(np.int64)          # s = math.ceil(xyScales[i])  (:802)
-    cnt1, cnt2, cval = batch.candidate_features(b, pix, half)
+    cnt1, cnt2, _ = batch.candidate_features(b, pix, half)
     c1 = cnt1 / ((2 * half + 1) ** 2)               # (:803-804)
     c2 = cnt2 / ((4 * half + 1) ** 2)               # (:805-807)
     keep = (x != 0) & ~((c1 < st) | (c2 < 0.6))     # (:800, :808)
-    sel, x, y, cval = sel[keep], x[keep], y[keep], cval[keep]
-    if x.size == 0:                                 # (:813)
-        return []
-    if intra:                                       # (:822-828)
-        ks, inv = np.unique(y - x, return_inverse=True)
-        diags = batch.diagonals(b, ks)
-        means = np.empty(len(ks))
-        for i, k in enumerate(ks):
-            dg = diags[i, :CH - int(k)]
-            means[i] = np.mean(dg[dg != 0])
-        ok = cval > 2 * means[inv]
-        if ok.size == 0 or ok.sum() == 0:
-            return []
-        sel, x, y = sel[ok], x[ok], y[ok]
+    return q, sel[keep]
 
-    # clustering (:830-848): candidates + their 8 neighbours, 8-connected, representative = arg-min o per cluster
+
+def diag_mean_filter(batch, b, idx):
+    """c[x, y] > 2 * mean(non-zero entries of that diagonal of the filled block)   (mustache.py:816-828)."""
+    CH = batch.CH
+    if idx.size == 0:
+        return idx
+    pix = batch.found[b]["pixel"][idx]
+    x = (pix // CH).astype(np.int64)
+    y = (pix % CH).astype(np.int64)
+    _, _, cval = batch.candidate_features(b, pix, np.zeros(len(pix), np.int64))
+    ks, inv = np.unique(y - x, return_inverse=True)
+    diags = batch.diagonals(b, ks)
+    means = np.empty(len(ks))
+    for i, k in enumerate(ks):
+        dg = diags[i, :CH - int(k)]
+        means[i] = np.mean(dg[dg != 0])
+    return idx[cval > 2 * means[inv]]
+
+
+def cluster_representatives(batch, b, q, idx):
+    """Clustering (mustache.py:830-848): candidates + their 8 neighbours, 8-connected components in raster order,
+    representative = first arg-min of o over ALL member pixels.  Returns record indices of the representatives."""
+    CH = batch.CH
+    rec = batch.found[b]
+    pix = rec["pixel"][idx]
+    x = (pix // CH).astype(np.int64)
+    y = (pix % CH).astype(np.int64)
     offs = np.array([(0, 0), (1, 0), (1, 1), (0, 1), (-1, 0), (-1, -1), (0, -1), (1, -1), (-1, 1)])
     hx = (x[:, None] + offs[None, :, 0]).ravel()
     hy = (y[:, None] + offs[None, :, 1]).ravel()
@@ -111,15 +120,43 @@ def block_tail(batch, b, start, pt, st, intra=True):
     pos_c = np.minimum(pos, len(fpix) - 1)
     hit = inside & (fpix[pos_c] == mp)
     o = np.where(hit, q[pos_c], 1.5)
-    out = []
+    reps = []
     for lb in range(ncomp):
         mem = np.nonzero(labels == lb)[0]           # raster order (hx, hy sorted)
         i = mem[np.argmin(o[mem])]
         if not hit[i]:
             raise AssertionError("cluster without a found pixel")
-        so = sigma_t[int(rec["level"][pos_c[i]]) - 1]
-        out.append([np.int64(hx[i] + start), np.int64(hy[i] + start), np.float64(o[i]), np.float64(so)])
+        reps.append(int(pos_c[i]))
+    return reps
+
+
+def loops_from_reps(batch, b, q, reps, start):
+    CH = batch.CH
+    rec = batch.found[b]
+    sigma_t = np.asarray(batch.engine.levels.tested_sigma)
+    out = []
+    for r in reps:
+        px = int(rec["pixel"][r])
+        out.append([np.int64(px // CH + start), np.int64(px % CH + start), np.float64(q[r]),
+                    np.float64(sigma_t[int(rec["level"][r]) - 1])])
     return out
+
+
+def block_tail(batch, b, start, pt, st, intra=True):
+    """Loops of block b as the reference's list of [x+start, y+start, fdr, sigma] (mustache.py:848)."""
+    if batch.nz_count[b] < 50:                      # (:701)
+        return []
+    if batch.nz_count[b] < 10000:                   # (:775)  len(pFound) counts the nz pixels
+        return []
+    q, idx = fdr_candidates(batch, b, pt, st)
+    if idx.size == 0:                               # (:813)
+        return []
+    if intra:                                       # (:822-828)
+        idx = diag_mean_filter(batch, b, idx)
+        if idx.size == 0:
+            return []
+    reps = cluster_representatives(batch, b, q, idx)
+    return loops_from_reps(batch, b, q, reps, start)
 
 
 CH_KEY = 1 << 20   # pixel-key radix for the halo set (coordinates can reach CH, one past the block edge)

@@ -19,9 +19,10 @@ from .tail import benjamini_hochberg, block_tail
 from .normalize import normalize_sparse
 from .tiling import block_bounds, block_mask_size, dense_block
 from .pipeline import mustache_block, regulator_coo
+from .diff import diff_block
 
 __all__ = [
     "gaussian_weights", "level_table", "blur_explicit", "blur_scipy", "maxfilter3_zero", "block_prologue",
     "scale_space_levels", "ScaleSpaceResult", "benjamini_hochberg", "block_tail", "normalize_sparse",
-    "block_bounds", "block_mask_size", "dense_block", "mustache_block", "regulator_coo",
+    "block_bounds", "block_mask_size", "dense_block", "mustache_block", "regulator_coo", "diff_block",
 ]

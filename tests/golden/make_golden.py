@@ -261,7 +261,57 @@ def make_regulator(ref):
     print("regulator loops", len(la))
 
 
+def make_diff():
+    """Two-sample path: run the reference's diff_mustache() on one 320x320 block pair and keep its locals."""
+    ref = load_reference("mustache")
+    dref = load_reference("diff_mustache")
+    n, dpx, start = 320, 80, 640
+    xa, ya, va = synth_coo(n, dpx, depth=300.0, seed=51, nloops=30)
+    xb, yb, vb = synth_coo(n, dpx, depth=260.0, seed=52, nloops=30)
+    ref.normalize_sparse(xa, ya, va, 50000, dpx)
+    ref.normalize_sparse(xb, yb, vb, 50000, dpx)
+    c1, c2 = dense(xa, ya, va, n), dense(xb, yb, vb, n)
+    fits = []
+    fit0 = dref.norm.fit
+
+    def nfit(data, *a, **k):
+        r = fit0(data, *a, **k)
+        fits.append((float(r[0]), float(r[1])))
+        return r
+
+    locs = {}
+
+    def tracer(frame, event, arg):
+        if frame.f_code.co_name != "diff_mustache":
+            return None
+
+        def local(frame, event, arg):
+            if event == "return":
+                for k in ("pAll1", "pAll2", "pPair1", "pPair2", "vAll1", "vAll2", "Scales1", "Scales2"):
+                    if k in frame.f_locals:
+                        locs[k] = np.array(frame.f_locals[k], copy=True)
+            return local
+        return local
+
+    dref.norm.fit = nfit
+    sys.settrace(tracer)
+    try:
+        out = dref.diff_mustache(c1.copy(), c2.copy(), "1", "1", 5000, start, start + n, 0, dpx, OCTAVES, 0.8, 0.3, 0.3)
+    finally:
+        sys.settrace(None)
+        dref.norm.fit = fit0
+    np.savez_compressed(os.path.join(HERE, "diff_320.npz"), xa=xa.astype(np.int32), ya=ya.astype(np.int32), va=va,
+                        xb=xb.astype(np.int32), yb=yb.astype(np.int32), vb=vb, n=n, dpx=dpx, start=start,
+                        st=0.8, pt=0.3, pt2=0.3, norm_fit=np.array(fits),
+                        loops1=loops_array(out[0]), diff1=loops_array(out[1]), loops2=loops_array(out[2]),
+                        diff2=loops_array(out[3]), **{"loc_" + k: v for k, v in locs.items()})
+    print("diff", [len(o) for o in out], {k: v.shape for k, v in locs.items()})
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["diff"]:
+        make_diff()
+        sys.exit(0)
     ref = load_reference("mustache")
     which = sys.argv[1:] or ["norm", "blocks", "edges", "tiling", "regulator"]
     if "norm" in which:

@@ -1,0 +1,92 @@
+"""GPU parity of the two-sample path (reference diff_mustache.py:260-569) against a fixture produced by the reference."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+OCT = [1.6, 3.2]
+
+
+def _load(golden_dir):
+    return np.load(os.path.join(golden_dir, "diff_320.npz"), allow_pickle=True)
+
+
+def _blocks(g):
+    n = int(g["n"])
+    c1 = np.zeros((n, n)); c1[g["xa"], g["ya"]] = g["va"]
+    c2 = np.zeros((n, n)); c2[g["xb"], g["yb"]] = g["vb"]
+    return c1, c2
+
+
+def test_pair_records_vs_reference(golden_dir):
+    import torch
+    from mustache_amd.engine import ScaleSpaceEngine
+    g = _load(golden_dir)
+    c1, c2 = _blocks(g)
+    eng = ScaleSpaceEngine(OCT)
+    batch = eng.run_block_pairs(torch.from_numpy(np.stack([c1, c2])).cuda(), int(g["dpx"]))
+    # norm.fit of the difference DoG: one (loc, scale) per octave, repeated for its 9 tested levels in the reference
+    ref_fit = g["norm_fit"]
+    np.testing.assert_allclose(batch.norm_fit[0, 0], ref_fit[0], rtol=1e-9)
+    np.testing.assert_allclose(batch.norm_fit[1, 0], ref_fit[9], rtol=1e-9)
+    for b, nm in ((0, "1"), (1, "2")):
+        rec = batch.found[b]
+        pall, ppair, vall = g["loc_pAll" + nm], g["loc_pPair" + nm], g["loc_vAll" + nm]
+        # the reference keeps per-nz arrays; found pixels are those whose pPair was written (pPair != 2)
+        f = ppair != 2
+        assert f.sum() == len(rec["pixel"])
+        assert np.array_equal(rec["value"], vall[f]), "winning DoG values must be bit-identical"
+        np.testing.assert_allclose(rec["pair"], ppair[f], rtol=1e-5, atol=1e-300)
+
+
+def test_diff_mustache_dropin_vs_reference(golden_dir):
+    from mustache_amd.diff_mustache import diff_mustache
+    g = _load(golden_dir)
+    c1, c2 = _blocks(g)
+    n, dpx, start = int(g["n"]), int(g["dpx"]), int(g["start"])
+    out = diff_mustache(c1, c2, "1", "1", 5000, start, start + n, 0, dpx, OCT, float(g["st"]), float(g["pt"]),
+                        float(g["pt2"]))
+    assert c1[0, 0] == 2 and c2[5, 5] == 2, "both blocks are filled in place like the reference does"
+    for got, key in zip(out, ("loops1", "diff1", "loops2", "diff2")):
+        exp = g[key]
+        arr = np.array([[float(a), float(b), q, s] for a, b, q, s in got]).reshape(-1, 4)
+        assert arr.shape == exp.shape, key
+        assert np.array_equal(arr[:, :2], exp[:, :2]) and np.array_equal(arr[:, 3], exp[:, 3]), key
+        np.testing.assert_allclose(arr[:, 2], exp[:, 2], rtol=1e-9)
+    assert len(g["loops1"]) > 5 and len(g["diff1"]) > 0 and len(g["loops2"]) > 5
+
+
+def test_diff_regulator_equals_blockwise_oracle(tmp_path):
+    """Two text files -> regulator(): 4 tagged lists; checked against the oracle run block by block."""
+    import oracle
+    from mustache_amd.diff_mustache import regulator
+    from mustache_amd.synth import synth_coo
+    n, dpx, res = 2300, 200, 10000
+    files = []
+    coos = []
+    for seed in (61, 62):
+        x, y, v = synth_coo(n, dpx, depth=300.0, seed=seed)
+        f = str(tmp_path / ("s%d.txt" % seed))
+        with open(f, "w") as fh:
+            for a, b, c in zip(x, y, v):
+                fh.write("%d\t%d\t%r\n" % (a * res, b * res, float(c)))
+        files.append(f)
+        coos.append((x, y, v))
+    got = regulator(files[0], files[1], False, False, "unused", res=res, pt=0.2, pt2=0.2, st=0.8,
+                    distance_filter=dpx * res, chromosome="S", verbose=False)
+    # oracle: normalise each sample, same tiling, diff_block per block pair, overlap mask, tags 1..4
+    for x, y, v in coos:
+        oracle.normalize_sparse(x, y, v, res, dpx)
+    CH, start, end = oracle.block_bounds(n, dpx)
+    exp = []
+    for i in range(len(start)):
+        cc = [oracle.dense_block(x, y, v, start[i], end[i], CH) for x, y, v in coos]
+        res4 = oracle.diff_block(cc[0], cc[1], start[i], dpx, OCT, 0.8, 0.2, 0.2)
+        mask = oracle.block_mask_size(i, start, end, dpx)
+        for tag, loops in enumerate(res4, start=1):
+            for lp in loops:
+                if lp[0] >= start[i] + mask or lp[1] >= start[i] + mask:
+                    exp.append((int(lp[0]), int(lp[1]), lp[3], tag))
+    assert len(exp) > 10
+    assert sorted((int(r[0]), int(r[1]), r[3], r[4]) for r in got) == sorted(exp)

@@ -148,3 +148,23 @@ def test_regulator_three_blocks(golden_dir, tmp_path):
     assert np.array_equal(got[:, :2], exp[:, :2])
     np.testing.assert_allclose(got[:, 2], exp[:, 2], rtol=1e-9)
     assert np.array_equal(got[:, 3], exp[:, 3])
+
+
+def test_diff_block_vs_reference(golden_dir):
+    """Two-sample path (diff_mustache.py:260-569): oracle == reference, every per-pixel array and all four lists."""
+    g = _load(golden_dir, "diff_320.npz")
+    n, dpx, start = int(g["n"]), int(g["dpx"]), int(g["start"])
+    c1 = np.zeros((n, n)); c1[g["xa"], g["ya"]] = g["va"]
+    c2 = np.zeros((n, n)); c2[g["xb"], g["yb"]] = g["vb"]
+    res, mid = oracle.diff_block(c1, c2, start, dpx, OCT, float(g["st"]), float(g["pt"]), float(g["pt2"]),
+                                 return_intermediate=True)
+    assert np.array_equal(np.array(mid["fits"]), g["norm_fit"])
+    for k, nm in ((1, "1"), (2, "2")):
+        assert np.array_equal(mid["best"][k], g["loc_vAll" + nm])
+        assert np.array_equal(mid["scale"][k], g["loc_Scales" + nm])
+        assert np.array_equal(mid["p"][k], g["loc_pAll" + nm])
+        assert np.array_equal(mid["pair"][k], g["loc_pPair" + nm])
+    for got, key in zip(res, ("loops1", "diff1", "loops2", "diff2")):
+        arr = np.array([[float(a), float(b), q, s] for a, b, q, s in got]).reshape(-1, 4)
+        assert np.array_equal(arr, g[key]), key
+    assert len(g["loops1"]) > 5 and len(g["diff1"]) > 0

@@ -1,0 +1,143 @@
+"""Binary contact-map readers: `.hic` (hic-straw), `.cool` / `.mcool` (cooler) -> upper-triangular COO in bin units.
+
+Host I/O, not part of the GPU hot path.  The third-party modules are imported lazily --
+they are optional and absent from the offline build image; a missing module raises an ImportError that names it.
+Semantics follow reference mustache/mustache.py:300-396 (read_hic_file), :399-493 (read_cooler), :496-592
+(read_mcooler): the chromosome is fetched in overlapping windows of max(2*dist/res, 2000) bins advancing by window - dist,
+records seen in several windows are kept once, and intra-chromosomal output keeps |x - y| <= dist/res with value > 0.
+Where the reference de-duplicates with Python set differences between consecutive windows, this module de-duplicates on
+the (x, y) key with NumPy (same set of records; the reference's output order is set-iteration order and is not
+reproduced -- nothing downstream depends on it here).
+"""
+import importlib
+
+import numpy as np
+
+
+def _need(module):
+    try:
+        return importlib.import_module(module)
+    except ImportError as e:
+        raise ImportError("reading this file type needs the optional third-party module %r (pip install %s)"
+                          % (module, {"hicstraw": "hic-straw"}.get(module, module))) from e
+
+
+def window_ranges(size_bp, distance_in_bp, res):
+    """(start, end) base-pair windows exactly as the reference walks them (mustache.py:319-363): the first window ends at
+    min(size, W), later ones are capped at size - 1, and the walk stops after the window that ends at size - 1."""
+    W = max(2 * distance_in_bp / res, 2000) * res
+    start, end = 0, min(size_bp, W)
+    out = []
+    while start < size_bp:
+        out.append((int(start), int(end)))
+        start = min(start + W - distance_in_bp, size_bp)
+        if end == size_bp - 1:
+            break
+        end = min(end + W - distance_in_bp, size_bp - 1)
+    return out
+
+
+def _finish(x, y, v, distance_in_bp, res, intra, label):
+    """Common tail (mustache.py:365-396, :477-493): drop NaN rows, NaN values -> 0, distance filter, value > 0."""
+    x, y = np.asarray(x), np.asarray(y)
+    v = np.asarray(v, dtype=np.float64)
+    if len(v) == 0:
+        print(f'There is no contact in chrmosome {label} to work on.')
+        return [], [], []
+    ok = ~(np.isnan(x.astype(np.float64)) | np.isnan(y.astype(np.float64)) | np.isnan(v))
+    x, y, v = x[ok].astype(np.int64), y[ok].astype(np.int64), v[ok]
+    if intra:
+        keep = (np.abs(x - y) <= distance_in_bp / res) & (v > 0)
+        x, y, v = x[keep], y[keep], v[keep]
+    if len(v) == 0:
+        print(f'There is no contact in chrmosome {label} to work on.')
+        return [], [], []
+    return x, y, v
+
+
+def _dedup(xs, ys, vs):
+    x, y, v = np.concatenate(xs), np.concatenate(ys), np.concatenate(vs)
+    key = x.astype(np.int64) * (1 << 32) + y.astype(np.int64)
+    _, first = np.unique(key, return_index=True)
+    first.sort()
+    return x[first], y[first], v[first]
+
+
+def read_hic_file(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, chr2, res):
+    hicstraw = _need("hicstraw")
+    if not CHRM_SIZE:
+        sizes = {"chr" + str(c.name).replace("chr", ''): c.length for c in hicstraw.HiCFile(f).getChromosomes()[1:]}
+        key = "chr" + str(chr1).replace("chr", '')
+        if key not in sizes:
+            raise NameError('wrong chromosome name!')
+        CHRM_SIZE = sizes[key]
+    norm = "KR" if not norm_method else str(norm_method)          # (:328-333)
+    xs, ys, vs = [], [], []
+    for start, end in window_ranges(CHRM_SIZE, distance_in_bp, res):
+        recs = hicstraw.straw("observed", norm, f, "%s:%d:%d" % (chr1, start, end), "%s:%d:%d" % (chr2, start, end),
+                              "BP", res)
+        if len(recs) == 0:
+            continue
+        xs.append(np.array([r.binX for r in recs], dtype=np.float64) // res)
+        ys.append(np.array([r.binY for r in recs], dtype=np.float64) // res)
+        vs.append(np.array([r.counts for r in recs], dtype=np.float64))
+    if not xs:
+        print(f'There is no contact in chrmosome {chr1} to work on.')
+        return [], [], []
+    x, y, v = _dedup(xs, ys, vs)
+    return _finish(x, y, v, distance_in_bp, res, chr1 == chr2, chr1)
+
+
+def _read_cooler_obj(clr, distance_in_bp, chr1, chr2, res, cooler_balance):
+    sparse = _need("scipy.sparse")
+    if chr1 not in clr.chromnames or chr2 not in clr.chromnames:
+        raise NameError('wrong chromosome name!')
+    balance = True if not cooler_balance else cooler_balance     # (:422-425)
+    if chr1 != chr2:
+        m = sparse.triu(clr.matrix(balance=True, sparse=True).fetch(chr1, chr2)).tocoo()
+        return _finish(m.row, m.col, np.nan_to_num(m.data, nan=0, posinf=0, neginf=0), distance_in_bp, res, False, chr1)
+    size = clr.chromsizes[chr1]
+    xs, ys, vs = [], [], []
+    for start, end in window_ranges(size, distance_in_bp, res):
+        m = sparse.triu(clr.matrix(balance=balance, sparse=True).fetch((chr1, start, end))).tocoo()
+        if len(m.row) == 0:
+            continue
+        off = int(start / res)
+        xs.append(off + m.row.astype(np.int64))
+        ys.append(off + m.col.astype(np.int64))
+        vs.append(np.nan_to_num(m.data.astype(np.float64), nan=0, posinf=0, neginf=0))
+    if not xs:
+        print(f'There is no contact in chrmosome {chr1} to work on.')
+        return [], [], []
+    x, y, v = _dedup(xs, ys, vs)
+    return _finish(x, y, v, distance_in_bp, res, True, chr1)
+
+
+def read_cooler(f, distance_in_bp, chr1, chr2, cooler_balance):
+    cooler = _need("cooler")
+    clr = cooler.Cooler(f)
+    res = clr.binsize
+    print(f'Your cooler data resolution is {res}')
+    x, y, v = _read_cooler_obj(clr, distance_in_bp, chr1, chr2, res, cooler_balance)
+    return x, y, v, res
+
+
+def read_mcooler(f, distance_in_bp, chr1, chr2, res, cooler_balance):
+    cooler = _need("cooler")
+    clr = cooler.Cooler('%s::/resolutions/%s' % (f, res))
+    try:
+        return _read_cooler_obj(clr, distance_in_bp, chr1, chr2, res, cooler_balance)
+    except NameError:
+        raise
+    except Exception as e:                      # (:558-559)
+        raise NameError('Reading from the file failed!') from e
+
+
+def list_chromosomes(f, res):
+    """Chromosomes main() iterates when -ch is omitted (mustache.py:1019-1036)."""
+    if f.endswith(".hic"):
+        hicstraw = _need("hicstraw")
+        return [c.name for c in hicstraw.HiCFile(f).getChromosomes()[1:]]
+    cooler = _need("cooler")
+    clr = cooler.Cooler(f if f.endswith(".cool") else '%s::/resolutions/%s' % (f, res))
+    return [name for i, name in enumerate(clr.chromnames) if clr.chromsizes[i] > 1000000]

@@ -82,7 +82,8 @@ class Workload:
         for group in pipe.batches(self.mine, self.CH):
             c, nz, nzc = pipe.blocks_from_band(self.band, self.n, self.dpx, [self.start[i] for i in group], self.CH)
             res = pipe.engine.sigma_loop(c, nz, nzc, skip_empty=skip_empty, download=download, timing=self.kernel_ms,
-                                         sort=False)   # the tail orders records by pixel when it needs look-ups
+                                         sort=False, with_value=False)   # records = (pixel, level, p-value); the tail
+            # orders them by pixel when it needs look-ups, and only the two-sample path reads the DoG values
             out.append(res)
         return out
 

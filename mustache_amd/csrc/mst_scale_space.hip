@@ -45,7 +45,7 @@ struct DevLevels {
     int n_octaves;
     int levels_per_octave;
     int radius[MST_MAX_LEVELS];
-    int pad_;
+    int first_level[16];          // per octave: 1, or 3 when its first two levels repeat the previous octave's last two
     double taps[MST_MAX_LEVELS][MST_MAX_RADIUS + 1];
 };
 
@@ -372,7 +372,11 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
     const int n_oct = lv->n_octaves, lpo = lv->levels_per_octave;
     int tested = 0;
     for (int o = 0; o < n_oct; ++o) {
-        for (int kl = 1; kl <= lpo; ++kl) {
+        // With octaves a factor 2 apart and s = 10, sigma_11 and sigma_12 of one octave are bit-identical to sigma_1 and
+        // sigma_2 of the next (checked on the host), so G_1, G_2 and D_1 of the new octave are exactly the G_11, G_12
+        // and D_11 this thread already holds: the rolling state after the previous octave's last level IS the state
+        // after this octave's second level, and the two blurs are skipped.
+        for (int kl = lv->first_level[o]; kl <= lpo; ++kl) {
             const int l = o * lpo + kl - 1;
             const int r = lv->radius[l];
             double g[K];
@@ -629,6 +633,19 @@ extern "C" int mst_scale_space(const double *c, const uint8_t *nz, int32_t B, in
     for (int l = 0; l < lv->n_octaves * lv->levels_per_octave; ++l) {
         h.radius[l] = lv->radius[l];
         for (int j = 0; j <= lv->radius[l]; ++j) h.taps[l][j] = lv->taps[l][j];
+    }
+    if (lv->n_octaves > 16) return mst::fail(MST_E_ARG, "mst_scale_space: more than 16 octaves");
+    const int lpo = lv->levels_per_octave;
+    for (int o = 0; o < lv->n_octaves; ++o) {
+        h.first_level[o] = 1;
+        if (o == 0 || getenv("MST_NO_LEVEL_REUSE")) continue;
+        bool same = true;
+        for (int q = 0; q < 2 && same; ++q) {
+            const int a = (o - 1) * lpo + lpo - 2 + q, b = o * lpo + q;      // (prev octave, k = lpo-1+q) vs (this, k = 1+q)
+            same = lv->radius[a] == lv->radius[b] &&
+                   memcmp(lv->taps[a], lv->taps[b], sizeof(double) * (lv->radius[a] + 1)) == 0;
+        }
+        if (same) h.first_level[o] = 3;
     }
     DevLevels *d_lv = reinterpret_cast<DevLevels *>(workspace);
     double *partial = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace) + align_up(sizeof(DevLevels), 256));

@@ -77,6 +77,7 @@ class ScaleSpaceEngine:
         self._lv_struct = self.levels.as_struct()
         self._found_cap = {}
         self._pin = {}
+        self._pin_flip = 0
 
     # ---- row 2: COO -> dense blocks ---------------------------------------------------------------------------
     def scatter_blocks(self, x, y, v, starts, CH):
@@ -111,7 +112,8 @@ class ScaleSpaceEngine:
                                                    1 if intra else 0, _stream()))
         return nz, nz_count
 
-    def sigma_loop(self, c, nz, nz_count, skip_empty=True, found_cap=None, download=True, timing=None, sort=True):
+    def sigma_loop(self, c, nz, nz_count, skip_empty=True, found_cap=None, download=True, timing=None, sort=True,
+                   with_value=True):
         """The fused kernel + p-values.  Returns host records (download=True) or the device buffers.
         `timing`: optional list; receives a (start, end) torch.cuda.Event pair bracketing the mst_scale_space launch
         on the launch stream."""
@@ -148,26 +150,31 @@ class ScaleSpaceEngine:
                 timing.append((e0, e1))     # mst_found_pvalues synchronised the stream: the events are complete
         if not download:
             return found, pval, count, fit, found_cap
-        return self._download(found, pval, count, fit, nt, sort=sort)
+        return self._download(found, pval, count, fit, nt, sort=sort, with_value=with_value)
 
     def _pinned(self, key, shape, dtype):
-        """Cached page-locked host staging buffers: D2H of the found records runs at PCIe rate, not pageable rate."""
+        """Page-locked host staging buffers (D2H at PCIe rate).  Two sets alternate, so the arrays handed out by one
+        download stay valid until the second-next download -- long enough for the per-batch tail that consumes them."""
         need = int(np.prod(shape))
-        buf = self._pin.get(key)
+        slot = (key, self._pin_flip)
+        buf = self._pin.get(slot)
         if buf is None or buf.numel() < need or buf.dtype != dtype:
-            buf = self._pin[key] = torch.empty(max(need, 1), dtype=dtype, pin_memory=True)
+            buf = self._pin[slot] = torch.empty(max(need, 1), dtype=dtype, pin_memory=True)
         return buf[:need].view(*shape)
 
-    def _download(self, found, pval, count, fit, nt, sort=True, extra=None):
+    def _download(self, found, pval, count, fit, nt, sort=True, extra=None, with_value=True):
         """Found records -> host.  The kernel appends records per workgroup, so their order inside a block is
         arbitrary; with sort=True they are ordered by pixel index on the device first (row-major = the reference's nz
-        order, which the tail's look-ups rely on).  Transfers go through cached pinned buffers."""
+        order, which the tail's look-ups rely on).  The returned arrays are views into pinned staging memory (see
+        _pinned); with_value=False leaves the winning DoG values on the device (only the two-sample path needs them)."""
+        self._pin_flip ^= 1
         cnt_d = count.to(torch.int64)
         cnt = cnt_d.cpu().numpy()
         fit_h = fit.cpu().numpy()
         B = len(cnt)
         mx = int(cnt.max()) if B else 0
         out, fits = [], []
+        extra_h = {}
         if mx > 0:
             rec = found[:, :mx]
             word = rec[..., 0]
@@ -179,35 +186,38 @@ class ScaleSpaceEngine:
                 rec = torch.gather(rec, 1, order[..., None].expand(-1, -1, 2))
                 word = rec[..., 0]
                 pv = torch.gather(pv, 1, order)
-            extra_h = {}
             for name, t in (extra or {}).items():      # further per-record float64 arrays, same order as the records
                 t = t[:, :mx]
                 extra_h[name] = (torch.gather(t, 1, order) if sort else t).cpu().numpy()
             pix_h = self._pinned("pix", (B, mx), torch.int32)
             lvl_h = self._pinned("lvl", (B, mx), torch.uint8)
-            val_h = self._pinned("val", (B, mx), torch.int64)
             pv_h = self._pinned("pv", (B, mx), torch.float64)
             pix_h.copy_((word & 0xFFFFFFFF).to(torch.int32), non_blocking=True)
             lvl_h.copy_((word >> 32).to(torch.uint8), non_blocking=True)
-            val_h.copy_(rec[..., 1], non_blocking=True)
             pv_h.copy_(pv, non_blocking=True)
+            if with_value:
+                val_h = self._pinned("val", (B, mx), torch.int64)
+                val_h.copy_(rec[..., 1], non_blocking=True)
             torch.cuda.current_stream().synchronize()
-            # per-block views into fresh host arrays (one bulk copy each; the pinned buffers are reused next call)
-            pix_n = pix_h.numpy().view(np.uint32).copy()
-            lvl_n = lvl_h.numpy().copy()
-            val_n = val_h.numpy().view(np.float64).copy()
-            pv_n = pv_h.numpy().copy()
+            pix_n = pix_h.numpy().view(np.uint32)
+            lvl_n = lvl_h.numpy()
+            pv_n = pv_h.numpy()
+            val_n = val_h.numpy().view(np.float64) if with_value else None
         for b in range(B):
             m = int(cnt[b])
             if m:
-                out.append(dict(pixel=pix_n[b, :m], level=lvl_n[b, :m], value=val_n[b, :m], pval=pv_n[b, :m]))
+                d = dict(pixel=pix_n[b, :m], level=lvl_n[b, :m], pval=pv_n[b, :m])
+                if with_value:
+                    d["value"] = val_n[b, :m]
                 for name, arr in extra_h.items():
-                    out[-1][name] = arr[b, :m]
+                    d[name] = arr[b, :m]
             else:
-                out.append(dict(pixel=np.zeros(0, np.uint32), level=np.zeros(0, np.uint8), value=np.zeros(0),
-                                pval=np.zeros(0)))
+                d = dict(pixel=np.zeros(0, np.uint32), level=np.zeros(0, np.uint8), pval=np.zeros(0))
+                if with_value:
+                    d["value"] = np.zeros(0)
                 for name in (extra or {}):
-                    out[-1][name] = np.zeros(0)
+                    d[name] = np.zeros(0)
+            out.append(d)
             fits.append((fit_h[b, :nt, 0].copy(), fit_h[b, :nt, 1].copy()))
         return out, fits
 

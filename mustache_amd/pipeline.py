@@ -60,7 +60,7 @@ class ChromosomePipeline:
         for group in self.batches(mine, CH):
             t0 = time.time()
             c, nz, nzc = self.blocks_from_band(band, n, dpx, [start[i] for i in group], CH)
-            found, fits = self.engine.sigma_loop(c, nz, nzc, skip_empty=skip_empty)
+            found, fits = self.engine.sigma_loop(c, nz, nzc, skip_empty=skip_empty, with_value=False)
             batch = BlockBatch(self.engine, c, nz, CH, len(group),
                                nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
             t1 = time.time()

@@ -105,6 +105,33 @@ __device__ __forceinline__ double lane_next(double x) {
     return __hiloint2double(hi, lo);
 }
 
+// 64-lane reductions with DPP moves only (no LDS round trips): inclusive scans inside the four 16-lane rows
+// (row_shr 1, 2, 4, 8), then row_bcast15 / row_bcast31 carry the row totals upward; lane 63 ends up with the total.
+// The combination order is fixed, so the result is deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fetch(double identity, double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(identity), lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(identity), hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wave_reduce_min_sum(double &mn, double &sm) {
+#define MST_STEP(CTRL, MASK)                                           \
+    {                                                                  \
+        const double a_ = dpp_fetch<CTRL, MASK>(INFINITY, mn);         \
+        const double b_ = dpp_fetch<CTRL, MASK>(0.0, sm);              \
+        mn = a_ < mn ? a_ : mn;                                        \
+        sm = sm + b_;                                                  \
+    }
+    MST_STEP(0x111, 0xf)   // row_shr:1
+    MST_STEP(0x112, 0xf)   // row_shr:2
+    MST_STEP(0x114, 0xf)   // row_shr:4
+    MST_STEP(0x118, 0xf)   // row_shr:8
+    MST_STEP(0x142, 0xa)   // row_bcast:15 -> rows 1 and 3
+    MST_STEP(0x143, 0xc)   // row_bcast:31 -> rows 2 and 3
+#undef MST_STEP
+}
+
 // K output samples from a register window of K + 2R input samples, SciPy's order per sample:
 //     t = x[c]*w0;  for j = R..1:  t += (x[c-j] + x[c+j]) * w[j]
 // The K accumulation chains are independent; the loops are written tap-major so the K adds / muls / adds of one
@@ -201,7 +228,7 @@ __device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const do
 // a full second round).
 template <class T, int R>
 __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__restrict__ vb,
-                                      const double *__restrict__ wg, int tid) {
+                                      const double (&wall)[T::RMAX + 1], int tid) {
     constexpr int K = T::K, KC = Chunk<T::K, R>::KC;
     constexpr int NC = T::RGC + 2 * R;               // columns to produce
     constexpr int NRG = T::RGR / K;                  // 8-row groups
@@ -209,7 +236,7 @@ __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__r
     constexpr int OFF = (T::RMAX - R) & 1;           // parity of the first tap's row index (row0, h*KC are even)
     double w[R + 1];
 #pragma unroll
-    for (int j = 0; j <= R; ++j) w[j] = wg[j];
+    for (int j = 0; j <= R; ++j) w[j] = wall[j];
     if (tid < NRG * MAINC) {
         const int rgp = tid / MAINC;
         const int col = tid - rgp * MAINC;
@@ -243,12 +270,12 @@ __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__r
 
 // Axis-1 pass: thread (row rr, column group cg) -> g[0..K) = G at region columns cg*K .. cg*K+K-1.
 template <class T, int R>
-__device__ __forceinline__ void hpass(const double *__restrict__ vb, const double *__restrict__ wg, int rr, int cg,
+__device__ __forceinline__ void hpass(const double *__restrict__ vb, const double (&wall)[T::RMAX + 1], int rr, int cg,
                                       double (&g)[T::K]) {
     constexpr int K = T::K, KC = Chunk<T::K, R>::KC;
     double w[R + 1];
 #pragma unroll
-    for (int j = 0; j <= R; ++j) w[j] = wg[j];
+    for (int j = 0; j <= R; ++j) w[j] = wall[j];
     const double *p = vb + rr * T::VP + cg * K;
 #pragma unroll
     for (int h = 0; h < K / KC; ++h) {
@@ -260,16 +287,16 @@ __device__ __forceinline__ void hpass(const double *__restrict__ vb, const doubl
 }
 
 template <class T, int R>
-__device__ __forceinline__ void blur_level(const double *ct, double *vb, const double *wg, int tid, int rr, int cg,
-                                           double (&g)[T::K]) {
-    vpass<T, R>(ct, vb, wg, tid);
+__device__ __forceinline__ void blur_level(const double *ct, double *vb, const double (&w)[T::RMAX + 1], int tid,
+                                           int rr, int cg, double (&g)[T::K]) {
+    vpass<T, R>(ct, vb, w, tid);
     __syncthreads();
-    hpass<T, R>(vb, wg, rr, cg, g);
+    hpass<T, R>(vb, w, rr, cg, g);
 }
 
 template <class T>
-__device__ __forceinline__ void blur_dispatch(int r, const double *ct, double *vb, const double *wg, int tid, int rr,
-                                              int cg, double (&g)[T::K]) {
+__device__ __forceinline__ void blur_dispatch(int r, const double *ct, double *vb, const double (&wg)[T::RMAX + 1],
+                                              int tid, int rr, int cg, double (&g)[T::K]) {
 #define MST_CASE(R_)                                                  \
     case R_:                                                          \
         if constexpr (R_ <= T::RMAX) blur_level<T, R_>(ct, vb, wg, tid, rr, cg, g); \
@@ -379,8 +406,12 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
         for (int kl = lv->first_level[o]; kl <= lpo; ++kl) {
             const int l = o * lpo + kl - 1;
             const int r = lv->radius[l];
+            // the level's taps, fetched ONCE (scalar loads, wave-uniform -> SGPRs) and shared by both passes
+            double taps[RMAX + 1];
+#pragma unroll
+            for (int j = 0; j <= RMAX; ++j) taps[j] = lv->taps[l][j];
             double g[K];
-            blur_dispatch<T>(r, ct, vb, lv->taps[l], tid, rr, cg, g);
+            blur_dispatch<T>(r, ct, vb, taps, tid, rr, cg, g);
             double d[K];
             if (kl >= 2) {
 #pragma unroll
@@ -433,16 +464,9 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
                         lsum = lsum + a;
                     }
                 }
-                // fixed-order butterfly inside the wave, then one slot per (level, wave): deterministic
-                if (!(variant & 2))
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const double omin = __shfl_xor(lmin, off, 64);
-                    const double osum = __shfl_xor(lsum, off, 64);
-                    lmin = omin < lmin ? omin : lmin;
-                    lsum = lsum + osum;
-                }
-                if (lane == 0) {
+                // fixed-order DPP reduction inside the wave (total lands in lane 63), one slot per (level, wave)
+                if (!(variant & 2)) wave_reduce_min_sum(lmin, lsum);
+                if (lane == 63) {
                     st[(tested * T::NW + wave) * 2] = lmin;
                     st[(tested * T::NW + wave) * 2 + 1] = lsum;
                 }

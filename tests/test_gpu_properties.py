@@ -1,0 +1,89 @@
+"""Size-independent properties at BASELINE's full block sizes, non-default scale-space parameters, determinism."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _normalised_block(n, dpx, seed, res):
+    """A dense near-diagonal block cut from a synthetic chromosome, normalised on the GPU."""
+    import torch
+    from mustache_amd.normalize import band_from_coo, normalize_band
+    from mustache_amd.pipeline import ChromosomePipeline
+    from mustache_amd.synth import band_counts, band_to_coo
+    dev = "cuda"
+    N = n + dpx
+    band = band_counts(N, dpx, 300.0, max(N // 32, 1), seed, device=dev)
+    band, _, _ = normalize_band(band, N, dpx, res)
+    pipe = ChromosomePipeline([1.6, 3.2])
+    c, nz, cnt = pipe.blocks_from_band(band, N, dpx, [dpx // 2], n)
+    return pipe, c, nz, cnt
+
+
+@pytest.mark.parametrize("n,dpx,res", [(4000, 2000, 1000), (2000, 400, 5000)])
+def test_full_size_block_properties(n, dpx, res):
+    """BASELINE shapes (4000^2 @ 1 kb, 2000^2 @ 5 kb): skipping empty tiles changes nothing; two runs are bit-identical
+    (no float atomics); every found pixel is a tested pixel inside the band with a positive response and p in [0, 1]."""
+    pipe, c, nz, cnt = _normalised_block(n, dpx, 5, res)
+    eng = pipe.engine
+    a, fa = eng.sigma_loop(c, nz, cnt, skip_empty=True)
+    b, fb = eng.sigma_loop(c, nz, cnt, skip_empty=False)
+    a2, fa2 = eng.sigma_loop(c, nz, cnt, skip_empty=True)
+    ra, rb, ra2 = a[0], b[0], a2[0]
+    for k in ("pixel", "level", "value", "pval"):
+        assert np.array_equal(ra[k], rb[k]), "dense and band-skipping runs must agree exactly (%s)" % k
+        assert np.array_equal(ra[k], ra2[k]), "run-to-run determinism (%s)" % k
+    assert np.array_equal(fa[0][0], fb[0][0]) and np.array_equal(fa[0][1], fb[0][1])
+    m = len(ra["pixel"])
+    assert m > 1000
+    assert np.all(np.diff(ra["pixel"].astype(np.int64)) > 0), "records sorted by pixel, no duplicates"
+    x, y = ra["pixel"].astype(np.int64) // n, ra["pixel"].astype(np.int64) % n
+    nzh = nz[0].cpu().numpy().astype(bool)
+    assert nzh[x, y].all() and np.all(y - x >= 4) and np.all(y - x <= dpx + 1)
+    assert np.all(ra["value"] > 0) and np.all((ra["level"] >= 1) & (ra["level"] <= 18))
+    assert np.all((ra["pval"] >= 0) & (ra["pval"] <= 1))
+    # a found pixel is a strict local maximum of its level among found neighbours of the same level? not required;
+    # but no two 8-adjacent pixels can both be found at the SAME level with equal value unless tied
+    loc, scale = fa[0]
+    assert np.all(scale > 0) and np.all(loc >= 0)
+
+
+@pytest.mark.parametrize("octaves,sz", [([1.6, 3.2, 6.4], None), ([2.0, 4.0], None), ([1.2], None)])
+def test_non_default_octaves_vs_oracle(octaves, sz):
+    """-sz / -oc variants: other radii (up to 28 uses the small-tile instantiation), 1 or 3 octaves, no level reuse."""
+    import oracle
+    from mustache_amd.mustache import mustache
+    from mustache_amd.synth import synth_coo
+    n, dpx = 384, 96
+    x, y, v = synth_coo(n, dpx, depth=300.0, seed=9, nloops=30)
+    oracle.normalize_sparse(x, y, v, 50000, dpx)
+    c = np.zeros((n, n))
+    c[x, y] = v
+    exp, mid = oracle.mustache_block(c.copy(), 0, dpx, octaves, 0.7, 0.3, return_intermediate=True)
+    got = mustache(c, "1", "1", 5000, [], 0, n, 0, dpx, octaves, 0.7, 0.3)
+    assert len(exp) > 0
+    assert [(int(a), int(b), s) for a, b, _, s in got] == [(int(a), int(b), s) for a, b, _, s in exp]
+    np.testing.assert_allclose([q for _, _, q, _ in got], [q for _, _, q, _ in exp], rtol=1e-9)
+
+
+def test_unsupported_radius_fails_loudly():
+    from mustache_amd.mustache import mustache
+    c = np.zeros((256, 256))
+    with pytest.raises(ValueError, match="radius"):
+        mustache(c, "1", "1", 5000, [], 0, 256, 0, 60, [1.6, 3.2, 6.4, 12.8], 0.8, 0.1)
+
+
+def test_ragged_and_tiny_blocks():
+    """Odd block edge (scalar prologue path, partial tiles), a block smaller than one tile, and an all-zero block."""
+    import oracle
+    from mustache_amd.mustache import mustache
+    from mustache_amd.synth import synth_coo
+    for n, dpx in ((333, 90), (61, 40)):
+        x, y, v = synth_coo(n, dpx, depth=300.0, seed=3)
+        oracle.normalize_sparse(x, y, v, 50000, dpx)
+        c = np.zeros((n, n))
+        c[x, y] = v
+        exp = oracle.mustache_block(c.copy(), 7, dpx, [1.6, 3.2], 0.7, 0.3)
+        got = mustache(c, "1", "1", 5000, [], 7, n + 7, 0, dpx, [1.6, 3.2], 0.7, 0.3)
+        assert [(int(a), int(b), s) for a, b, _, s in got] == [(int(a), int(b), s) for a, b, _, s in exp]
+    assert mustache(np.zeros((128, 128)), "1", "1", 5000, [], 0, 128, 0, 40, [1.6, 3.2], 0.8, 0.1) == []

@@ -39,6 +39,10 @@
 #include <cstring>
 #include "mst_common.h"
 
+#ifndef MST_KC8_BELOW
+#define MST_KC8_BELOW 11      // radii below this use one 8-output window per item, wider ones two 4-output windows
+#endif
+
 namespace {
 
 struct DevLevels {
@@ -157,7 +161,7 @@ __device__ __forceinline__ void fir_sym(const double (&win)[K + 2 * R], const do
 // of 4 so window + accumulators + the per-pixel sieve state stay inside the 256-VGPR budget.
 template <int K, int R>
 struct Chunk {
-    static constexpr int KC = (K >= 8 && R < 11) ? 8 : (K >= 4 ? 4 : K);
+    static constexpr int KC = (K >= 8 && R < MST_KC8_BELOW) ? 8 : (K >= 4 ? 4 : K);
 };
 
 // One FIR chunk: KC outputs whose first tap sits at p[OFF]; p is 16-byte aligned, OFF is 0 or 1.
@@ -228,7 +232,8 @@ __device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const do
 // a full second round).
 template <class T, int R>
 __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__restrict__ vb,
-                                      const double (&wall)[T::RMAX + 1], int tid) {
+                                      const double (&wall)[T::RMAX + 1], int tid, const double *__restrict__ vsrc,
+                                      double *__restrict__ vdst) {
     constexpr int K = T::K, KC = Chunk<T::K, R>::KC;
     constexpr int NC = T::RGC + 2 * R;               // columns to produce
     constexpr int NRG = T::RGR / K;                  // 8-row groups
@@ -237,12 +242,12 @@ __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__r
     double w[R + 1];
 #pragma unroll
     for (int j = 0; j <= R; ++j) w[j] = wall[j];
-    if (tid < NRG * MAINC) {
-        const int rgp = tid / MAINC;
-        const int col = tid - rgp * MAINC;
-        const int row0 = rgp * K;
-        const double *p = ct + ((T::RMAX - R) + col) * T::CTP + (row0 + T::RMAX - R - OFF);
-        double *q = vb + row0 * T::VP + col;
+    static_assert(MAINC == T::NT / NRG, "the main-item mapping below is radius independent");
+    {
+        // vsrc = ct + col * CTP + row0, vdst = vb + row0 * VP + col for this thread's (8-row group, column): computed once
+        // per tile; the radius only adds a compile-time constant that folds into the ds_read offset field
+        const double *p = vsrc + (T::RMAX - R) * T::CTP + (T::RMAX - R - OFF);
+        double *q = vdst;
 #pragma unroll
         for (int h = 0; h < K / KC; ++h) {
             double t[KC];
@@ -270,13 +275,12 @@ __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__r
 
 // Axis-1 pass: thread (row rr, column group cg) -> g[0..K) = G at region columns cg*K .. cg*K+K-1.
 template <class T, int R>
-__device__ __forceinline__ void hpass(const double *__restrict__ vb, const double (&wall)[T::RMAX + 1], int rr, int cg,
+__device__ __forceinline__ void hpass(const double *__restrict__ p, const double (&wall)[T::RMAX + 1],
                                       double (&g)[T::K]) {
     constexpr int K = T::K, KC = Chunk<T::K, R>::KC;
     double w[R + 1];
 #pragma unroll
     for (int j = 0; j <= R; ++j) w[j] = wall[j];
-    const double *p = vb + rr * T::VP + cg * K;
 #pragma unroll
     for (int h = 0; h < K / KC; ++h) {
         double t[KC];
@@ -288,18 +292,19 @@ __device__ __forceinline__ void hpass(const double *__restrict__ vb, const doubl
 
 template <class T, int R>
 __device__ __forceinline__ void blur_level(const double *ct, double *vb, const double (&w)[T::RMAX + 1], int tid,
-                                           int rr, int cg, double (&g)[T::K]) {
-    vpass<T, R>(ct, vb, w, tid);
+                                           const double *vsrc, double *vdst, const double *hsrc, double (&g)[T::K]) {
+    vpass<T, R>(ct, vb, w, tid, vsrc, vdst);
     __syncthreads();
-    hpass<T, R>(vb, w, rr, cg, g);
+    hpass<T, R>(hsrc, w, g);
 }
 
 template <class T>
 __device__ __forceinline__ void blur_dispatch(int r, const double *ct, double *vb, const double (&wg)[T::RMAX + 1],
-                                              int tid, int rr, int cg, double (&g)[T::K]) {
+                                              int tid, const double *vsrc, double *vdst, const double *hsrc,
+                                              double (&g)[T::K]) {
 #define MST_CASE(R_)                                                  \
     case R_:                                                          \
-        if constexpr (R_ <= T::RMAX) blur_level<T, R_>(ct, vb, wg, tid, rr, cg, g); \
+        if constexpr (R_ <= T::RMAX) blur_level<T, R_>(ct, vb, wg, tid, vsrc, vdst, hsrc, g); \
         break;
     switch (r) {
         MST_CASE(1) MST_CASE(2) MST_CASE(3) MST_CASE(4) MST_CASE(5) MST_CASE(6) MST_CASE(7)
@@ -392,9 +397,17 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
         lvl[k] = 0;
     }
     const int wave = tid >> 6, lane = tid & 63;
+    const bool all_tested = __all(nz_mask == ((1u << K) - 1u));
     double *de_mine = de + (cg * 2) * RGR + rr;                                   // [cg][0 = left edge, 1 = right edge][rr]
     const double *de_left = de + ((cg > 0 ? cg - 1 : 0) * 2 + 1) * RGR + rr;      // left neighbour's right edge
     const double *de_right = de + ((cg < T::NCG - 1 ? cg + 1 : cg) * 2) * RGR + rr;  // right neighbour's left edge
+
+    // thread-constant LDS addresses of the blur passes
+    constexpr int V_MAINC = T::NT / (T::RGR / K);
+    const int v_rgp = tid / V_MAINC, v_col = tid - v_rgp * V_MAINC;
+    const double *vsrc = ct + v_col * T::CTP + v_rgp * K;
+    double *vdst = vb + (v_rgp * K) * T::VP + v_col;
+    const double *hsrc = vb + rr * T::VP + cg * K;
 
     const int n_oct = lv->n_octaves, lpo = lv->levels_per_octave;
     int tested = 0;
@@ -411,7 +424,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
 #pragma unroll
             for (int j = 0; j <= RMAX; ++j) taps[j] = lv->taps[l][j];
             double g[K];
-            blur_dispatch<T>(r, ct, vb, taps, tid, rr, cg, g);
+            blur_dispatch<T>(r, ct, vb, taps, tid, vsrc, vdst, hsrc, g);
             double d[K];
             if (kl >= 2) {
 #pragma unroll
@@ -588,10 +601,13 @@ int check_levels(const mst_levels *lv, int *max_radius, int *n_tested) {
 #ifndef MST_TILE_K
 #define MST_TILE_K 8
 #endif
+#ifndef MST_TILE_W
+#define MST_TILE_W 64
+#endif
 #if MST_TILE_K == 4
 using TileDefault = Tile<32, 64, 14, 4, 4>;   // 512 threads x 4 pixels, 128 VGPRs -> 4 waves per SIMD
 #else
-using TileDefault = Tile<32, 64, 14>;   // the reference's default octaves (radius <= 14): 77 KB LDS, 256 threads, 2 per CU
+using TileDefault = Tile<32, MST_TILE_W, 14>;   // the reference's default octaves (radius <= 14)
 #endif
 using TileWide = Tile<32, 32, 28>;      // -sz / -oc variants up to radius 28: smaller tile, same code
 

@@ -95,17 +95,17 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 
 __device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }
 
-// value held by the previous / next lane (lane 0 / 63 keep their own): DPP wave shifts, no LDS traffic
+// value held by the previous / next lane: DPP wave shifts, no LDS traffic.  bound_ctrl is set, so the lane without a
+// source (0 for prev, 63 for next) reads 0.0 and no `old` operand has to be copied in first; those lanes hold ring
+// rows whose maxima are never used.
 __device__ __forceinline__ double lane_prev(double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xf, 0xf, true);   // wave_shr:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double lane_next(double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xf, 0xf, true);   // wave_shl:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 

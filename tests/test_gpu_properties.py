@@ -87,3 +87,36 @@ def test_ragged_and_tiny_blocks():
         got = mustache(c, "1", "1", 5000, [], 7, n + 7, 0, dpx, [1.6, 3.2], 0.7, 0.3)
         assert [(int(a), int(b), s) for a, b, _, s in got] == [(int(a), int(b), s) for a, b, _, s in exp]
     assert mustache(np.zeros((128, 128)), "1", "1", 5000, [], 0, 128, 0, 40, [1.6, 3.2], 0.8, 0.1) == []
+
+
+@pytest.mark.parametrize("depth,seed", [(6.0, 17), (1.5, 18)])
+def test_sparse_block_vs_oracle(depth, seed):
+    """Sparse contact maps (most far-diagonal pixels are exact zeros, like real 1 kb data): partially tested tiles, runs
+    of identical DoG values, tiles with a handful of nz pixels -- found set and loops must still equal the oracle's."""
+    import torch
+    import oracle
+    from mustache_amd.engine import ScaleSpaceEngine
+    from mustache_amd.mustache import mustache
+    from mustache_amd.synth import synth_coo
+    n, dpx = 700, 300
+    x, y, v = synth_coo(n, dpx, depth=depth, seed=seed, nloops=40)
+    oracle.normalize_sparse(x, y, v, 20000, dpx)
+    c = np.zeros((n, n))
+    c[x, y] = v
+    frac = (c != 0).sum() / (n * dpx)
+    assert frac < 0.8
+    ref = c.copy()
+    nz = oracle.block_prologue(ref, dpx)
+    ss = oracle.scale_space_levels(ref, nz, [1.6, 3.2])
+    eng = ScaleSpaceEngine([1.6, 3.2])
+    dev = torch.from_numpy(c.copy()).cuda().unsqueeze(0)
+    nzd, cnt = eng.prologue(dev, dpx, True)
+    found, fits = eng.sigma_loop(dev, nzd, cnt)
+    f = ss.pval != 2
+    assert np.array_equal(found[0]["pixel"].astype(np.int64), np.flatnonzero(nz.ravel())[f])
+    assert np.array_equal(found[0]["value"], ss.best[f])
+    assert np.array_equal(found[0]["level"].astype(np.int64), ss.level[f])
+    np.testing.assert_allclose(found[0]["pval"], ss.pval[f], rtol=1e-9)
+    exp = oracle.mustache_block(c.copy(), 0, dpx, [1.6, 3.2], 0.5, 0.3)
+    got = mustache(c, "1", "1", 5000, [], 0, n, 0, dpx, [1.6, 3.2], 0.5, 0.3)
+    assert [(int(a), int(b), s) for a, b, _, s in got] == [(int(a), int(b), s) for a, b, _, s in exp]

@@ -102,9 +102,13 @@ diag_stats_kernel(const double *__restrict__ band, int64_t n, double *__restrict
 }
 
 // Branch A (mustache.py:632-669): sliding-window z-score.  One workgroup = SEG consecutive positions of one
-// diagonal; the SEG + W samples it needs (+0.001 shift applied, and their squares) are staged in LDS once and every
-// window is summed directly from there.
+// diagonal; the SEG + W samples it needs (+0.001 shift applied, and their squares) are staged in LDS once, together
+// with the sums of every 16-sample block aligned to absolute position (i mod 16 == 0).  A window is then summed as
+// head (<= 15 samples) + whole aligned blocks + tail (<= 15 samples): ~150 additions instead of W = 2000, in an order
+// that depends only on the window's absolute position (deterministic, independent of how the diagonal is segmented),
+// and with the rounding behaviour of a two-level (blocked) summation.
 constexpr int kSeg = 1024;
+constexpr int kBlk = 16;
 
 __global__ void __launch_bounds__(kThreads)
 normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ band_out, int64_t n, int W,
@@ -115,11 +119,16 @@ normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ 
     const int64_t seg0 = (int64_t)blockIdx.x * kSeg;
     if (seg0 >= L) return;
     const int left = W / 2;                 // np.convolve(..., 'same'): window = [i - W/2, i - W/2 + W - 1]
-    const int tile = kSeg + W;
-    double *val = lds, *sq = lds + tile;
+    // tile element t <-> absolute position base + t; base is rounded DOWN to a multiple of kBlk so LDS blocks are the
+    // absolute aligned blocks
+    const int64_t first = seg0 - left;
+    const int64_t base = (first >= 0 ? first : first - (kBlk - 1)) / kBlk * kBlk;      // floor to multiple of kBlk
+    const int tile = (int)(seg0 + kSeg - 1 - left + W - base) + 1;                     // covers the last window's end
+    const int nblk = (tile + kBlk - 1) / kBlk;
+    double *val = lds, *sq = val + nblk * kBlk, *b1 = sq + nblk * kBlk, *b2 = b1 + nblk;
+    int *bc = reinterpret_cast<int *>(b2 + nblk);
     const double *row = band_in + (int64_t)d * n;
-    const int64_t base = seg0 - left;       // position of tile element 0
-    for (int t = threadIdx.x; t < tile; t += kThreads) {
+    for (int t = threadIdx.x; t < nblk * kBlk; t += kThreads) {
         const int64_t i = base + t;
         double v = 0.0;
         if (i >= 0 && i < L) {
@@ -130,42 +139,67 @@ normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ 
         sq[t] = v * v;                      // vals ** 2             (:649)
     }
     __syncthreads();
+    for (int q = threadIdx.x; q < nblk; q += kThreads) {
+        double s1 = 0.0, s2 = 0.0;
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < kBlk; ++u) {
+            const double a = val[q * kBlk + u];
+            c += (a != 0.0) ? 1 : 0;
+            s1 = s1 + a;
+            s2 = s2 + sq[q * kBlk + u];
+        }
+        b1[q] = s1;
+        b2[q] = s2;
+        bc[q] = c;
+    }
+    __syncthreads();
     const double mean = diag_stats[4 * d + 0], sd = diag_stats[4 * d + 1], wgt = diag_stats[4 * d + 2];
     const double std2 = sd * sd;
     double *orow = band_out + (int64_t)d * n;
     for (int k = threadIdx.x; k < kSeg; k += kThreads) {
         const int64_t i = seg0 + k;
         if (i >= L) break;
-        const double x = val[k + left];
+        const int ta = (int)(i - left - base);          // window = tile elements [ta, ta + W - 1]
+        const double x = val[ta + left];
         double z = 0.0;
         if (x != 0.0) {
+            const int tb = ta + W;                       // exclusive end
+            const int A = (ta + kBlk - 1) / kBlk * kBlk; // first aligned block start >= ta
+            const int B = tb / kBlk * kBlk;              // last aligned block end <= tb
             double s1 = 0.0, s2 = 0.0;
             int c = 0;
-            // two-level summation (16-sample partials, then the partials): keeps the rounding error of a
-            // 2000-sample window near that of a pairwise / multi-accumulator BLAS dot
-            int j = 0;
-            for (; j + 16 <= W; j += 16) {
-                double p1 = 0.0, p2 = 0.0;
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const double a = val[k + j + u];
+            if (A <= B) {
+                double h1 = 0.0, h2 = 0.0;
+                for (int t = ta; t < A; ++t) {           // head
+                    const double a = val[t];
                     c += (a != 0.0) ? 1 : 0;
-                    p1 = p1 + a;
-                    p2 = p2 + sq[k + j + u];
+                    h1 = h1 + a;
+                    h2 = h2 + sq[t];
                 }
-                s1 = s1 + p1;
-                s2 = s2 + p2;
-            }
-            {
-                double p1 = 0.0, p2 = 0.0;
-                for (; j < W; ++j) {
-                    const double a = val[k + j];
+                s1 = h1;
+                s2 = h2;
+                for (int q = A / kBlk; q < B / kBlk; ++q) {   // whole aligned blocks
+                    c += bc[q];
+                    s1 = s1 + b1[q];
+                    s2 = s2 + b2[q];
+                }
+                double t1 = 0.0, t2 = 0.0;
+                for (int t = B; t < tb; ++t) {           // tail
+                    const double a = val[t];
                     c += (a != 0.0) ? 1 : 0;
-                    p1 = p1 + a;
-                    p2 = p2 + sq[k + j];
+                    t1 = t1 + a;
+                    t2 = t2 + sq[t];
                 }
-                s1 = s1 + p1;
-                s2 = s2 + p2;
+                s1 = s1 + t1;
+                s2 = s2 + t2;
+            } else {                                      // window shorter than one aligned block
+                for (int t = ta; t < tb; ++t) {
+                    const double a = val[t];
+                    c += (a != 0.0) ? 1 : 0;
+                    s1 = s1 + a;
+                    s2 = s2 + sq[t];
+                }
             }
             const double cnt = (double)c;
             double var = (s2 - s1 * s1 / cnt) / (cnt - 1.0);        // (:650)
@@ -310,10 +344,11 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
     diag_stats_kernel<<<nd, kThreads, 0, s>>>(band_in, n, diag_stats);
     MST_LAUNCH_CHECK();
     if (local) {
-        if (window < 2 || (size_t)(kSeg + window) * 16 > 160 * 1024)
-            return mst::fail(MST_E_ARG, "mst_normalize_band: window %d outside [2, %d]", window,
-                             160 * 1024 / 16 - kSeg);
-        const size_t lds = sizeof(double) * 2 * (size_t)(kSeg + window);
+        // LDS: 2 doubles per staged sample + 2 doubles and an int per 16-sample block, for up to SEG + W + 2*16 samples
+        const size_t nblk = (size_t)(kSeg + window + 2 * kBlk + kBlk - 1) / kBlk;
+        const size_t lds = sizeof(double) * (2 * nblk * kBlk + 2 * nblk) + sizeof(int) * nblk + 16;
+        if (window < 2 || lds > 160 * 1024)
+            return mst::fail(MST_E_ARG, "mst_normalize_band: window %d outside [2, ~8800]", window);
         static bool attr_set = false;
         if (!attr_set) {
             MST_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&normalize_local_kernel),

@@ -114,6 +114,13 @@ int mst_found_pvalues(const mst_found *found, uint32_t found_cap, const uint32_t
                       const uint32_t *nz_count, const double *level_stats, int32_t B, int32_t n_tested,
                       double *pval, double *fit, void *stream);
 
+/* mustache.py:778, multipletests(p, method='fdr_bh') per block, on the device: q[b][i] for the first count[b] records of
+ * each block (sort ascending, p * m / rank with NumPy's operation order, suffix minimum, clip at 1, back to record order).
+ * pval, q: dev [B][cap]; count: dev [B]; workspace: dev, >= mst_bh_workspace_bytes(B, cap). */
+uint64_t mst_bh_workspace_bytes(int32_t B, uint32_t cap);
+int mst_bh_fdr(const double *pval, const uint32_t *count, int32_t B, uint32_t cap, double *q, void *workspace,
+               uint64_t workspace_bytes, void *stream);
+
 /* mustache.py:800-811 + :824 inputs for a list of candidate pixels of ONE block b:
  * cnt1[i] = sum nz[x-s:x+s+1, y-s:y+s+1], cnt2[i] = same with 2s (Python slice semantics: a window whose start
  * is negative is empty -> 0; windows are clipped at the far edge), cval[i] = c[x, y].

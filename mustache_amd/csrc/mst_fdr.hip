@@ -1,0 +1,110 @@
+// Benjamini-Hochberg FDR on the device, one segment per block (reference mustache/mustache.py:778:
+// statsmodels.stats.multitest.multipletests(p, method='fdr_bh')).
+//   sort p ascending (hipCUB segmented radix sort, keys = p, values = record index)
+//   adj[i] = p_sorted[i] / ((i + 1) / m)            -- the same two IEEE divisions statsmodels / NumPy perform
+//   q_sorted[i] = min(adj[i..m-1]), clipped at 1     -- min is exact, so the parallel suffix-min is bit-identical
+//   q[record] = q_sorted[rank(record)]
+// Ties in p receive equal q, so the (unstable) order among equal keys does not matter.
+#include <hipcub/hipcub.hpp>
+#include <cmath>
+#include "mst_common.h"
+
+namespace {
+
+constexpr int kBH = 1024;
+
+__global__ void __launch_bounds__(256)
+bh_setup_kernel(const uint32_t *__restrict__ count, uint32_t cap, int B, int *__restrict__ seg_begin,
+                int *__restrict__ seg_end, uint32_t *__restrict__ idx) {
+    const int b = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t m = count[b] < cap ? count[b] : cap;
+        seg_begin[b] = (int)((size_t)b * cap);
+        seg_end[b] = (int)((size_t)b * cap + m);
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x)
+        idx[(size_t)b * cap + i] = i;
+}
+
+__global__ void __launch_bounds__(kBH)
+bh_adjust_kernel(const double *__restrict__ ps, const uint32_t *__restrict__ idx_sorted,
+                 const uint32_t *__restrict__ count, uint32_t cap, double *__restrict__ q) {
+    __shared__ double chunk_min[kBH];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const uint32_t m = count[b] < cap ? count[b] : cap;
+    if (m == 0) return;
+    const double *p = ps + (size_t)b * cap;
+    const uint32_t *id = idx_sorted + (size_t)b * cap;
+    double *qb = q + (size_t)b * cap;
+    const uint32_t L = (m + kBH - 1) / kBH;
+    const uint32_t lo = t * L < m ? t * L : m, hi = (t + 1) * L < m ? (t + 1) * L : m;
+    const double dm = (double)m;
+    double mn = INFINITY;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const double adj = p[i] / ((double)(i + 1) / dm);
+        mn = adj < mn ? adj : mn;
+    }
+    chunk_min[t] = mn;
+    __syncthreads();
+    // suffix minimum over the chunks (inclusive), log-step scan
+    for (int off = 1; off < kBH; off <<= 1) {
+        const double other = (t + off < kBH) ? chunk_min[t + off] : INFINITY;
+        __syncthreads();
+        if (other < chunk_min[t]) chunk_min[t] = other;
+        __syncthreads();
+    }
+    double run = (t + 1 < kBH) ? chunk_min[t + 1] : INFINITY;      // minimum over all later chunks
+    for (uint32_t i = hi; i > lo; --i) {
+        const double adj = p[i - 1] / ((double)i / dm);
+        run = adj < run ? adj : run;
+        qb[id[i - 1]] = run > 1.0 ? 1.0 : run;
+    }
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t sort_temp_bytes(int B, uint32_t cap) {
+    size_t bytes = 0;
+    hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, bytes, (const double *)nullptr, (double *)nullptr,
+                                               (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)((size_t)B * cap), B,
+                                               (const int *)nullptr, (const int *)nullptr, 0, 64, (hipStream_t)0);
+    return bytes;
+}
+
+}  // namespace
+
+extern "C" uint64_t mst_bh_workspace_bytes(int32_t B, uint32_t cap) {
+    if (B <= 0 || cap == 0 || (size_t)B * cap > 0x7FFFFFFFull) return 0;
+    const size_t n = (size_t)B * cap;
+    return align_up(sizeof(int) * 2 * B, 256) + align_up(sizeof(uint32_t) * n, 256) * 2 + align_up(sizeof(double) * n, 256) +
+           align_up(sort_temp_bytes(B, cap), 256);
+}
+
+extern "C" int mst_bh_fdr(const double *pval, const uint32_t *count, int32_t B, uint32_t cap, double *q, void *workspace,
+                          uint64_t workspace_bytes, void *stream) {
+    if (!pval || !count || !q || !workspace || B <= 0 || B > 65535 || cap == 0 || (size_t)B * cap > 0x7FFFFFFFull)
+        return mst::fail(MST_E_ARG, "mst_bh_fdr: bad argument (B * cap must fit in int32)");
+    if (workspace_bytes < mst_bh_workspace_bytes(B, cap))
+        return mst::fail(MST_E_ARG, "mst_bh_fdr: workspace too small");
+    hipStream_t s = mst::as_stream(stream);
+    const size_t n = (size_t)B * cap;
+    char *w = reinterpret_cast<char *>(workspace);
+    int *seg_begin = reinterpret_cast<int *>(w);
+    int *seg_end = seg_begin + B;
+    w += align_up(sizeof(int) * 2 * B, 256);
+    uint32_t *idx_in = reinterpret_cast<uint32_t *>(w);
+    w += align_up(sizeof(uint32_t) * n, 256);
+    uint32_t *idx_out = reinterpret_cast<uint32_t *>(w);
+    w += align_up(sizeof(uint32_t) * n, 256);
+    double *keys_out = reinterpret_cast<double *>(w);
+    w += align_up(sizeof(double) * n, 256);
+    size_t temp = sort_temp_bytes(B, cap);
+    const int gx = (int)((cap + 255) / 256 < 1024 ? (cap + 255) / 256 : 1024);
+    bh_setup_kernel<<<dim3(gx, B), 256, 0, s>>>(count, cap, B, seg_begin, seg_end, idx_in);
+    MST_LAUNCH_CHECK();
+    MST_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(w, temp, pval, keys_out, idx_in, idx_out, (int)n, B, seg_begin,
+                                                        seg_end, 0, 64, s));
+    bh_adjust_kernel<<<B, kBH, 0, s>>>(keys_out, idx_out, count, cap, q);
+    MST_LAUNCH_CHECK();
+    return MST_OK;
+}

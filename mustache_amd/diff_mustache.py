@@ -157,7 +157,8 @@ def _pairs_from_filled(eng, pipe, dbands, n, dpx, starts, CH):
     del c1, c2, nz1, nz2
     found, pval, count, fit, cap = eng.sigma_loop(c, nz, nzc, download=False)
     ppair, nfit = eng.pair_pvalues(c, nz, found, cap, count)
-    recs, fits = eng._download(found, pval, count, fit, eng.levels.n_tested, sort=True, extra={"pair": ppair})
+    recs, fits = eng._download(found, pval, count, fit, eng.levels.n_tested, sort=True,
+                               extra={"pair": ppair, "q": eng.fdr(pval, count, cap)})
     return BlockBatch(eng, c, nz, CH, c.shape[0], nzc.cpu().numpy().view(np.uint32).astype(np.int64), recs, fits)
 
 

@@ -113,7 +113,7 @@ class ScaleSpaceEngine:
         return nz, nz_count
 
     def sigma_loop(self, c, nz, nz_count, skip_empty=True, found_cap=None, download=True, timing=None, sort=True,
-                   with_value=True):
+                   with_value=True, with_q=True):
         """The fused kernel + p-values.  Returns host records (download=True) or the device buffers.
         `timing`: optional list; receives a (start, end) torch.cuda.Event pair bracketing the mst_scale_space launch
         on the launch stream."""
@@ -150,7 +150,20 @@ class ScaleSpaceEngine:
                 timing.append((e0, e1))     # mst_found_pvalues synchronised the stream: the events are complete
         if not download:
             return found, pval, count, fit, found_cap
-        return self._download(found, pval, count, fit, nt, sort=sort, with_value=with_value)
+        extra = {"q": self.fdr(pval, count, found_cap)} if with_q else None
+        return self._download(found, pval, count, fit, nt, sort=sort, with_value=with_value, extra=extra)
+
+    def fdr(self, pval, count, found_cap):
+        """Benjamini-Hochberg q-values per block on the device (reference mustache.py:778); same record order as pval."""
+        B = pval.shape[0]
+        q = torch.empty_like(pval)
+        ws_bytes = int(self.lib.mst_bh_workspace_bytes(B, found_cap))
+        if ws_bytes == 0:
+            raise ValueError("too many found records for one BH launch (B * capacity must fit in int32)")
+        with torch.cuda.device(self.device):
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.mst_bh_fdr(_ptr(pval), _ptr(count), B, found_cap, _ptr(q), _ptr(ws), ws_bytes, _stream()))
+        return q
 
     def _pinned(self, key, shape, dtype):
         """Page-locked host staging buffers (D2H at PCIe rate).  Two sets alternate, so the arrays handed out by one
@@ -258,7 +271,8 @@ class ScaleSpaceEngine:
         nz, nz_count = self.prologue(c, dpx, intra)
         found, pval, count, fit, cap = self.sigma_loop(c, nz, nz_count, skip_empty=skip_empty, download=False)
         ppair, nfit = self.pair_pvalues(c, nz, found, cap, count)
-        recs, fits = self._download(found, pval, count, fit, self.levels.n_tested, sort=True, extra={"pair": ppair})
+        recs, fits = self._download(found, pval, count, fit, self.levels.n_tested, sort=True,
+                                    extra={"pair": ppair, "q": self.fdr(pval, count, cap)})
         B, CH, _ = c.shape
         batch = BlockBatch(self, c, nz, CH, B, nz_count.cpu().numpy().view(np.uint32).astype(np.int64), recs, fits)
         batch.norm_fit = nfit.cpu().numpy()

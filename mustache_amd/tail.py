@@ -64,7 +64,7 @@ def fdr_candidates(batch, b, pt, st):
         raise ValueError("pThreshold must be <= 1")
     rec = batch.found[b]
     sigma_t = np.asarray(batch.engine.levels.tested_sigma)
-    q = benjamini_hochberg(rec["pval"])             # (:778-779)
+    q = rec["q"] if "q" in rec else benjamini_hochberg(rec["pval"])   # (:778-779) BH ran on the device when "q" is present
     sel = np.nonzero(q < pt)[0]                     # (:789-797)  o < pt can only hold at found pixels (pt <= 1)
     if sel.size == 0:
         return q, sel

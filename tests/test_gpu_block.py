@@ -134,3 +134,15 @@ def test_full_size_block_vs_oracle(eng, n, dpx, seed):
     assert [(int(a), int(b)) for a, b, _, _ in got] == [(int(a), int(b)) for a, b, _, _ in exp]
     assert [s for _, _, _, s in got] == [s for _, _, _, s in exp]
     np.testing.assert_allclose([q for _, _, q, _ in got], [q for _, _, q, _ in exp], rtol=1e-9)
+
+
+def test_device_bh_equals_numpy_bh(eng, golden_dir):
+    """mst_bh_fdr (hipCUB segmented sort + suffix minimum) == the NumPy restatement of statsmodels' fdr_bh, bit for bit,
+    and == the reference's multipletests output captured in the fixture."""
+    from mustache_amd.tail import benjamini_hochberg
+    g = _load(golden_dir, "block_512.npz")
+    c = _dense(g)
+    dev, nz_d, nzc, found, fit = _run_block(eng, c, int(g["dpx"]))
+    assert "q" in found
+    assert np.array_equal(found["q"], benjamini_hochberg(found["pval"]))
+    np.testing.assert_allclose(found["q"], g["bh_out"], rtol=1e-9)

@@ -245,59 +245,66 @@ constexpr int kTR = 16, kTC = 128;
 constexpr int kND = kTR + kTC - 1;      // diagonals crossing a strip
 constexpr int kTP = kTR + 1;            // LDS pitch
 
+constexpr int kStrips = 8;             // 16-row strips per workgroup: 128 x 128 pixels, so the grid is not dispatch-bound
+
 __global__ void __launch_bounds__(kThreads)
 blocks_from_band_kernel(const double *__restrict__ band, int64_t n, int dpx, const int64_t *__restrict__ starts,
                         int CH, double *__restrict__ c, uint8_t *__restrict__ nz, uint32_t *__restrict__ nz_count) {
     __shared__ double tile[kND * kTP];
     const int b = blockIdx.z;
-    const int r0 = blockIdx.y * kTR, c0 = blockIdx.x * kTC;
+    const int c0 = blockIdx.x * kTC;
     const int64_t start = starts[b];
     double *cb = c + (size_t)b * CH * CH;
     uint8_t *nb = nz + (size_t)b * CH * CH;
-    const int off_lo = c0 - r0 - (kTR - 1), off_hi = c0 - r0 + (kTC - 1);   // range of col - row inside the strip
     const int tid = threadIdx.x;
-    const bool has_data = off_hi >= 0 && off_lo <= dpx + 1;
-    if (has_data) {
-        // tile[(d - off_lo) * kTP + ii] = band[d][start + r0 + ii]
-        for (int idx = tid; idx < kND * kTR; idx += kThreads) {
-            const int dd = idx / kTR, ii = idx - dd * kTR;
-            const int d = off_lo + dd;
-            const int64_t i = start + r0 + ii;
-            double v = 0.0;
-            if (d >= 0 && d <= dpx + 1 && i >= 0 && i + d < n && r0 + ii < CH) v = band[(int64_t)d * n + i];
-            tile[dd * kTP + ii] = v;
-        }
-        __syncthreads();
-    }
-    uint32_t local = 0;
     const bool pairs_ok = (CH & 1) == 0;        // 16-byte stores need even row length (rows start 16-byte aligned)
-    for (int idx = tid; idx < kTR * (kTC / 2); idx += kThreads) {
-        const int rr = idx / (kTC / 2), cp = idx - rr * (kTC / 2);
-        const int row = r0 + rr, col = c0 + 2 * cp;
-        if (row >= CH || col >= CH) continue;
-        double val[2];
-        uint32_t t[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int off = col + e - row;
-            double raw = 0.0;
-            if (has_data && off >= 0 && off <= dpx + 1) raw = tile[(off - off_lo) * kTP + rr];
-            t[e] = (raw != 0.0 && off >= 4) ? 1u : 0u;                                   // (:699)
-            val[e] = (off <= 4 || off >= dpx + 1) ? 2.0 : raw;                           // (:703-706)
+    uint32_t local = 0;
+    for (int sidx = 0; sidx < kStrips; ++sidx) {
+        const int r0 = (blockIdx.y * kStrips + sidx) * kTR;
+        if (r0 >= CH) break;
+        const int off_lo = c0 - r0 - (kTR - 1), off_hi = c0 - r0 + (kTC - 1);   // range of col - row inside the strip
+        const bool has_data = off_hi >= 0 && off_lo <= dpx + 1;                  // workgroup-uniform
+        if (has_data) {
+            __syncthreads();                     // previous strip's readers are done with the tile
+            // tile[(d - off_lo) * kTP + ii] = band[d][start + r0 + ii]
+            for (int idx = tid; idx < kND * kTR; idx += kThreads) {
+                const int dd = idx / kTR, ii = idx - dd * kTR;
+                const int d = off_lo + dd;
+                const int64_t i = start + r0 + ii;
+                double v = 0.0;
+                if (d >= 0 && d <= dpx + 1 && i >= 0 && i + d < n && r0 + ii < CH) v = band[(int64_t)d * n + i];
+                tile[dd * kTP + ii] = v;
+            }
+            __syncthreads();
         }
-        const size_t at = (size_t)row * CH + col;
-        if (pairs_ok && col + 1 < CH) {
-            *reinterpret_cast<double2 *>(cb + at) = make_double2(val[0], val[1]);
-            *reinterpret_cast<uint16_t *>(nb + at) = (uint16_t)(t[0] | (t[1] << 8));
-            local += t[0] + t[1];
-        } else {
-            cb[at] = val[0];
-            nb[at] = (uint8_t)t[0];
-            local += t[0];
-            if (col + 1 < CH) {
-                cb[at + 1] = val[1];
-                nb[at + 1] = (uint8_t)t[1];
-                local += t[1];
+        for (int idx = tid; idx < kTR * (kTC / 2); idx += kThreads) {
+            const int rr = idx / (kTC / 2), cp = idx - rr * (kTC / 2);
+            const int row = r0 + rr, col = c0 + 2 * cp;
+            if (row >= CH || col >= CH) continue;
+            double val[2];
+            uint32_t t[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int off = col + e - row;
+                double raw = 0.0;
+                if (has_data && off >= 0 && off <= dpx + 1) raw = tile[(off - off_lo) * kTP + rr];
+                t[e] = (raw != 0.0 && off >= 4) ? 1u : 0u;                                   // (:699)
+                val[e] = (off <= 4 || off >= dpx + 1) ? 2.0 : raw;                           // (:703-706)
+            }
+            const size_t at = (size_t)row * CH + col;
+            if (pairs_ok && col + 1 < CH) {
+                *reinterpret_cast<double2 *>(cb + at) = make_double2(val[0], val[1]);
+                *reinterpret_cast<uint16_t *>(nb + at) = (uint16_t)(t[0] | (t[1] << 8));
+                local += t[0] + t[1];
+            } else {
+                cb[at] = val[0];
+                nb[at] = (uint8_t)t[0];
+                local += t[0];
+                if (col + 1 < CH) {
+                    cb[at + 1] = val[1];
+                    nb[at + 1] = (uint8_t)t[1];
+                    local += t[1];
+                }
             }
         }
     }
@@ -378,7 +385,7 @@ extern "C" int mst_blocks_from_band(const double *band, int64_t n, int32_t dpx, 
     MST_HIP(hipMallocAsync((void **)&d_starts, sizeof(int64_t) * B, s));
     MST_HIP(hipMemcpyAsync(d_starts, starts, sizeof(int64_t) * B, hipMemcpyHostToDevice, s));
     MST_HIP(hipMemsetAsync(nz_count, 0, sizeof(uint32_t) * B, s));
-    blocks_from_band_kernel<<<dim3((CH + kTC - 1) / kTC, (CH + kTR - 1) / kTR, B), kThreads, 0, s>>>(
+    blocks_from_band_kernel<<<dim3((CH + kTC - 1) / kTC, (CH + kTR * kStrips - 1) / (kTR * kStrips), B), kThreads, 0, s>>>(
         band, n, dpx, d_starts, CH, c, nz, nz_count);
     MST_LAUNCH_CHECK();
     MST_HIP(hipFreeAsync(d_starts, s));

@@ -50,10 +50,13 @@ class ChromosomePipeline:
         bs = max(1, int(self.max_batch_bytes // per_block))
         return [idx[i:i + bs] for i in range(0, len(idx), bs)]
 
-    def run_band(self, band, n, dpx, st, pt, skip_empty=True, distributed=True, timings=None):
-        """band: normalised band on the device.  Returns this chromosome's loops (all ranks, after the gather)."""
+    def run_band(self, band, n, dpx, st, pt, skip_empty=True, distributed=True, timings=None, shard=None):
+        """band: normalised band on the device.  Returns this chromosome's loops (all ranks, after the gather).
+        `shard=(rank, world_size)` runs one rank's share without a process group (no gather) -- used by tests."""
         CH, start, end = block_tiling(n, dpx)
         rank, ws = world() if distributed else (0, 1)
+        if shard is not None:
+            rank, ws, distributed = shard[0], shard[1], False
         mine = shard_blocks(len(start), rank, ws)
         loops = []
         t_dev = t_tail = 0.0

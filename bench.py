@@ -88,10 +88,8 @@ class Workload:
         return out
 
 
-def cpu_baseline(w, block_index):
-    """The oracle (reference arithmetic: SciPy gaussian_filter / maximum_filter / expm1) on one block, 1 core."""
+def _dense_raw_block(w, block_index):
     import numpy as np
-    import oracle
     s = w.start[block_index]
     CH, dpx = w.CH, w.dpx
     slab = w.band[:, s:s + CH].cpu().numpy()
@@ -100,11 +98,33 @@ def cpu_baseline(w, block_index):
     for d in range(dpx + 2):
         L = CH - d
         c[r[:L], r[:L] + d] = slab[d, :L]
+    return c
+
+
+def _oracle_block(args):
+    """one block through the oracle's rows 3-7 (runs in a worker process for the -p 4 leg)"""
+    c, dpx = args
+    import oracle
     t0 = time.time()
     nz = oracle.block_prologue(c, dpx)
     ss = oracle.scale_space_levels(c, nz, [1.6, 3.2], blur="scipy")
-    dt = time.time() - t0
-    return dt, int((ss.pval != 2).sum()), int(nz.sum())
+    return time.time() - t0, int((ss.pval != 2).sum()), int(nz.sum())
+
+
+def cpu_baseline(w, block_index):
+    """The oracle (reference arithmetic: SciPy gaussian_filter / maximum_filter / expm1) on one block, 1 core."""
+    return _oracle_block((_dense_raw_block(w, block_index), w.dpx))
+
+
+def cpu_baseline_p4(w, block_indices):
+    """The reference's default parallelism (-p 4, mustache.py:146): 4 blocks in 4 processes at once."""
+    import multiprocessing as mp
+    blocks = [(_dense_raw_block(w, i), w.dpx) for i in block_indices]
+    ctx = mp.get_context("spawn")
+    t0 = time.time()
+    with ctx.Pool(len(blocks)) as pool:
+        res = pool.map(_oracle_block, blocks)
+    return time.time() - t0, res
 
 
 def main():
@@ -225,6 +245,11 @@ def main():
                                "found_pixels_cpu": cpu_found, "found_pixels_gpu": found_gpu,
                                "cpu_model": _cpu_model(), "host_cores": os.cpu_count()}
         out["speedup_vs_cpu_1core"] = round(value / out["cpu_baseline"]["value"], 1)
+        wall4, _ = cpu_baseline_p4(w, [bi - 2, bi - 1, bi + 1, bi + 2])
+        out["cpu_baseline_p4"] = {"value": round(4 * w.CH * w.CH / 1e6 / wall4, 4), "unit": "Mpix/s", "cores": 4,
+                                  "kind": "port", "sample": "4 blocks of the same workload in 4 worker processes (the "
+                                  "reference's default -p 4), wall %.1f s incl. process start-up" % wall4}
+        out["speedup_vs_cpu_p4"] = round(value / out["cpu_baseline_p4"]["value"], 1)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

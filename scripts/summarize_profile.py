@@ -33,6 +33,10 @@ lines += ["", "## Fused kernel `scale_space_kernel<Tile<32,64,14>>` per launch s
           "| tiles/block (padded) | blocks | launches | durations ms |", "|---|---|---|---|"]
 for (gx, gy), d in sorted(groups.items(), reverse=True):
     lines.append("| %d | %d | %d | %s |" % (gx, gy, len(d), ", ".join("%.3f" % x for x in d[:8])))
+big = max(groups, key=lambda k: k[0] * k[1])
+dense = [x for x in groups[big] if x > 0.8 * max(groups[big])]
+lines += ["", "Dense %d-block launches (the ones `bench.py` times for `roofline.kernel_ms`): mean **%.3f ms** over %d launches; "
+          "the shorter launches of the same shape are the `band_skip` runs." % (big[1], sum(dense) / len(dense), len(dense))]
 r0 = ss[0]
 lines += ["", "VGPR_Count %s, Accum_VGPR_Count %s, SGPR_Count %s, Scratch_Size %s B/lane, workgroup %s threads."
           % (r0["VGPR_Count"], r0["Accum_VGPR_Count"], r0["SGPR_Count"], r0["Scratch_Size"], r0["Workgroup_Size_X"]), ""]

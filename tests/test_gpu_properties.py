@@ -120,3 +120,62 @@ def test_sparse_block_vs_oracle(depth, seed):
     exp = oracle.mustache_block(c.copy(), 0, dpx, [1.6, 3.2], 0.5, 0.3)
     got = mustache(c, "1", "1", 5000, [], 0, n, 0, dpx, [1.6, 3.2], 0.5, 0.3)
     assert [(int(a), int(b), s) for a, b, _, s in got] == [(int(a), int(b), s) for a, b, _, s in exp]
+
+
+def test_found_capacity_overflow_is_reported_and_recovered():
+    """A too-small record capacity must surface as MST_E_OVERFLOW (never silently dropped records); the engine then
+    re-runs with a larger buffer and gets the same records."""
+    import torch
+    from mustache_amd import _lib
+    from mustache_amd.engine import ScaleSpaceEngine, _ptr, _stream
+    import ctypes
+    pipe, c, nz, cnt = _normalised_block(2000, 400, 7, 5000)
+    eng = pipe.engine
+    ref, _ = eng.sigma_loop(c, nz, cnt)
+    m = len(ref[0]["pixel"])
+    assert m > 5000
+    got, _ = eng.sigma_loop(c, nz, cnt, found_cap=1024)          # overflows, engine grows x4 until it fits
+    assert np.array_equal(got[0]["pixel"], ref[0]["pixel"]) and np.array_equal(got[0]["pval"], ref[0]["pval"])
+    eng._found_cap.clear()
+    # and the raw ABI reports it
+    lv = ctypes.byref(eng._lv_struct)
+    B, CH = 1, 2000
+    cap = 512
+    found = torch.empty((B, cap, 2), dtype=torch.int64, device="cuda")
+    count = torch.empty(B, dtype=torch.int32, device="cuda")
+    stats = torch.empty((B, 48, 2), dtype=torch.float64, device="cuda")
+    fit = torch.empty((B, 48, 2), dtype=torch.float64, device="cuda")
+    pval = torch.empty((B, cap), dtype=torch.float64, device="cuda")
+    wsb = int(eng.lib.mst_scale_space_workspace_bytes(B, CH, lv))
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    assert eng.lib.mst_scale_space(_ptr(c), _ptr(nz), B, CH, lv, _ptr(found), cap, _ptr(count), _ptr(stats), 1, _ptr(ws),
+                                   wsb, _stream()) == 0
+    rc = eng.lib.mst_found_pvalues(_ptr(found), cap, _ptr(count), _ptr(cnt), _ptr(stats), B, 18, _ptr(pval), _ptr(fit),
+                                   _stream())
+    assert rc == _lib.MST_E_OVERFLOW and b"capacity" in eng.lib.mst_last_error()
+    assert int(count.cpu()[0]) == m, "the counter keeps counting past the capacity, so the caller knows the need"
+
+
+def test_non_finite_input_is_an_error_not_garbage():
+    """The reference raises ValueError inside expon.fit for NaN/inf DoG values; the library returns MST_E_NONFINITE."""
+    from mustache_amd import _lib
+    from mustache_amd.mustache import mustache
+    from mustache_amd.synth import synth_coo
+    import oracle
+    n, dpx = 320, 80
+    x, y, v = synth_coo(n, dpx, depth=300.0, seed=1)
+    oracle.normalize_sparse(x, y, v, 50000, dpx)
+    c = np.zeros((n, n))
+    c[x, y] = v
+    c[100, 130] = np.nan
+    with pytest.raises(_lib.MstError) as e:
+        mustache(c, "1", "1", 5000, [], 0, n, 0, dpx, [1.6, 3.2], 0.8, 0.1)
+    assert e.value.code == _lib.MST_E_NONFINITE
+
+
+def test_bad_arguments_are_rejected():
+    from mustache_amd import _lib
+    lib = _lib.load()
+    assert lib.mst_block_prologue(None, None, None, 1, 16, 4, 1, None) == _lib.MST_E_ARG
+    assert b"mst_block_prologue" in lib.mst_last_error()
+    assert lib.mst_scale_space_workspace_bytes(0, 100, None) == 0

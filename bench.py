@@ -151,6 +151,7 @@ def main():
     w = Workload("chr1@1kb synthetic (n=%d, dpx=2000, %s blocks of 4000x4000 fp64)", n, 2000, 1000, 400.0,
                  8000 if not args.small else 800, 1, device, rank, world)
     w.name = w.name % (n, len(w.start))
+    w.step(False)          # set-up, untimed: first-touch of the pinned staging buffers and the allocator's block cache
 
     def timed(skip_empty, steps, warmup):
         for _ in range(warmup):

@@ -74,7 +74,7 @@ class Workload:
         self.total_mpix = len(self.start) * self.CH * self.CH / 1e6
         self.kernel_ms = []
 
-    def step(self, skip_empty=False, download=True):
+    def step(self, skip_empty=False, download=True, fma=False):
         """rows 2-7 for this rank's blocks; returns (found records per block, kernel event pair)."""
         import torch
         pipe = self.pipe
@@ -82,7 +82,7 @@ class Workload:
         for group in pipe.batches(self.mine, self.CH):
             c, nz, nzc = pipe.blocks_from_band(self.band, self.n, self.dpx, [self.start[i] for i in group], self.CH)
             res = pipe.engine.sigma_loop(c, nz, nzc, skip_empty=skip_empty, download=download, timing=self.kernel_ms,
-                                         sort=False, with_value=False, with_q=False)   # records = (pixel, level, p-value); the tail
+                                         sort=False, with_value=False, with_q=False, fma=fma)   # records = (pixel, level, p-value); the tail
             # orders them by pixel when it needs look-ups, and only the two-sample path reads the DoG values
             out.append(res)
         return out
@@ -153,14 +153,14 @@ def main():
     w.name = w.name % (n, len(w.start))
     w.step(False)          # set-up, untimed: first-touch of the pinned staging buffers and the allocator's block cache
 
-    def timed(skip_empty, steps, warmup):
+    def timed(skip_empty, steps, warmup, fma=False):
         for _ in range(warmup):
-            w.step(skip_empty)
+            w.step(skip_empty, fma=fma)
         w.kernel_ms.clear()
         barrier()
         t0 = time.time()
         for _ in range(steps):
-            last = w.step(skip_empty)
+            last = w.step(skip_empty, fma=fma)
         barrier()
         dt = time.time() - t0
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -201,13 +201,20 @@ def main():
                  "speedup": round((dt / args.steps) / (dt_s / max(1, args.steps // 2)), 3),
                  "kernel_ms": round(sum(kms_s) / len(kms_s), 3)}
 
+    # opt-in relaxed arithmetic (fused multiply-add per tap pair): DoG no longer bit-identical (~1e-16 relative, north_star
+    # allows 1e-5), found set unchanged on every case tested.  Reported separately; `value` is always the exact mode.
+    dt_f, kms_f, _ = timed(False, max(1, args.steps // 2), 1, fma=True)
+    fma_mode = {"value": round(w.total_mpix / (dt_f / max(1, args.steps // 2)), 1), "unit": "Mpix/s",
+                "kernel_ms": round(sum(kms_f) / len(kms_f), 3),
+                "note": "MST_FLAG_FMA, dense; not bit-exact DoG, therefore never the headline value"}
+
     out = {"metric": "scale-space Mpix/s (sigma-stack+local-max)", "value": round(value, 1), "unit": "Mpix/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": w.name, "blocks": len(w.start), "chunk": w.CH, "distance_px": w.dpx,
                       "megapixels_per_step": round(w.total_mpix, 1), "sharding": "blocks round-robin over %d rank(s)" % world,
                       "timed_region": "normalised band in HBM -> blocks -> fused sigma loop -> found records on host"},
-           "roofline": roof, "band_skip": band_skip,
+           "roofline": roof, "band_skip": band_skip, "fma_mode": fma_mode,
            "normalize_ms_untimed": round(w.normalize_s * 1e3, 1)}
 
     if rank == 0 and world == 1:

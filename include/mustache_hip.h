@@ -36,6 +36,11 @@ extern "C" {
 #define MST_E_OVERFLOW (-3) /* an output buffer capacity was exceeded (caller re-runs with a larger one) */
 #define MST_E_NONFINITE (-4)/* non-finite DoG statistics (the reference raises ValueError in expon.fit) */
 
+/* mst_scale_space flags */
+#define MST_FLAG_SKIP_EMPTY 1 /* tiles that contain no nz pixel are not computed (identical outputs, less work) */
+#define MST_FLAG_FMA 2        /* OPT-IN relaxed arithmetic: fuse the multiply-add of each tap pair.  DoG values then differ
+                                 from the reference's by ~1e-16 relative (instead of being bit-identical); default off */
+
 #define MST_MAX_LEVELS 64   /* octaves * (s + 2) */
 #define MST_MAX_RADIUS 32
 #define MST_MAX_TESTED 48   /* octaves * (s - 1) */
@@ -94,12 +99,12 @@ int mst_gauss_blur(const double *in, double *out, double *tmp, int32_t B, int32_
  *                 must re-run with a larger capacity (mst_found_pvalues reports MST_E_OVERFLOW)
  *   level_stats : dev [B][MST_MAX_TESTED][2] float64, overwritten: {min |D_c| over nz, sum |D_c| over nz} per
  *                 tested level (deterministic reduction order)
- *   skip_empty  : !=0 -> tiles that contain no nz pixel are not computed (identical outputs, less work)
+ *   flags       : MST_FLAG_SKIP_EMPTY | MST_FLAG_FMA (see above); 0 = dense, exact
  *   workspace   : dev scratch of at least mst_scale_space_workspace_bytes(B, CH, lv) bytes
  */
 int mst_scale_space(const double *c, const uint8_t *nz, int32_t B, int32_t CH, const mst_levels *lv,
                     mst_found *found, uint32_t found_cap, uint32_t *found_count, double *level_stats,
-                    int32_t skip_empty, void *workspace, uint64_t workspace_bytes, void *stream);
+                    int32_t flags, void *workspace, uint64_t workspace_bytes, void *stream);
 
 /* Bytes of device scratch mst_scale_space needs for (B, CH, lv): the level table plus per-tile partial
  * statistics.  Returns 0 on bad arguments. */

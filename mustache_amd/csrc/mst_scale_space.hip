@@ -62,8 +62,14 @@ constexpr int pitch_for(int need) {
     return p;
 }
 
-template <int RGR_, int RGC_, int RMAX_, int K_ = 8, int MINW_ = 1>
+template <int RGR_, int RGC_, int RMAX_, int K_ = 8, int MINW_ = 1, bool FMA_ = false>
 struct Tile {
+    // FMA = false: SciPy's exact operation sequence (add, multiply, add -- three roundings per tap pair), DoG values
+    //              bit-identical to the reference.  This is the default and what every parity claim refers to.
+    // FMA = true : opt-in relaxed arithmetic, the multiply-add of each tap pair fused (two roundings).  DoG values then
+    //              differ from the reference by ~1e-16 relative (north_star allows 1e-5); one third fewer FP64
+    //              instructions in the blurs.  Never used unless the caller sets MST_FLAG_FMA.
+    static constexpr bool FMA = FMA_;
     static constexpr int RGR = RGR_, RGC = RGC_;  // region rows / cols: interior + 1-pixel ring for the 3x3 max
     static constexpr int ITR = RGR_ - 2, ITC = RGC_ - 2;   // interior (owned) pixels
     static constexpr int RMAX = RMAX_;            // largest blur radius this instantiation supports
@@ -172,7 +178,7 @@ struct Chunk {
 // loads in flight are live at a time instead of all KC + 2R, and the LDS latency hides under the FP64 work.
 // For each tap the KC adds / muls / accumulates are adjacent in program order: KC independent chains keep the FP64
 // pipe issuing (a sample-major order is one serial add->mul->add chain).
-template <int KC, int R, int OFF>
+template <int KC, int R, int OFF, bool FMA>
 __device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const double (&w)[R + 1], double (&t)[KC]) {
     constexpr int NP = (KC + 2 * R + OFF + 1) / 2;                       // 16-byte pairs spanned by the window
     constexpr int QC0 = (R + OFF) >> 1, QC1 = (R + KC - 1 + OFF) >> 1;   // pairs holding the centre run
@@ -215,10 +221,15 @@ __device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const do
         double s[KC];
 #pragma unroll
         for (int k = 0; k < KC; ++k) s[k] = x[R + k - j + OFF] + x[R + k + j + OFF];
+        if constexpr (FMA) {
 #pragma unroll
-        for (int k = 0; k < KC; ++k) s[k] = s[k] * w[j];
+            for (int k = 0; k < KC; ++k) t[k] = __builtin_fma(s[k], w[j], t[k]);
+        } else {
 #pragma unroll
-        for (int k = 0; k < KC; ++k) t[k] = t[k] + s[k];
+            for (int k = 0; k < KC; ++k) s[k] = s[k] * w[j];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) t[k] = t[k] + s[k];
+        }
 #endif
     }
 #undef MST_LD
@@ -251,7 +262,7 @@ __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__r
 #pragma unroll
         for (int h = 0; h < K / KC; ++h) {
             double t[KC];
-            fir_chunk<KC, R, OFF>(p + h * KC, w, t);
+            fir_chunk<KC, R, OFF, T::FMA>(p + h * KC, w, t);
 #pragma unroll
             for (int k = 0; k < KC; ++k) q[(h * KC + k) * T::VP] = t[k];
         }
@@ -265,7 +276,7 @@ __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__r
             const int row0 = rgp * 4;
             const double *p = ct + ((T::RMAX - R) + col) * T::CTP + (row0 + T::RMAX - R - OFF);
             double t[4];
-            fir_chunk<4, R, OFF>(p, w, t);
+            fir_chunk<4, R, OFF, T::FMA>(p, w, t);
             double *q = vb + row0 * T::VP + col;
 #pragma unroll
             for (int k = 0; k < 4; ++k) q[k * T::VP] = t[k];
@@ -284,7 +295,7 @@ __device__ __forceinline__ void hpass(const double *__restrict__ p, const double
 #pragma unroll
     for (int h = 0; h < K / KC; ++h) {
         double t[KC];
-        fir_chunk<KC, R, 0>(p + h * KC, w, t);
+        fir_chunk<KC, R, 0, T::FMA>(p + h * KC, w, t);
 #pragma unroll
         for (int k = 0; k < KC; ++k) g[h * KC + k] = t[k];
     }
@@ -610,6 +621,7 @@ using TileDefault = Tile<32, 64, 14, 4, 4>;   // 512 threads x 4 pixels, 128 VGP
 using TileDefault = Tile<32, MST_TILE_W, 14>;   // the reference's default octaves (radius <= 14)
 #endif
 using TileWide = Tile<32, 32, 28>;      // -sz / -oc variants up to radius 28: smaller tile, same code
+using TileDefaultFma = Tile<32, MST_TILE_W, 14, 8, 1, true>;   // opt-in relaxed arithmetic (MST_FLAG_FMA), default radii only
 
 template <class T>
 int tiles_x(int CH) { return (CH + T::ITC - 1) / T::ITC; }
@@ -652,7 +664,9 @@ static int launch_scale_space(const double *c, const uint8_t *nz, int B, int CH,
 
 extern "C" int mst_scale_space(const double *c, const uint8_t *nz, int32_t B, int32_t CH, const mst_levels *lv,
                                mst_found *found, uint32_t found_cap, uint32_t *found_count, double *level_stats,
-                               int32_t skip_empty, void *workspace, uint64_t workspace_bytes, void *stream) {
+                               int32_t flags, void *workspace, uint64_t workspace_bytes, void *stream) {
+    const int skip_empty = (flags & MST_FLAG_SKIP_EMPTY) ? 1 : 0;
+    const bool fma = (flags & MST_FLAG_FMA) != 0;
     int mr = 0, nt = 0;
     int rc = check_levels(lv, &mr, &nt);
     if (rc != MST_OK) return rc;
@@ -693,7 +707,13 @@ extern "C" int mst_scale_space(const double *c, const uint8_t *nz, int32_t B, in
     MST_HIP(hipMemsetAsync(found_count, 0, sizeof(uint32_t) * B, s));
 
     int ntiles;
-    if (mr <= TileDefault::RMAX) {
+    if (fma && mr > TileDefault::RMAX)
+        return mst::fail(MST_E_ARG, "mst_scale_space: MST_FLAG_FMA is only built for blur radii <= %d", TileDefault::RMAX);
+    if (fma) {
+        rc = launch_scale_space<TileDefaultFma>(c, nz, B, CH, d_lv, found, found_cap, found_count, partial, nt,
+                                                skip_empty, s);
+        ntiles = tiles_total<TileDefault>(CH);
+    } else if (mr <= TileDefault::RMAX) {
         rc = launch_scale_space<TileDefault>(c, nz, B, CH, d_lv, found, found_cap, found_count, partial, nt,
                                              skip_empty, s);
         ntiles = tiles_total<TileDefault>(CH);

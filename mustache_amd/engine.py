@@ -113,7 +113,7 @@ class ScaleSpaceEngine:
         return nz, nz_count
 
     def sigma_loop(self, c, nz, nz_count, skip_empty=True, found_cap=None, download=True, timing=None, sort=True,
-                   with_value=True, with_q=True):
+                   with_value=True, with_q=True, fma=False):
         """The fused kernel + p-values.  Returns host records (download=True) or the device buffers.
         `timing`: optional list; receives a (start, end) torch.cuda.Event pair bracketing the mst_scale_space launch
         on the launch stream."""
@@ -135,7 +135,8 @@ class ScaleSpaceEngine:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                 _lib.check(self.lib.mst_scale_space(_ptr(c), _ptr(nz), B, CH, lv, _ptr(found), found_cap,
-                                                    _ptr(count), _ptr(stats), 1 if skip_empty else 0, _ptr(ws),
+                                                    _ptr(count), _ptr(stats),
+                                                    (1 if skip_empty else 0) | (2 if fma else 0), _ptr(ws),
                                                     ws_bytes, _stream()))
                 if timing is not None:
                     e1.record()

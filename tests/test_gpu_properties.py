@@ -179,3 +179,18 @@ def test_bad_arguments_are_rejected():
     assert lib.mst_block_prologue(None, None, None, 1, 16, 4, 1, None) == _lib.MST_E_ARG
     assert b"mst_block_prologue" in lib.mst_last_error()
     assert lib.mst_scale_space_workspace_bytes(0, 100, None) == 0
+
+
+def test_opt_in_fma_mode_within_north_star_tolerance():
+    """MST_FLAG_FMA (off by default) fuses each tap's multiply-add.  It must keep the found SET identical on the reference
+    fixture geometry, and DoG / p-values within the tolerance north_star states (1e-5 relative; observed ~1e-13)."""
+    pipe, c, nz, cnt = _normalised_block(2000, 400, 5, 5000)
+    eng = pipe.engine
+    a, fa = eng.sigma_loop(c, nz, cnt, fma=False)
+    b, fb = eng.sigma_loop(c, nz, cnt, fma=True)
+    ra, rb = a[0], b[0]
+    assert np.array_equal(ra["pixel"], rb["pixel"]) and np.array_equal(ra["level"], rb["level"])
+    assert not np.array_equal(ra["value"], rb["value"]), "the relaxed mode really is a different rounding sequence"
+    np.testing.assert_allclose(rb["value"], ra["value"], rtol=1e-9)
+    np.testing.assert_allclose(rb["pval"], ra["pval"], rtol=1e-5, atol=1e-300)
+    np.testing.assert_allclose(fb[0][1], fa[0][1], rtol=1e-9)

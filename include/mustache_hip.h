@@ -167,6 +167,24 @@ int mst_normalize_band(const double *band_in, double *band_out, int64_t n, int32
 int mst_blocks_from_band(const double *band, int64_t n, int32_t dpx, const int64_t *starts, int32_t B, int32_t CH,
                          double *c, uint8_t *nz, uint32_t *nz_count, void *stream);
 
+/* ---- band-direct variants: the block is a window of the band, never materialised ---------------------------------------
+ * Same results as mst_blocks_from_band + mst_scale_space / mst_candidate_features / mst_gather_diagonals, without the
+ * [B][CH][CH] dense blocks (9 B per pixel written and read back, 18 GB for a 1 kb chr1). */
+
+/* mustache.py:919-924 + :699-706 + :714-772 in one launch.  starts: host [B]; nz_count: dev [B] out = tested pixels per
+ * block (what mst_found_pvalues needs).  Other arguments as mst_scale_space; workspace from mst_scale_space_workspace_bytes. */
+int mst_scale_space_band(const double *band, int64_t n, int32_t dpx, const int64_t *starts, int32_t B, int32_t CH,
+                         const mst_levels *lv, mst_found *found, uint32_t found_cap, uint32_t *found_count,
+                         double *level_stats, uint32_t *nz_count, int32_t flags, void *workspace,
+                         uint64_t workspace_bytes, void *stream);
+
+/* mst_candidate_features / mst_gather_diagonals for the block that starts at bin `start` of the band. */
+int mst_candidate_features_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,
+                                const uint32_t *pixel, const int32_t *half, int32_t ncand, uint32_t *cnt1,
+                                uint32_t *cnt2, double *cval, void *stream);
+int mst_gather_diagonals_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,
+                              const int32_t *diag_k, int32_t nd, double *out, void *stream);
+
 /* ---- two-sample (differential) caller, reference mustache/diff_mustache.py:260-569 ------------------------------------
  * The per-sample sigma loops are mst_scale_space on both samples' blocks.  The entry points below add what
  * diff_mustache() computes on the difference image.  NB (reference behaviour, kept): the difference image's DoG is

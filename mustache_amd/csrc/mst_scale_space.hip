@@ -327,9 +327,20 @@ __device__ __forceinline__ void blur_dispatch(int r, const double *ct, double *v
 #undef MST_CASE
 }
 
-template <class T>
+// Where the block pixels come from.  Dense: caller-built filled blocks + nz masks (the reference's `c`).  Band: straight from
+// the chromosome's diagonal-major band -- the fills of mustache.py:703-706 and the nz rule of :699 are applied while the
+// tile is staged, so dense blocks are never materialised (no 9 B/pixel write + re-read, no 18 GB for chr1 @ 1 kb).
+struct BandSrc {
+    const double *band;        // band[d * n + i] = pixel (i, i + d)
+    int64_t n;
+    int dpx;
+    const int64_t *starts;     // dev [B]: block origins
+    uint32_t *nz_count;        // dev [B]: out, number of tested pixels per block
+};
+
+template <class T, bool BAND>
 __global__ void __launch_bounds__(T::NT, T::MINW)
-scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz, int CH,
+scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz, BandSrc src, int CH,
                    const DevLevels *__restrict__ lv, mst_found *__restrict__ found, uint32_t found_cap,
                    uint32_t *__restrict__ found_count, double *__restrict__ partial, int tiles_x, int tiles_y,
                    int n_tested, int skip_empty, int variant) {
@@ -356,45 +367,151 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
     const int gy = y0 + rr;
     const bool row_in = gy >= 0 && gy < CH;
     const bool row_own = row_in && rr >= 1 && rr <= T::ITR;
-    const double *cb = c + (size_t)b * CH * CH;
-    const uint8_t *nb = nz + (size_t)b * CH * CH;
     double *part = partial + ((size_t)b * ntiles + tile) * n_tested * 2;
 
     uint32_t in_mask = 0, nz_mask = 0;  // per-k bits: column inside the block / tested pixel owned by this thread
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int rc = cg * K + k;
-        const int gx = x0 + rc;
-        const bool col_in = gx >= 0 && gx < CH;
-        if (row_in && col_in) in_mask |= 1u << k;
-        if (row_own && col_in && rc >= 1 && rc <= T::ITC && nb[(size_t)gy * CH + gx]) nz_mask |= 1u << k;
-    }
-    const int any_nz = __syncthreads_or(nz_mask != 0);
-    if (!any_nz && skip_empty) {
-        for (int t = tid; t < n_tested; t += T::NT) {
-            part[2 * t] = INFINITY;
-            part[2 * t + 1] = 0.0;
-        }
-        return;
+        const int gx = x0 + cg * K + k;
+        if (row_in && gx >= 0 && gx < CH) in_mask |= 1u << k;
     }
 
-    // ---- stage the c tile (reflect halo) in LDS, transposed: the only bulk HBM/L2 read of the kernel.
-    // A wave takes whole rows (row reflection is wave-uniform); each lane's column reflections are computed once.
-    {
+    if constexpr (!BAND) {
+        const double *cb = c + (size_t)b * CH * CH;
+        const uint8_t *nb = nz + (size_t)b * CH * CH;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int rc = cg * K + k;
+            const int gx = x0 + rc;
+            if (row_own && gx >= 0 && gx < CH && rc >= 1 && rc <= T::ITC && nb[(size_t)gy * CH + gx]) nz_mask |= 1u << k;
+        }
+        const int any_nz = __syncthreads_or(nz_mask != 0);
+        if (!any_nz && skip_empty) {
+            for (int t = tid; t < n_tested; t += T::NT) {
+                part[2 * t] = INFINITY;
+                part[2 * t + 1] = 0.0;
+            }
+            return;
+        }
+        // ---- stage the c tile (reflect halo) in LDS, transposed: the only bulk HBM/L2 read of the kernel.
+        // A wave takes whole rows (row reflection is wave-uniform); each lane's column reflections are computed once.
         constexpr int CPL = (T::CTC + 63) / 64;          // columns per lane
         int sx[CPL];
 #pragma unroll
         for (int q = 0; q < CPL; ++q) sx[q] = reflect_idx(x0 - RMAX + (tid & 63) + 64 * q, CH);
         for (int i = tid >> 6; i < T::CTR; i += T::NW) {
-            const double *src = cb + (size_t)reflect_idx(y0 - RMAX + i, CH) * CH;
+            const double *srow = cb + (size_t)reflect_idx(y0 - RMAX + i, CH) * CH;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
                 const int j = (tid & 63) + 64 * q;
-                if (j < T::CTC) ct[j * T::CTP + i] = src[sx[q]];
+                if (j < T::CTC) ct[j * T::CTP + i] = srow[sx[q]];
             }
         }
+        __syncthreads();
+    } else {
+        // ---- band source.  Pixel (by, bx) of the block: off = bx - by;
+        //   raw    = band[off][start + by]            for 0 <= off <= dpx+1 and start + bx < n, else 0
+        //   tested = raw != 0 and off >= 4            (mustache.py:699, before the fills)
+        //   value  = 2 where off <= 4 or off >= dpx+1 (mustache.py:703-706), else raw
+        const int64_t start = src.starts[b];
+        const int64_t n = src.n;
+        const int dpx = src.dpx;
+        // cheap geometric rejection first: can the owned pixels of this tile reach the tested band 4 <= off <= dpx+1 ?
+        const int r_lo = y0 + 1 > 0 ? y0 + 1 : 0, r_hi = y0 + T::ITR < CH - 1 ? y0 + T::ITR : CH - 1;
+        const int c_lo = x0 + 1 > 0 ? x0 + 1 : 0, c_hi = x0 + T::ITC < CH - 1 ? x0 + T::ITC : CH - 1;
+        const bool reaches_band = (c_hi - r_lo >= 4) && (c_lo - r_hi <= dpx + 1);
+        if (!reaches_band && skip_empty) {
+            for (int t = tid; t < n_tested; t += T::NT) {
+                part[2 * t] = INFINITY;
+                part[2 * t + 1] = 0.0;
+            }
+            return;
+        }
+        uint8_t *nzb = reinterpret_cast<uint8_t *>(vb);      // [RGR][RGC] tested flags of the region; vb is free until the V pass
+        const int Y0 = y0 - RMAX, X0 = x0 - RMAX;
+        const bool inner = Y0 >= 0 && X0 >= 0 && Y0 + T::CTR <= CH && X0 + T::CTC <= CH;   // no reflection in this tile
+        if (inner) {
+            // walk the tile by diagonals: pixels (Y0+i, X0+i+dd) of one diagonal are CONTIGUOUS in band row off = X0-Y0+dd,
+            // so a wave reads one 480-byte run per diagonal; the fill decision is wave-uniform
+            constexpr int ND = T::CTR + T::CTC - 1;
+            constexpr int U = 8;                         // diagonals in flight per wave: loads first, then the LDS stores
+            constexpr int PER = (T::CTR + 63) / 64;      // elements of one diagonal per lane
+            for (int q0 = tid >> 6; q0 < ND; q0 += T::NW * U) {
+                double rawv[U][PER];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int q = q0 + u * T::NW;
+                    const int dd = q - (T::CTR - 1);
+                    const int off = X0 - Y0 + dd;
+                    const int i_lo = dd < 0 ? -dd : 0;
+                    const int i_hi = T::CTC - dd < T::CTR ? T::CTC - dd : T::CTR;
+                    const bool in_band = q < ND && off >= 0 && off <= dpx + 1;
+                    const double *brow = src.band + (int64_t)(in_band ? off : 0) * n + start + Y0;
+#pragma unroll
+                    for (int e = 0; e < PER; ++e) {
+                        const int i = i_lo + (tid & 63) + 64 * e;
+                        rawv[u][e] = (in_band && i < i_hi && start + X0 + i + dd < n) ? brow[i] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int q = q0 + u * T::NW;
+                    if (q >= ND) break;
+                    const int dd = q - (T::CTR - 1);
+                    const int off = X0 - Y0 + dd;
+                    const int i_lo = dd < 0 ? -dd : 0;
+                    const int i_hi = T::CTC - dd < T::CTR ? T::CTC - dd : T::CTR;
+                    const bool filled = off <= 4 || off >= dpx + 1;
+#pragma unroll
+                    for (int e = 0; e < PER; ++e) {
+                        const int i = i_lo + (tid & 63) + 64 * e;
+                        if (i >= i_hi) continue;
+                        const int j = i + dd;
+                        const double raw = rawv[u][e];
+                        ct[j * T::CTP + i] = filled ? 2.0 : raw;
+                        const int ri = i - RMAX, rj = j - RMAX;
+                        if (ri >= 0 && ri < RGR && rj >= 0 && rj < RGC)
+                            nzb[ri * RGC + rj] = (raw != 0.0 && off >= 4) ? 1 : 0;
+                    }
+                }
+            }
+        } else {
+            // border tiles: element-wise with reflection (few tiles; loads are served by L2)
+            for (int idx = tid; idx < T::CTR * T::CTC; idx += T::NT) {
+                const int i = idx / T::CTC, j = idx - i * T::CTC;
+                const int uy = Y0 + i, ux = X0 + j;                       // unreflected block coordinates
+                const int by = reflect_idx(uy, CH), bx = reflect_idx(ux, CH);
+                const int off = bx - by;
+                double raw = 0.0;
+                if (off >= 0 && off <= dpx + 1 && start + bx < n) raw = src.band[(int64_t)off * n + start + by];
+                ct[j * T::CTP + i] = (off <= 4 || off >= dpx + 1) ? 2.0 : raw;
+                const int ri = i - RMAX, rj = j - RMAX;
+                if (ri >= 0 && ri < RGR && rj >= 0 && rj < RGC) {
+                    const bool inside = uy >= 0 && uy < CH && ux >= 0 && ux < CH;
+                    nzb[ri * RGC + rj] = (inside && raw != 0.0 && off >= 4) ? 1 : 0;
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int rc = cg * K + k;
+            if (row_own && ((in_mask >> k) & 1u) && rc >= 1 && rc <= T::ITC && nzb[rr * RGC + rc]) nz_mask |= 1u << k;
+        }
+        mine = __builtin_popcount(nz_mask);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+        if ((tid & 63) == 0 && mine) atomicAdd(src.nz_count + b, mine);       // integer: exact in any order
+        const int any_nz = __syncthreads_or(nz_mask != 0);                  // also fences nzb reads before vb is reused
+        if (!any_nz && skip_empty) {
+            for (int t = tid; t < n_tested; t += T::NT) {
+                part[2 * t] = INFINITY;
+                part[2 * t + 1] = 0.0;
+            }
+            return;
+        }
     }
-    __syncthreads();
 
     // per-pixel rolling state across levels.  For the tested level c the sieve needs
     //   D_c == M_c (ec),  D_{c-1} == M_{c-1} (ep),  D_c > M_{c-1} (gp),  and against the incoming level D_c > M_{c+1};
@@ -638,16 +755,17 @@ extern "C" uint64_t mst_scale_space_workspace_bytes(int32_t B, int32_t CH, const
     int mr = 0, nt = 0;
     if (B <= 0 || CH <= 0 || check_levels(lv, &mr, &nt) != MST_OK) return 0;
     const int nt_tiles = mr <= TileDefault::RMAX ? tiles_total<TileDefault>(CH) : tiles_total<TileWide>(CH);
-    return align_up(sizeof(DevLevels), 256) + sizeof(double) * 2 * (size_t)B * nt_tiles * nt;
+    return align_up(sizeof(DevLevels), 256) + align_up(sizeof(int64_t) * (size_t)B, 256) +
+           sizeof(double) * 2 * (size_t)B * nt_tiles * nt;
 }
 
-template <class T>
-static int launch_scale_space(const double *c, const uint8_t *nz, int B, int CH, const DevLevels *d_lv,
+template <class T, bool BAND>
+static int launch_scale_space(const double *c, const uint8_t *nz, BandSrc src, int B, int CH, const DevLevels *d_lv,
                               mst_found *found, uint32_t found_cap, uint32_t *found_count, double *partial,
                               int n_tested, int skip_empty, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        MST_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scale_space_kernel<T>),
+        MST_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scale_space_kernel<T, BAND>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES));
         attr_set = true;
     }
@@ -656,26 +774,30 @@ static int launch_scale_space(const double *c, const uint8_t *nz, int B, int CH,
     const int gx = (ntiles + 7) / 8 * 8;
     const char *venv = getenv("MST_ABLATE");          // timing ablations for profiling only (results invalid)
     const int variant = venv ? atoi(venv) : 0;
-    scale_space_kernel<T><<<dim3(gx, B), T::NT, T::LDS_BYTES, s>>>(c, nz, CH, d_lv, found, found_cap, found_count,
-                                                                 partial, tx, ty, n_tested, skip_empty, variant);
+    scale_space_kernel<T, BAND><<<dim3(gx, B), T::NT, T::LDS_BYTES, s>>>(c, nz, src, CH, d_lv, found, found_cap,
+                                                                       found_count, partial, tx, ty, n_tested,
+                                                                       skip_empty, variant);
     MST_LAUNCH_CHECK();
     return MST_OK;
 }
 
-extern "C" int mst_scale_space(const double *c, const uint8_t *nz, int32_t B, int32_t CH, const mst_levels *lv,
-                               mst_found *found, uint32_t found_cap, uint32_t *found_count, double *level_stats,
-                               int32_t flags, void *workspace, uint64_t workspace_bytes, void *stream) {
+// shared body of mst_scale_space (dense blocks) and mst_scale_space_band (blocks cut out of the band on the fly)
+template <bool BAND>
+static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, const int64_t *starts_host, int32_t B,
+                            int32_t CH, const mst_levels *lv, mst_found *found, uint32_t found_cap,
+                            uint32_t *found_count, double *level_stats, int32_t flags, void *workspace,
+                            uint64_t workspace_bytes, void *stream, const char *who) {
     const int skip_empty = (flags & MST_FLAG_SKIP_EMPTY) ? 1 : 0;
     const bool fma = (flags & MST_FLAG_FMA) != 0;
     int mr = 0, nt = 0;
     int rc = check_levels(lv, &mr, &nt);
     if (rc != MST_OK) return rc;
-    if (!c || !nz || !found || !found_count || !level_stats || !workspace || B <= 0 || B > 65535 || CH <= 0 ||
+    if (!found || !found_count || !level_stats || !workspace || B <= 0 || B > 65535 || CH <= 0 ||
         (int64_t)CH * CH > 0xFFFFFFFFLL)
-        return mst::fail(MST_E_ARG, "mst_scale_space: bad argument");
+        return mst::fail(MST_E_ARG, "%s: bad argument", who);
     const uint64_t need = mst_scale_space_workspace_bytes(B, CH, lv);
     if (workspace_bytes < need)
-        return mst::fail(MST_E_ARG, "mst_scale_space: workspace too small (%llu < %llu bytes)",
+        return mst::fail(MST_E_ARG, "%s: workspace too small (%llu < %llu bytes)", who,
                          (unsigned long long)workspace_bytes, (unsigned long long)need);
     hipStream_t s = mst::as_stream(stream);
 
@@ -688,7 +810,7 @@ extern "C" int mst_scale_space(const double *c, const uint8_t *nz, int32_t B, in
         h.radius[l] = lv->radius[l];
         for (int j = 0; j <= lv->radius[l]; ++j) h.taps[l][j] = lv->taps[l][j];
     }
-    if (lv->n_octaves > 16) return mst::fail(MST_E_ARG, "mst_scale_space: more than 16 octaves");
+    if (lv->n_octaves > 16) return mst::fail(MST_E_ARG, "%s: more than 16 octaves", who);
     const int lpo = lv->levels_per_octave;
     for (int o = 0; o < lv->n_octaves; ++o) {
         h.first_level[o] = 1;
@@ -701,29 +823,58 @@ extern "C" int mst_scale_space(const double *c, const uint8_t *nz, int32_t B, in
         }
         if (same) h.first_level[o] = 3;
     }
-    DevLevels *d_lv = reinterpret_cast<DevLevels *>(workspace);
-    double *partial = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace) + align_up(sizeof(DevLevels), 256));
+    char *w = reinterpret_cast<char *>(workspace);
+    DevLevels *d_lv = reinterpret_cast<DevLevels *>(w);
+    w += align_up(sizeof(DevLevels), 256);
+    int64_t *d_starts = reinterpret_cast<int64_t *>(w);
+    w += align_up(sizeof(int64_t) * (size_t)B, 256);
+    double *partial = reinterpret_cast<double *>(w);
     MST_HIP(hipMemcpyAsync(d_lv, &h, sizeof(h), hipMemcpyHostToDevice, s));
     MST_HIP(hipMemsetAsync(found_count, 0, sizeof(uint32_t) * B, s));
+    if (BAND) {
+        MST_HIP(hipMemcpyAsync(d_starts, starts_host, sizeof(int64_t) * B, hipMemcpyHostToDevice, s));
+        MST_HIP(hipMemsetAsync(src.nz_count, 0, sizeof(uint32_t) * B, s));
+        src.starts = d_starts;
+    }
 
     int ntiles;
     if (fma && mr > TileDefault::RMAX)
-        return mst::fail(MST_E_ARG, "mst_scale_space: MST_FLAG_FMA is only built for blur radii <= %d", TileDefault::RMAX);
+        return mst::fail(MST_E_ARG, "%s: MST_FLAG_FMA is only built for blur radii <= %d", who, TileDefault::RMAX);
     if (fma) {
-        rc = launch_scale_space<TileDefaultFma>(c, nz, B, CH, d_lv, found, found_cap, found_count, partial, nt,
-                                                skip_empty, s);
+        rc = launch_scale_space<TileDefaultFma, BAND>(c, nz, src, B, CH, d_lv, found, found_cap, found_count, partial,
+                                                      nt, skip_empty, s);
         ntiles = tiles_total<TileDefault>(CH);
     } else if (mr <= TileDefault::RMAX) {
-        rc = launch_scale_space<TileDefault>(c, nz, B, CH, d_lv, found, found_cap, found_count, partial, nt,
-                                             skip_empty, s);
+        rc = launch_scale_space<TileDefault, BAND>(c, nz, src, B, CH, d_lv, found, found_cap, found_count, partial, nt,
+                                                   skip_empty, s);
         ntiles = tiles_total<TileDefault>(CH);
     } else {
-        rc = launch_scale_space<TileWide>(c, nz, B, CH, d_lv, found, found_cap, found_count, partial, nt,
-                                          skip_empty, s);
+        rc = launch_scale_space<TileWide, BAND>(c, nz, src, B, CH, d_lv, found, found_cap, found_count, partial, nt,
+                                                skip_empty, s);
         ntiles = tiles_total<TileWide>(CH);
     }
     if (rc != MST_OK) return rc;
     stats_reduce_kernel<<<dim3(nt, B), 256, 0, s>>>(partial, ntiles, nt, level_stats);
     MST_LAUNCH_CHECK();
     return MST_OK;
+}
+
+extern "C" int mst_scale_space(const double *c, const uint8_t *nz, int32_t B, int32_t CH, const mst_levels *lv,
+                               mst_found *found, uint32_t found_cap, uint32_t *found_count, double *level_stats,
+                               int32_t flags, void *workspace, uint64_t workspace_bytes, void *stream) {
+    if (!c || !nz) return mst::fail(MST_E_ARG, "mst_scale_space: bad argument");
+    BandSrc none = {nullptr, 0, 0, nullptr, nullptr};
+    return scale_space_impl<false>(c, nz, none, nullptr, B, CH, lv, found, found_cap, found_count, level_stats, flags,
+                                   workspace, workspace_bytes, stream, "mst_scale_space");
+}
+
+extern "C" int mst_scale_space_band(const double *band, int64_t n, int32_t dpx, const int64_t *starts, int32_t B,
+                                    int32_t CH, const mst_levels *lv, mst_found *found, uint32_t found_cap,
+                                    uint32_t *found_count, double *level_stats, uint32_t *nz_count, int32_t flags,
+                                    void *workspace, uint64_t workspace_bytes, void *stream) {
+    if (!band || !starts || !nz_count || n <= 0 || dpx < 0)
+        return mst::fail(MST_E_ARG, "mst_scale_space_band: bad argument");
+    BandSrc src = {band, n, dpx, nullptr, nz_count};
+    return scale_space_impl<true>(nullptr, nullptr, src, starts, B, CH, lv, found, found_cap, found_count, level_stats,
+                                  flags, workspace, workspace_bytes, stream, "mst_scale_space_band");
 }

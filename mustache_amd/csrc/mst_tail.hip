@@ -106,7 +106,88 @@ diag_kernel(const double *__restrict__ c, int CH, int b, const int32_t *__restri
         out[(size_t)i * CH + r] = (k >= 0 && r + k < CH) ? cb[(size_t)r * CH + r + k] : 0.0;
 }
 
+// ---- the same two gathers when the block only exists as a window of the band (mst_scale_space_band) -----------------
+// pixel (x, y) of the block that starts at `start`:  off = y - x,  raw = band[off][start + x] (0 outside 0..dpx+1 or past
+// the chromosome end),  tested = raw != 0 && off >= 4,  value = 2 where off <= 4 or off >= dpx+1 else raw.
+__device__ __forceinline__ double band_raw(const double *__restrict__ band, int64_t n, int dpx, int64_t start, int x,
+                                           int y) {
+    const int off = y - x;
+    if (off < 0 || off > dpx + 1 || start + y >= n) return 0.0;
+    return band[(int64_t)off * n + start + x];
+}
+
+__global__ void __launch_bounds__(256)
+features_band_kernel(const double *__restrict__ band, int64_t n, int dpx, int64_t start, int CH,
+                     const uint32_t *__restrict__ pixel, const int32_t *__restrict__ half, int ncand,
+                     uint32_t *__restrict__ cnt1, uint32_t *__restrict__ cnt2, double *__restrict__ cval) {
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= ncand) return;
+    const int x = (int)(pixel[i] / (uint32_t)CH), y = (int)(pixel[i] % (uint32_t)CH);
+    uint32_t out[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int s = half[i] * (pass + 1);
+        uint32_t acc = 0;
+        int xs = x - s, ys = y - s;                              // Python slice semantics, see features_kernel
+        if (xs < 0) xs = xs + CH > 0 ? xs + CH : 0;
+        if (ys < 0) ys = ys + CH > 0 ? ys + CH : 0;
+        const int x1 = x + s + 1 < CH ? x + s + 1 : CH, y1 = y + s + 1 < CH ? y + s + 1 : CH;
+        const int w = y1 - ys, h = x1 - xs;
+        if (w > 0 && h > 0) {
+            for (int q = lane; q < w * h; q += 64) {
+                const int dx = q / w, dy = q - dx * w;
+                const int px = xs + dx, py = ys + dy;
+                acc += (py - px >= 4 && band_raw(band, n, dpx, start, px, py) != 0.0) ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        out[pass] = acc;
+    }
+    if (lane == 0) {
+        cnt1[i] = out[0];
+        cnt2[i] = out[1];
+        const int off = y - x;
+        cval[i] = (off <= 4 || off >= dpx + 1) ? 2.0 : band_raw(band, n, dpx, start, x, y);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+diag_band_kernel(const double *__restrict__ band, int64_t n, int dpx, int64_t start, int CH,
+                 const int32_t *__restrict__ diag_k, double *__restrict__ out) {
+    const int i = blockIdx.y;
+    const int k = diag_k[i];
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < CH; r += gridDim.x * blockDim.x) {
+        double v = 0.0;
+        if (k >= 0 && r + k < CH) v = (k <= 4 || k >= dpx + 1) ? 2.0 : band_raw(band, n, dpx, start, r, r + k);
+        out[(size_t)i * CH + r] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int mst_candidate_features_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,
+                                           const uint32_t *pixel, const int32_t *half, int32_t ncand, uint32_t *cnt1,
+                                           uint32_t *cnt2, double *cval, void *stream) {
+    if (ncand == 0) return MST_OK;
+    if (!band || !pixel || !half || !cnt1 || !cnt2 || !cval || CH <= 0 || n <= 0 || dpx < 0 || ncand < 0)
+        return mst::fail(MST_E_ARG, "mst_candidate_features_band: bad argument");
+    features_band_kernel<<<(ncand + 3) / 4, 256, 0, mst::as_stream(stream)>>>(band, n, dpx, start, CH, pixel, half, ncand,
+                                                                            cnt1, cnt2, cval);
+    MST_LAUNCH_CHECK();
+    return MST_OK;
+}
+
+extern "C" int mst_gather_diagonals_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,
+                                         const int32_t *diag_k, int32_t nd, double *out, void *stream) {
+    if (nd == 0) return MST_OK;
+    if (!band || !diag_k || !out || CH <= 0 || n <= 0 || dpx < 0 || nd < 0 || nd > 65535)
+        return mst::fail(MST_E_ARG, "mst_gather_diagonals_band: bad argument");
+    diag_band_kernel<<<dim3((CH + 255) / 256, nd), 256, 0, mst::as_stream(stream)>>>(band, n, dpx, start, CH, diag_k, out);
+    MST_LAUNCH_CHECK();
+    return MST_OK;
+}
 
 extern "C" int mst_found_pvalues(const mst_found *found, uint32_t found_cap, const uint32_t *found_count,
                                  const uint32_t *nz_count, const double *level_stats, int32_t B, int32_t n_tested,

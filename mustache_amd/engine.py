@@ -67,6 +67,44 @@ class BlockBatch:
         return out.cpu().numpy()
 
 
+class BandBatch:
+    """Same interface as BlockBatch for blocks that exist only as windows of the band (mst_scale_space_band): the tail's
+    gathers read the band directly, no dense block is ever built."""
+
+    def __init__(self, engine, band, n, dpx, starts, CH, nz_count, found, fit):
+        self.engine, self.band, self.n, self.dpx, self.starts, self.CH = engine, band, int(n), int(dpx), list(starts), CH
+        self.B = len(self.starts)
+        self.nz_count, self.found, self.fit = nz_count, found, fit
+
+    def candidate_features(self, b, pixel, half):
+        lib = self.engine.lib
+        m = int(len(pixel))
+        if m == 0:
+            return np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0)
+        dev = self.band.device
+        d_pix = torch.from_numpy(np.ascontiguousarray(pixel, dtype=np.uint32).view(np.int32)).to(dev)
+        d_half = torch.from_numpy(np.ascontiguousarray(half, dtype=np.int32)).to(dev)
+        cnt1 = torch.empty(m, dtype=torch.int32, device=dev)
+        cnt2 = torch.empty(m, dtype=torch.int32, device=dev)
+        cval = torch.empty(m, dtype=torch.float64, device=dev)
+        _lib.check(lib.mst_candidate_features_band(_ptr(self.band), self.n, self.dpx, int(self.starts[b]), self.CH,
+                                                   _ptr(d_pix), _ptr(d_half), m, _ptr(cnt1), _ptr(cnt2), _ptr(cval),
+                                                   _stream()))
+        return (cnt1.cpu().numpy().view(np.uint32), cnt2.cpu().numpy().view(np.uint32), cval.cpu().numpy())
+
+    def diagonals(self, b, ks):
+        lib = self.engine.lib
+        m = int(len(ks))
+        if m == 0:
+            return np.zeros((0, self.CH))
+        dev = self.band.device
+        d_k = torch.from_numpy(np.ascontiguousarray(ks, dtype=np.int32)).to(dev)
+        out = torch.empty((m, self.CH), dtype=torch.float64, device=dev)
+        _lib.check(lib.mst_gather_diagonals_band(_ptr(self.band), self.n, self.dpx, int(self.starts[b]), self.CH,
+                                                 _ptr(d_k), m, _ptr(out), _stream()))
+        return out.cpu().numpy()
+
+
 class ScaleSpaceEngine:
     """Owns the level table and runs rows 2-7 of SURVEY.md section 8a on the GPU."""
 
@@ -112,12 +150,26 @@ class ScaleSpaceEngine:
                                                    1 if intra else 0, _stream()))
         return nz, nz_count
 
+    def sigma_loop_band(self, band, n, dpx, starts, CH, **kw):
+        """Rows 2-7 straight from the normalised band: blocks are cut, filled and masked inside the fused kernel.
+        Returns what sigma_loop returns plus the per-block tested-pixel counts (device int32 tensor) as last element."""
+        nz_count = torch.empty(len(starts), dtype=torch.int32, device=self.device)
+        res = self.sigma_loop(None, None, nz_count, band_src=(band, int(n), int(dpx), [int(s) for s in starts], int(CH)),
+                              **kw)
+        return res + (nz_count,)
+
     def sigma_loop(self, c, nz, nz_count, skip_empty=True, found_cap=None, download=True, timing=None, sort=True,
-                   with_value=True, with_q=True, fma=False):
+                   with_value=True, with_q=True, fma=False, band_src=None):
         """The fused kernel + p-values.  Returns host records (download=True) or the device buffers.
         `timing`: optional list; receives a (start, end) torch.cuda.Event pair bracketing the mst_scale_space launch
-        on the launch stream."""
-        B, CH, _ = c.shape
+        on the launch stream.  `band_src` = (band, n, dpx, starts, CH) selects the band-direct kernel (c, nz unused;
+        nz_count is then an OUTPUT)."""
+        if band_src is not None:
+            band, bn, bdpx, bstarts, CH = band_src
+            B = len(bstarts)
+            st_arr = (ctypes.c_int64 * B)(*bstarts)
+        else:
+            B, CH, _ = c.shape
         nt = self.levels.n_tested
         if found_cap is None:
             found_cap = self._found_cap.get(CH, max(4096, (CH * CH) // 32))
@@ -134,10 +186,14 @@ class ScaleSpaceEngine:
                 if timing is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                _lib.check(self.lib.mst_scale_space(_ptr(c), _ptr(nz), B, CH, lv, _ptr(found), found_cap,
-                                                    _ptr(count), _ptr(stats),
-                                                    (1 if skip_empty else 0) | (2 if fma else 0), _ptr(ws),
-                                                    ws_bytes, _stream()))
+                flags = (1 if skip_empty else 0) | (2 if fma else 0)
+                if band_src is not None:
+                    _lib.check(self.lib.mst_scale_space_band(_ptr(band), bn, bdpx, st_arr, B, CH, lv, _ptr(found),
+                                                             found_cap, _ptr(count), _ptr(stats), _ptr(nz_count), flags,
+                                                             _ptr(ws), ws_bytes, _stream()))
+                else:
+                    _lib.check(self.lib.mst_scale_space(_ptr(c), _ptr(nz), B, CH, lv, _ptr(found), found_cap,
+                                                        _ptr(count), _ptr(stats), flags, _ptr(ws), ws_bytes, _stream()))
                 if timing is not None:
                     e1.record()
                 try:

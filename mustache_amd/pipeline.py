@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .engine import ScaleSpaceEngine, BlockBatch, _ptr, _stream
+from .engine import ScaleSpaceEngine, BlockBatch, BandBatch, _ptr, _stream
 from .normalize import band_from_coo, normalize_band
 from .sharding import shard_blocks, gather_loops, world
 from .tail import block_tail
@@ -45,12 +45,13 @@ class ChromosomePipeline:
                                                             _ptr(nz), _ptr(nzc), _stream()))
         return c, nz, nzc
 
-    def batches(self, idx, CH):
-        per_block = CH * CH * 9 + max(4096, CH * CH // 32) * 24
+    def batches(self, idx, CH, dense=True):
+        per_block = (CH * CH * 9 if dense else 0) + max(4096, CH * CH // 32) * 48
         bs = max(1, int(self.max_batch_bytes // per_block))
         return [idx[i:i + bs] for i in range(0, len(idx), bs)]
 
-    def run_band(self, band, n, dpx, st, pt, skip_empty=True, distributed=True, timings=None, shard=None):
+    def run_band(self, band, n, dpx, st, pt, skip_empty=True, distributed=True, timings=None, shard=None,
+                 dense=False):
         """band: normalised band on the device.  Returns this chromosome's loops (all ranks, after the gather).
         `shard=(rank, world_size)` runs one rank's share without a process group (no gather) -- used by tests."""
         CH, start, end = block_tiling(n, dpx)
@@ -60,12 +61,20 @@ class ChromosomePipeline:
         mine = shard_blocks(len(start), rank, ws)
         loops = []
         t_dev = t_tail = 0.0
-        for group in self.batches(mine, CH):
+        for group in self.batches(mine, CH, dense):
             t0 = time.time()
-            c, nz, nzc = self.blocks_from_band(band, n, dpx, [start[i] for i in group], CH)
-            found, fits = self.engine.sigma_loop(c, nz, nzc, skip_empty=skip_empty, with_value=False)
-            batch = BlockBatch(self.engine, c, nz, CH, len(group),
-                               nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
+            starts_g = [start[i] for i in group]
+            if dense:       # materialise [B, CH, CH] blocks first (what mustache() gets from its caller) -- cross-check path
+                c, nz, nzc = self.blocks_from_band(band, n, dpx, starts_g, CH)
+                found, fits = self.engine.sigma_loop(c, nz, nzc, skip_empty=skip_empty, with_value=False)
+                batch = BlockBatch(self.engine, c, nz, CH, len(group),
+                                   nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
+            else:           # default: blocks are windows of the band, cut inside the fused kernel
+                c = nz = None
+                found, fits, nzc = self.engine.sigma_loop_band(band, n, dpx, starts_g, CH, skip_empty=skip_empty,
+                                                               with_value=False)
+                batch = BandBatch(self.engine, band, n, dpx, starts_g, CH,
+                                  nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
             t1 = time.time()
             for j, i in enumerate(group):
                 mask = block_mask_size(i, start, end, dpx)

@@ -144,3 +144,34 @@ def test_rank_shards_union_equals_single_rank():
         for rank in range(ws):
             union += [key(r) for r in pipe.run_band(band, n, dpx, 0.8, 0.1, shard=(rank, ws))]
         assert sorted(union) == full, "world_size %d" % ws
+
+
+@pytest.mark.parametrize("n,dpx,res", [(4300, 400, 5000), (1500, 400, 5000), (9000, 2000, 1000)])
+def test_band_direct_kernel_equals_dense_path(n, dpx, res):
+    """mst_scale_space_band (blocks cut, filled and masked inside the fused kernel) == mst_blocks_from_band +
+    mst_scale_space, record for record, and the two tails give identical loops (also for a chromosome shorter than one
+    block, where the block runs past the chromosome end)."""
+    import torch
+    from mustache_amd.normalize import band_from_coo, normalize_band
+    from mustache_amd.pipeline import ChromosomePipeline, block_tiling
+    from mustache_amd.synth import synth_coo
+    x, y, v = synth_coo(n, dpx, depth=120.0, seed=21)
+    pipe = ChromosomePipeline(OCT)
+    dev = pipe.device
+    band = band_from_coo(*(torch.from_numpy(a).to(dev) for a in (x, y, v)), n, dpx)
+    band, _, _ = normalize_band(band, n, dpx, res)
+    CH, start, end = block_tiling(n, dpx)
+    c, nz, cnt = pipe.blocks_from_band(band, n, dpx, start, CH)
+    for skip in (True, False):
+        fa, fita = pipe.engine.sigma_loop(c, nz, cnt, skip_empty=skip)
+        fb, fitb, cntb = pipe.engine.sigma_loop_band(band, n, dpx, start, CH, skip_empty=skip)
+        assert torch.equal(cnt, cntb)
+        for a, b in zip(fa, fb):
+            for k in ("pixel", "level", "value", "pval", "q"):
+                assert np.array_equal(a[k], b[k]), k
+        for (la, sa), (lb, sb) in zip(fita, fitb):
+            assert np.array_equal(la, lb) and np.array_equal(sa, sb)
+    key = lambda r: (int(r[0]), int(r[1]), float(r[2]), float(r[3]))
+    dense = [key(r) for r in pipe.run_band(band, n, dpx, 0.8, 0.2, distributed=False, dense=True)]
+    direct = [key(r) for r in pipe.run_band(band, n, dpx, 0.8, 0.2, distributed=False)]
+    assert dense == direct and (len(dense) > 0 or n < 2000)

@@ -24,12 +24,12 @@ for r in st[:12]:
     lines.append("| `%s` | %s | %.3f | %.3f | %s |" % (name, r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                      float(r["AverageNs"]) / 1e6, r["Percentage"]))
 tr = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_trace.csv"))))
-ss = [r for r in tr if "scale_space_kernel" in r["Kernel_Name"]]
+ss = [r for r in tr if "scale_space_kernel" in r["Kernel_Name"] and ", true>," not in r["Kernel_Name"]]   # exact mode only
 groups = collections.defaultdict(list)
 for r in ss:
     groups[(int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]))].append(
         (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-lines += ["", "## Fused kernel `scale_space_kernel<Tile<32,64,14>>` per launch shape", "",
+lines += ["", "## Fused kernel `scale_space_kernel<Tile<32,64,14>, band>` (exact arithmetic) per launch shape", "",
           "| tiles/block (padded) | blocks | launches | durations ms |", "|---|---|---|---|"]
 for (gx, gy), d in sorted(groups.items(), reverse=True):
     lines.append("| %d | %d | %d | %s |" % (gx, gy, len(d), ", ".join("%.3f" % x for x in d[:8])))

@@ -317,6 +317,8 @@ def write_loops(path, chromosome, chromosome2, res, loops, first):
 def main(argv=None):
     start_time = time.time()
     args = parse_args(sys.argv[1:] if argv is None else argv)
+    from .sharding import init_from_env
+    rank, _world = init_from_env()      # multi-GPU: blocks of each chromosome are sharded, rank 0 writes the TSV
     print("\n")
     f = args.f_path
     if args.bed and args.mat:
@@ -364,7 +366,7 @@ def main(argv=None):
                       octaves=args.octaves)
         print("{0} loops found for chrmosome={1}, fdr<{2} in {3}sec".format(
             len(o), chromosome, args.pt, "%.2f" % (time.time() - start_time)))
-        if i == 0 or o:
+        if rank == 0 and (i == 0 or o):
             write_loops(args.outdir, chromosome, chromosome2, res, o, first=(i == 0))
         start_time = time.time()
 

@@ -45,3 +45,19 @@ def gather_loops(loops, device=None, group=None):
         arr = parts[r][:counts[r]].cpu().numpy()
         out.extend([[np.int64(a), np.int64(b), np.float64(q), np.float64(s)] for a, b, q, s in arr])
     return out
+
+
+def init_from_env():
+    """`python -m torch.distributed.run --nproc-per-node N -m mustache_amd ...`: one process per GPU.  Joins the process
+    group described by the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*) with backend nccl (= RCCL) and
+    binds this process to its GPU.  A plain single-process run (no WORLD_SIZE) is left untouched.  Returns (rank, world)."""
+    import os
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws <= 1 or (dist.is_available() and dist.is_initialized()):
+        return world()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", rank=int(os.environ["RANK"]), world_size=ws,
+                            device_id=torch.device("cuda", local))
+    return world()

@@ -175,3 +175,20 @@ def test_band_direct_kernel_equals_dense_path(n, dpx, res):
     dense = [key(r) for r in pipe.run_band(band, n, dpx, 0.8, 0.2, distributed=False, dense=True)]
     direct = [key(r) for r in pipe.run_band(band, n, dpx, 0.8, 0.2, distributed=False)]
     assert dense == direct and (len(dense) > 0 or n < 2000)
+
+
+def test_chr21_5kb_shape_end_to_end_vs_oracle():
+    """BASELINE config 1/2 shape: n = 9630 bins at 5 kb (6 blocks of 2000 x 2000), -pt 0.1 -st 0.8.  Whole per-chromosome run
+    on the GPU against the CPU oracle's regulator restatement: identical loop coordinates and scales, FDR to 1e-6."""
+    import oracle
+    from mustache_amd.pipeline import ChromosomePipeline
+    from mustache_amd.synth import synth_coo
+    n, dpx, res = 9630, 400, 5000
+    x, y, v = synth_coo(n, dpx, depth=300.0, seed=0, nloops=300)
+    exp = oracle.regulator_coo(x, y, v.copy(), res, dpx, OCT, 0.8, 0.1)           # normalises a copy on the CPU
+    pipe = ChromosomePipeline(OCT)
+    got = pipe.run(x, y, v.copy(), res, dpx, 0.8, 0.1)                             # normalises on the GPU
+    got = sorted(got, key=lambda r: (int(r[0]), int(r[1])))
+    assert len(exp) > 50
+    assert [(int(a), int(b), s) for a, b, _, s in got] == [(int(a), int(b), s) for a, b, _, s in exp]
+    np.testing.assert_allclose([q for _, _, q, _ in got], [q for _, _, q, _ in exp], rtol=1e-6)

@@ -194,3 +194,41 @@ def test_opt_in_fma_mode_within_north_star_tolerance():
     np.testing.assert_allclose(rb["value"], ra["value"], rtol=1e-9)
     np.testing.assert_allclose(rb["pval"], ra["pval"], rtol=1e-5, atol=1e-300)
     np.testing.assert_allclose(fb[0][1], fa[0][1], rtol=1e-9)
+
+
+def test_exact_zero_pvalue_and_top_edge_candidates():
+    """SURVEY 8c edge cases: (1) a response so strong that 1 - (-expm1(-z)) is exactly 0.0; (2) strong candidates within
+    2*ceil(sigma) rows of the block's top edge, which the reference drops through a negative-start (empty) slice."""
+    import torch
+    import oracle
+    from mustache_amd.engine import ScaleSpaceEngine
+    from mustache_amd.mustache import mustache
+    from mustache_amd.synth import synth_coo
+    n, dpx = 360, 90
+    x, y, v = synth_coo(n, dpx, depth=300.0, seed=23, nloops=20)
+    oracle.normalize_sparse(x, y, v, 50000, dpx)
+    c = np.zeros((n, n))
+    c[x, y] = v
+    yy, xx = np.mgrid[0:n, 0:n]
+    for (cy, cx, amp) in ((5, 45, 60.0), (2, 30, 40.0), (200, 250, 4000.0)):      # two blobs at the top edge, one enormous
+        c += amp * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * 1.5 ** 2)) * (c != 0)
+    ref = c.copy()
+    nz = oracle.block_prologue(ref, dpx)
+    ss = oracle.scale_space_levels(ref, nz, [1.6, 3.2])
+    f = ss.pval != 2
+    assert (ss.pval[f] == 0.0).sum() >= 1, "fixture must contain an exactly-zero p-value"
+    eng = ScaleSpaceEngine([1.6, 3.2])
+    dev = torch.from_numpy(c.copy()).cuda().unsqueeze(0)
+    nzd, cnt = eng.prologue(dev, dpx, True)
+    found, _ = eng.sigma_loop(dev, nzd, cnt)
+    assert np.array_equal(found[0]["pixel"].astype(np.int64), np.flatnonzero(nz.ravel())[f])
+    assert np.array_equal(found[0]["pval"] == 0.0, ss.pval[f] == 0.0), "exact zeros must coincide"
+    np.testing.assert_allclose(found[0]["pval"], ss.pval[f], rtol=1e-9, atol=0)
+    exp, mid = oracle.mustache_block(c.copy(), 0, dpx, [1.6, 3.2], 0.7, 0.2, return_intermediate=True)
+    got = mustache(c, "1", "1", 5000, [], 0, n, 0, dpx, [1.6, 3.2], 0.7, 0.2)
+    assert [(int(a), int(b), s) for a, b, _, s in got] == [(int(a), int(b), s) for a, b, _, s in exp]
+    assert not any(int(a) < 8 for a, _, _, _ in exp), "top-edge candidates are dropped by the reference's slice semantics"
+    # the top-edge blobs were genuinely found and significant -- they are dropped by the filter, not missed
+    q = oracle.benjamini_hochberg(ss.pval[f])
+    rows = np.flatnonzero(nz.ravel())[f] // n
+    assert ((rows < 8) & (q < 0.2)).any()

@@ -192,3 +192,16 @@ def test_chr21_5kb_shape_end_to_end_vs_oracle():
     assert len(exp) > 50
     assert [(int(a), int(b), s) for a, b, _, s in got] == [(int(a), int(b), s) for a, b, _, s in exp]
     np.testing.assert_allclose([q for _, _, q, _ in got], [q for _, _, q, _ in exp], rtol=1e-6)
+
+
+@pytest.mark.parametrize("n,dpx,res", [(300, 400, 5000), (450, 400, 5000), (2600, 400, 1000)])
+def test_tiny_chromosomes_do_not_break_the_pipeline(n, dpx, res):
+    """Chromosome shorter than the distance limit / than one block, and the branch-B normalisation: same result as the oracle
+    (usually no loops at all -- the reference returns [] below 10000 tested pixels)."""
+    import oracle
+    from mustache_amd.pipeline import ChromosomePipeline
+    from mustache_amd.synth import synth_coo
+    x, y, v = synth_coo(n, dpx, depth=200.0, seed=3)
+    exp = oracle.regulator_coo(x, y, v.copy(), res, dpx, OCT, 0.8, 0.2)
+    got = sorted(ChromosomePipeline(OCT).run(x, y, v.copy(), res, dpx, 0.8, 0.2), key=lambda r: (int(r[0]), int(r[1])))
+    assert [(int(a), int(b), s) for a, b, _, s in got] == [(int(a), int(b), s) for a, b, _, s in exp]

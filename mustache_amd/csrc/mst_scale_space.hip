@@ -525,6 +525,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
         lvl[k] = 0;
     }
     const int wave = tid >> 6, lane = tid & 63;
+    const bool wave_has_nz = __any(nz_mask != 0);
     const bool all_tested = __all(nz_mask == ((1u << K) - 1u));
     double *de_mine = de + (cg * 2) * RGR + rr;                                   // [cg][0 = left edge, 1 = right edge][rr]
     const double *de_left = de + ((cg > 0 ? cg - 1 : 0) * 2 + 1) * RGR + rr;      // left neighbour's right edge
@@ -590,6 +591,10 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
                 // tested level = D_{kl-2}: previous = D_{kl-3} (ep), current (Dc, ec, gp), next = this one (m, en)
                 double lmin = INFINITY, lsum = 0.0;
                 const uint32_t code = (uint32_t)tested + 1u;
+                // the reference evaluates the sieve and expon.fit on the tested pixels only (Lc[nz], mustache.py:755-768);
+                // a wave that owns none has nothing to do here (its 3x3 maxima above are still computed, as the
+                // reference's maximum_filter runs over the whole block)
+                if (wave_has_nz)
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const bool tz = (nz_mask >> k) & 1u;

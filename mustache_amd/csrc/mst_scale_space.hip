@@ -526,7 +526,6 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
     }
     const int wave = tid >> 6, lane = tid & 63;
     const bool wave_has_nz = __any(nz_mask != 0);
-    const bool all_tested = __all(nz_mask == ((1u << K) - 1u));
     double *de_mine = de + (cg * 2) * RGR + rr;                                   // [cg][0 = left edge, 1 = right edge][rr]
     const double *de_left = de + ((cg > 0 ? cg - 1 : 0) * 2 + 1) * RGR + rr;      // left neighbour's right edge
     const double *de_right = de + ((cg < T::NCG - 1 ? cg + 1 : cg) * 2) * RGR + rr;  // right neighbour's left edge

@@ -65,7 +65,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 size_t sort_temp_bytes(int B, uint32_t cap) {
     size_t bytes = 0;
-    hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, bytes, (const double *)nullptr, (double *)nullptr,
+    (void)hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, bytes, (const double *)nullptr, (double *)nullptr,
                                                (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)((size_t)B * cap), B,
                                                (const int *)nullptr, (const int *)nullptr, 0, 64, (hipStream_t)0);
     return bytes;

@@ -138,11 +138,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
+    # test hooks (used to exercise the N > 1 control flow on a single-GPU box): a gloo process group and all ranks on GPU 0
+    backend = os.environ.get("MST_BENCH_BACKEND", "nccl")
+    if os.environ.get("MST_BENCH_ONE_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
@@ -165,7 +172,7 @@ def main():
             last = w.step(skip_empty, fma=fma)
         barrier()
         dt = time.time() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         kms = [a.elapsed_time(b) for a, b in w.kernel_ms]

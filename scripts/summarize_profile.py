@@ -80,8 +80,9 @@ if "FETCH_SIZE" in allc and "WRITE_SIZE" in allc:
                "note": "FETCH_SIZE x2 (gfx950 correction), KiB units; measured on 12 blocks, scaled per pixel to the "
                        "124-block launch bench.py times"}
     lines += ["", "HBM traffic of the launch: fetch %.1f MB (x2-corrected) + write %.1f MB = **%.2f B/pixel** "
-              "(algorithmic level-streaming model: 592 B/pixel; minimum for a fully fused kernel: ~9 B/pixel read + "
-              "found records)." % (fetch_b / 1e6, write_b / 1e6, (fetch_b + write_b) / px)]
+              "(algorithmic level-streaming model: 592 B/pixel.  With the dense-block source the input alone is 8 "
+              "B/pixel + 1 B/pixel of mask; with the band source -- the default since r01e -- only the in-band part of "
+              "the band is read, the constant regions are synthesised in the kernel)." % (fetch_b / 1e6, write_b / 1e6, (fetch_b + write_b) / px)]
 if "SQ_WAVE_CYCLES" in allc:
     wc = allc["SQ_WAVE_CYCLES"]
     lines += ["", "Wave-cycle split: ACTIVE_INST_ANY %.1f %%, of which VALU %.1f %% of wave cycles; WAIT_INST_ANY %.1f %%; "

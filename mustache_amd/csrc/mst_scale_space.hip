@@ -117,19 +117,22 @@ __device__ __forceinline__ double lane_next(double x) {
 
 // 64-lane reductions with DPP moves only (no LDS round trips): inclusive scans inside the four 16-lane rows
 // (row_shr 1, 2, 4, 8), then row_bcast15 / row_bcast31 carry the row totals upward; lane 63 ends up with the total.
-// The combination order is fixed, so the result is deterministic.
+// The combination order is fixed, so the result is deterministic.  ONLY lane 63 is meaningful afterwards: the lanes a
+// shift or a row mask leaves without a source are not given an identity value (that costs four extra moves per step) --
+// they read 0 / keep an unspecified register, and none of them lies on the path into lane 63 (lane 15 of a row combines
+// lanes 14, 13, 11, 7 after steps 1, 2, 4, 8, each of which only ever read lanes with a valid source; the broadcasts
+// read lanes 15 / 47 and 31).
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_fetch(double identity, double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(__double2loint(identity), lo, CTRL, ROW_MASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(__double2hiint(identity), hi, CTRL, ROW_MASK, 0xf, false);
+__device__ __forceinline__ double dpp_fetch(double x) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, ROW_MASK, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ void wave_reduce_min_sum(double &mn, double &sm) {
 #define MST_STEP(CTRL, MASK)                                           \
     {                                                                  \
-        const double a_ = dpp_fetch<CTRL, MASK>(INFINITY, mn);         \
-        const double b_ = dpp_fetch<CTRL, MASK>(0.0, sm);              \
+        const double a_ = dpp_fetch<CTRL, MASK>(mn);                   \
+        const double b_ = dpp_fetch<CTRL, MASK>(sm);                   \
         mn = a_ < mn ? a_ : mn;                                        \
         sm = sm + b_;                                                  \
     }
@@ -243,7 +246,7 @@ __device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const do
 // a full second round).
 template <class T, int R>
 __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__restrict__ vb,
-                                      const double (&wall)[T::RMAX + 1], int tid, const double *__restrict__ vsrc,
+                                      const double (&wall)[T::RMAX + 1], int ptid, const double *__restrict__ vsrc,
                                       double *__restrict__ vdst) {
     constexpr int K = T::K, KC = Chunk<T::K, R>::KC;
     constexpr int NC = T::RGC + 2 * R;               // columns to produce
@@ -270,7 +273,7 @@ __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__r
     if constexpr (MAINC < NC) {
         constexpr int XC = NC - MAINC;               // leftover columns
         constexpr int XRG = T::RGR / 4;              // 4-row pieces per column
-        for (int it = tid; it < XRG * XC; it += T::NT) {
+        for (int it = ptid; it < XRG * XC; it += T::NT) {
             const int rgp = it / XC;
             const int col = MAINC + (it - rgp * XC);
             const int row0 = rgp * 4;
@@ -526,6 +529,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
     }
     const int wave = tid >> 6, lane = tid & 63;
     const bool wave_has_nz = __any(nz_mask != 0);
+    const bool wave_all_in = __all(in_mask == (1u << K) - 1u);   // no pixel of this wave lies outside the block
     double *de_mine = de + (cg * 2) * RGR + rr;                                   // [cg][0 = left edge, 1 = right edge][rr]
     const double *de_left = de + ((cg > 0 ? cg - 1 : 0) * 2 + 1) * RGR + rr;      // left neighbour's right edge
     const double *de_right = de + ((cg < T::NCG - 1 ? cg + 1 : cg) * 2) * RGR + rr;  // right neighbour's left edge
@@ -538,6 +542,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
     const double *hsrc = vb + rr * T::VP + cg * K;
 
     const int n_oct = lv->n_octaves, lpo = lv->levels_per_octave;
+    const int prot = (int)(blockIdx.x >> 3) * 2 + (int)(blockIdx.x >> 11);
     int tested = 0;
     for (int o = 0; o < n_oct; ++o) {
         // With octaves a factor 2 apart and s = 10, sigma_11 and sigma_12 of one octave are bit-identical to sigma_1 and
@@ -552,13 +557,18 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
 #pragma unroll
             for (int j = 0; j <= RMAX; ++j) taps[j] = lv->taps[l][j];
             double g[K];
-            blur_dispatch<T>(r, ct, vb, taps, tid, vsrc, vdst, hsrc, g);
+            // the leftover V-pass pieces occupy the first ceil(R/4) waves of a rotated wave order, so that over the
+            // levels (and between the workgroups sharing a CU) every SIMD carries the same share of them
+            const int ptid = (tid + 64 * ((l + prot) & 3)) & (T::NT - 1);
+            blur_dispatch<T>(r, ct, vb, taps, ptid, vsrc, vdst, hsrc, g);
             double d[K];
             if (kl >= 2) {
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    d[k] = gprev[k] - g[k];
-                    if (!((in_mask >> k) & 1u)) d[k] = 0.0;  // maximum_filter pads with zeros outside the block
+                for (int k = 0; k < K; ++k) d[k] = gprev[k] - g[k];
+                if (!wave_all_in) {                          // maximum_filter pads with zeros outside the block
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        if (!((in_mask >> k) & 1u)) d[k] = 0.0;
                 }
                 de_mine[0] = d[0];
                 de_mine[RGR] = d[K - 1];

@@ -139,6 +139,13 @@ int mst_candidate_features(const double *c, const uint8_t *nz, int32_t CH, int32
 int mst_gather_diagonals(const double *c, int32_t CH, int32_t b, const int32_t *diag_k, int32_t n, double *out,
                          void *stream);
 
+/* mustache.py:816-824: mean_out[i] = np.mean(dg[dg != 0]) for dg = diagonal diag_k[i] of block b -- the non-zero entries
+ * summed in NumPy's pairwise order (numpy/_core/src/umath/loops_utils.h.src), so the value is bit-identical to the
+ * reference's and only nd doubles leave the device.  A diagonal without non-zero entries gives NaN (as np.mean does).
+ * diag_k: dev [nd]; mean_out: dev [nd].  CH*8 bytes must fit the LDS (CH <= 20000). */
+int mst_diag_means(const double *c, int32_t CH, int32_t b, const int32_t *diag_k, int32_t nd, double *mean_out,
+                   void *stream);
+
 /* ---- diagonal-major band layout ---------------------------------------------------------------------------------
  * band[d * n + i] = value of pixel (i, i + d), d = 0 .. dpx+1, i = 0 .. n-1; 0.0 = no contact.  dev, float64. */
 
@@ -178,12 +185,14 @@ int mst_scale_space_band(const double *band, int64_t n, int32_t dpx, const int64
                          double *level_stats, uint32_t *nz_count, int32_t flags, void *workspace,
                          uint64_t workspace_bytes, void *stream);
 
-/* mst_candidate_features / mst_gather_diagonals for the block that starts at bin `start` of the band. */
+/* mst_candidate_features / mst_gather_diagonals / mst_diag_means for the block that starts at bin `start` of the band. */
 int mst_candidate_features_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,
                                 const uint32_t *pixel, const int32_t *half, int32_t ncand, uint32_t *cnt1,
                                 uint32_t *cnt2, double *cval, void *stream);
 int mst_gather_diagonals_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,
                               const int32_t *diag_k, int32_t nd, double *out, void *stream);
+int mst_diag_means_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH, const int32_t *diag_k,
+                        int32_t nd, double *mean_out, void *stream);
 
 /* ---- two-sample (differential) caller, reference mustache/diff_mustache.py:260-569 ------------------------------------
  * The per-sample sigma loops are mst_scale_space on both samples' blocks.  The entry points below add what

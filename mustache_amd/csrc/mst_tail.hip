@@ -2,6 +2,7 @@
 //   mst_found_pvalues      <- reference mustache/mustache.py:755-756 (expon.fit + 1 - expon.cdf), found pixels only
 //   mst_candidate_features <- reference mustache/mustache.py:800-811, :824 (window densities of nz, c[x, y])
 //   mst_gather_diagonals   <- reference mustache/mustache.py:816-823 (diagonals for the diagonal-mean filter)
+//   mst_diag_means         <- reference mustache/mustache.py:816-824 (np.mean of their non-zero entries, NumPy's order)
 // All of them touch a few thousand pixels per block; they exist so the tail never pulls a dense block to the host.
 #include <cmath>
 #include <cstdlib>
@@ -166,7 +167,129 @@ diag_band_kernel(const double *__restrict__ band, int64_t n, int dpx, int64_t st
     }
 }
 
+// ---- diagonal means for the diagonal-mean filter (mustache.py:816-824): mean of the NON-ZERO entries of diagonal k of the
+// filled block, np.mean(dg[dg != 0]).  NumPy reduces a contiguous float64 array with its pairwise summation
+// (numpy/_core/src/umath/loops_utils.h.src, @TYPE@_pairwise_sum: < 8 elements serially; <= 128 elements with eight strided
+// accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the n % 8 tail added serially; larger arrays split at
+// n/2 rounded down to a multiple of 8, recursively).  The kernel follows that order exactly, on the compacted non-zero
+// entries, so the mean -- and with it the filter's `c[x,y] > 2*mean` decision -- is bit-identical to the reference's.
+__device__ double np_pairwise_leaf(const double *a, int n) {
+    if (n < 8) {
+        double res = -0.0;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+__device__ double np_pairwise_sum(const double *a, int n) {
+    int off[24], len[24], state[24];
+    double left[24];
+    int sp = 1;
+    off[0] = 0;
+    len[0] = n;
+    state[0] = 0;
+    double r = 0.0;
+    bool have = false;                 // r holds the value of the node just popped
+    while (sp > 0) {
+        const int t = sp - 1;
+        if (!have) {
+            if (len[t] <= 128) {
+                r = np_pairwise_leaf(a + off[t], len[t]);
+                have = true;
+                --sp;
+            } else {                    // descend into the left half
+                int n2 = len[t] / 2;
+                n2 -= n2 % 8;
+                state[t] = 0;
+                off[sp] = off[t];
+                len[sp] = n2;
+                ++sp;
+            }
+        } else if (state[t] == 0) {    // left half done -> right half
+            int n2 = len[t] / 2;
+            n2 -= n2 % 8;
+            left[t] = r;
+            state[t] = 1;
+            off[sp] = off[t] + n2;
+            len[sp] = len[t] - n2;
+            ++sp;
+            have = false;
+        } else {                        // both halves done
+            r = left[t] + r;
+            --sp;
+        }
+    }
+    return r;
+}
+
+// one 64-lane workgroup per diagonal: ordered compaction of the non-zero entries into LDS, then lane 0 sums them
+template <bool BAND>
+__global__ void __launch_bounds__(64)
+diag_mean_kernel(const double *__restrict__ src, int64_t n, int dpx, int64_t start, int CH, int b,
+                 const int32_t *__restrict__ diag_k, double *__restrict__ mean_out) {
+    extern __shared__ double dm_buf[];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int k = diag_k[i];
+    const int L = (k >= 0 && k < CH) ? CH - k : 0;
+    const double *cb = BAND ? src : src + (size_t)b * CH * CH;
+    int base = 0;
+    for (int r0 = 0; r0 < L; r0 += 64) {
+        const int r = r0 + lane;
+        double v = 0.0;
+        if (r < L) {
+            if (BAND) v = (k <= 4 || k >= dpx + 1) ? 2.0 : band_raw(src, n, dpx, start, r, r + k);
+            else v = cb[(size_t)r * CH + r + k];
+        }
+        const bool keep = r < L && v != 0.0;           // NaN != 0 is true, as in NumPy
+        const unsigned long long bal = __ballot(keep);
+        if (keep) dm_buf[base + __popcll(bal & ((1ull << lane) - 1ull))] = v;
+        base += __popcll(bal);
+    }
+    __syncthreads();
+    if (lane == 0) mean_out[i] = np_pairwise_sum(dm_buf, base) / (double)base;
+}
+
+template <bool BAND>
+int diag_means_launch(const double *src, int64_t n, int dpx, int64_t start, int CH, int b, const int32_t *diag_k, int nd,
+                      double *mean_out, hipStream_t s) {
+    const size_t lds = (size_t)CH * sizeof(double);
+    if (lds > 160 * 1024 - 256) return mst::fail(MST_E_ARG, "diagonal means: CH %d does not fit the LDS", CH);
+    if (lds > 64 * 1024)
+        MST_HIP(hipFuncSetAttribute((const void *)diag_mean_kernel<BAND>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+    diag_mean_kernel<BAND><<<nd, 64, lds, s>>>(src, n, dpx, start, CH, b, diag_k, mean_out);
+    MST_LAUNCH_CHECK();
+    return MST_OK;
+}
+
 }  // namespace
+
+extern "C" int mst_diag_means(const double *c, int32_t CH, int32_t b, const int32_t *diag_k, int32_t nd, double *mean_out,
+                              void *stream) {
+    if (nd == 0) return MST_OK;
+    if (!c || !diag_k || !mean_out || CH <= 0 || b < 0 || nd < 0)
+        return mst::fail(MST_E_ARG, "mst_diag_means: bad argument");
+    return diag_means_launch<false>(c, 0, 0, 0, CH, b, diag_k, nd, mean_out, mst::as_stream(stream));
+}
+
+extern "C" int mst_diag_means_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,
+                                   const int32_t *diag_k, int32_t nd, double *mean_out, void *stream) {
+    if (nd == 0) return MST_OK;
+    if (!band || !diag_k || !mean_out || CH <= 0 || n <= 0 || dpx < 0 || nd < 0)
+        return mst::fail(MST_E_ARG, "mst_diag_means_band: bad argument");
+    return diag_means_launch<true>(band, n, dpx, start, CH, 0, diag_k, nd, mean_out, mst::as_stream(stream));
+}
 
 extern "C" int mst_candidate_features_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,
                                            const uint32_t *pixel, const int32_t *half, int32_t ncand, uint32_t *cnt1,

@@ -26,48 +26,123 @@ def require_gpu():
     return _lib.load()
 
 
-class BlockBatch:
+def _off(t, n):
+    """Device pointer of element n of tensor t."""
+    return ctypes.c_void_p(t.data_ptr() + n * t.element_size())
+
+
+class _MultiGather:
+    """Block-batched forms of the tail's gathers: ONE upload of the concatenated candidates, one launch per block on the
+    same stream (pointer offsets into the shared buffers), ONE download -- instead of a host round trip per block."""
+
+    def candidate_features_multi(self, bs, pixels, halfs):
+        sizes = [int(len(p)) for p in pixels]
+        total = sum(sizes)
+        empty = (np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0))
+        if total == 0:
+            return [empty for _ in bs]
+        dev = self._device()
+        pix = np.concatenate([np.asarray(p, dtype=np.uint32) for p in pixels])
+        half = np.concatenate([np.asarray(h, dtype=np.int32) for h in halfs])
+        d_pix = torch.from_numpy(pix.view(np.int32)).to(dev)
+        d_half = torch.from_numpy(half).to(dev)
+        cnt = torch.empty((2, total), dtype=torch.int32, device=dev)
+        cval = torch.empty(total, dtype=torch.float64, device=dev)
+        off = 0
+        for b, m in zip(bs, sizes):
+            if m:
+                self._features_launch(b, _off(d_pix, off), _off(d_half, off), m, _off(cnt, off), _off(cnt, total + off),
+                                      _off(cval, off))
+            off += m
+        cnt_h = cnt.cpu().numpy().view(np.uint32)
+        cval_h = cval.cpu().numpy()
+        out, off = [], 0
+        for m in sizes:
+            out.append((cnt_h[0, off:off + m], cnt_h[1, off:off + m], cval_h[off:off + m]) if m else empty)
+            off += m
+        return out
+
+    def diagonals_multi(self, bs, kss):
+        sizes = [int(len(k)) for k in kss]
+        total = sum(sizes)
+        if total == 0:
+            return [np.zeros((0, self.CH)) for _ in bs]
+        dev = self._device()
+        d_k = torch.from_numpy(np.concatenate([np.asarray(k, dtype=np.int32) for k in kss])).to(dev)
+        out = torch.empty((total, self.CH), dtype=torch.float64, device=dev)
+        off = 0
+        for b, m in zip(bs, sizes):
+            if m:
+                self._diagonals_launch(b, _off(d_k, off), m, _off(out, off * self.CH))
+            off += m
+        host = self.engine._pinned("diags", (total, self.CH), torch.float64)
+        host.copy_(out, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        host = host.numpy()
+        res, off = [], 0
+        for m in sizes:
+            res.append(host[off:off + m])
+            off += m
+        return res
+
+    def diagonal_means_multi(self, bs, kss):
+        """Per block the mean of the non-zero entries of its diagonals kss[i] (np.mean(dg[dg != 0]), mustache.py:816-820),
+        computed on the device in NumPy's summation order -- bit-identical, and only one double per diagonal comes back."""
+        sizes = [int(len(k)) for k in kss]
+        total = sum(sizes)
+        if total == 0:
+            return [np.zeros(0) for _ in bs]
+        dev = self._device()
+        d_k = torch.from_numpy(np.concatenate([np.asarray(k, dtype=np.int32) for k in kss])).to(dev)
+        out = torch.empty(total, dtype=torch.float64, device=dev)
+        off = 0
+        for b, m in zip(bs, sizes):
+            if m:
+                self._diag_means_launch(b, _off(d_k, off), m, _off(out, off))
+            off += m
+        host = out.cpu().numpy()
+        res, off = [], 0
+        for m in sizes:
+            res.append(host[off:off + m])
+            off += m
+        return res
+
+    def candidate_features(self, b, pixel, half):
+        """(cnt1, cnt2, cval) for candidate pixels of block b (reference mustache.py:800-807, :824)."""
+        return self.candidate_features_multi([b], [pixel], [half])[0]
+
+    def diagonals(self, b, ks):
+        """Rows = diagonals c[r, r+k] of block b, zero padded to CH (reference mustache.py:816-820)."""
+        return self.diagonals_multi([b], [ks])[0].copy()      # the multi form hands out views of a reused pinned buffer
+
+
+class BlockBatch(_MultiGather):
     """Results of the sigma loop for B blocks, plus the device buffers the tail needs.
 
     found[b] = dict(pixel uint32 [m] ascending, level uint32 [m] (1-based tested level), value float64 [m],
                     pval float64 [m])  on the host;  nz_count[b];  fit[b] = (loc[n_tested], scale[n_tested]).
+    The tail's gathers are tiny, so dense blocks never leave the device.
     """
 
     def __init__(self, engine, c, nz, CH, B, nz_count, found, fit):
         self.engine, self.c, self.nz, self.CH, self.B = engine, c, nz, CH, B
         self.nz_count, self.found, self.fit = nz_count, found, fit
 
-    # ---- tail helpers: tiny gathers so dense blocks never leave the device ------------------------------------
-    def candidate_features(self, b, pixel, half):
-        """(cnt1, cnt2, cval) for candidate pixels of block b (reference mustache.py:800-807, :824)."""
-        lib = self.engine.lib
-        n = int(len(pixel))
-        if n == 0:
-            return np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0)
-        dev = self.c.device
-        d_pix = torch.from_numpy(np.ascontiguousarray(pixel, dtype=np.uint32).view(np.int32)).to(dev)
-        d_half = torch.from_numpy(np.ascontiguousarray(half, dtype=np.int32)).to(dev)
-        cnt1 = torch.empty(n, dtype=torch.int32, device=dev)
-        cnt2 = torch.empty(n, dtype=torch.int32, device=dev)
-        cval = torch.empty(n, dtype=torch.float64, device=dev)
-        _lib.check(lib.mst_candidate_features(_ptr(self.c), _ptr(self.nz), self.CH, b, _ptr(d_pix), _ptr(d_half),
-                                              n, _ptr(cnt1), _ptr(cnt2), _ptr(cval), _stream()))
-        return (cnt1.cpu().numpy().view(np.uint32), cnt2.cpu().numpy().view(np.uint32), cval.cpu().numpy())
+    def _device(self):
+        return self.c.device
 
-    def diagonals(self, b, ks):
-        """Rows = diagonals c[r, r+k] of block b, zero padded to CH (reference mustache.py:816-820)."""
-        lib = self.engine.lib
-        n = int(len(ks))
-        if n == 0:
-            return np.zeros((0, self.CH))
-        dev = self.c.device
-        d_k = torch.from_numpy(np.ascontiguousarray(ks, dtype=np.int32)).to(dev)
-        out = torch.empty((n, self.CH), dtype=torch.float64, device=dev)
-        _lib.check(lib.mst_gather_diagonals(_ptr(self.c), self.CH, b, _ptr(d_k), n, _ptr(out), _stream()))
-        return out.cpu().numpy()
+    def _features_launch(self, b, pix, half, m, cnt1, cnt2, cval):
+        _lib.check(self.engine.lib.mst_candidate_features(_ptr(self.c), _ptr(self.nz), self.CH, b, pix, half, m, cnt1,
+                                                          cnt2, cval, _stream()))
+
+    def _diagonals_launch(self, b, ks, m, out):
+        _lib.check(self.engine.lib.mst_gather_diagonals(_ptr(self.c), self.CH, b, ks, m, out, _stream()))
+
+    def _diag_means_launch(self, b, ks, m, out):
+        _lib.check(self.engine.lib.mst_diag_means(_ptr(self.c), self.CH, b, ks, m, out, _stream()))
 
 
-class BandBatch:
+class BandBatch(_MultiGather):
     """Same interface as BlockBatch for blocks that exist only as windows of the band (mst_scale_space_band): the tail's
     gathers read the band directly, no dense block is ever built."""
 
@@ -76,33 +151,20 @@ class BandBatch:
         self.B = len(self.starts)
         self.nz_count, self.found, self.fit = nz_count, found, fit
 
-    def candidate_features(self, b, pixel, half):
-        lib = self.engine.lib
-        m = int(len(pixel))
-        if m == 0:
-            return np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0)
-        dev = self.band.device
-        d_pix = torch.from_numpy(np.ascontiguousarray(pixel, dtype=np.uint32).view(np.int32)).to(dev)
-        d_half = torch.from_numpy(np.ascontiguousarray(half, dtype=np.int32)).to(dev)
-        cnt1 = torch.empty(m, dtype=torch.int32, device=dev)
-        cnt2 = torch.empty(m, dtype=torch.int32, device=dev)
-        cval = torch.empty(m, dtype=torch.float64, device=dev)
-        _lib.check(lib.mst_candidate_features_band(_ptr(self.band), self.n, self.dpx, int(self.starts[b]), self.CH,
-                                                   _ptr(d_pix), _ptr(d_half), m, _ptr(cnt1), _ptr(cnt2), _ptr(cval),
-                                                   _stream()))
-        return (cnt1.cpu().numpy().view(np.uint32), cnt2.cpu().numpy().view(np.uint32), cval.cpu().numpy())
+    def _device(self):
+        return self.band.device
 
-    def diagonals(self, b, ks):
-        lib = self.engine.lib
-        m = int(len(ks))
-        if m == 0:
-            return np.zeros((0, self.CH))
-        dev = self.band.device
-        d_k = torch.from_numpy(np.ascontiguousarray(ks, dtype=np.int32)).to(dev)
-        out = torch.empty((m, self.CH), dtype=torch.float64, device=dev)
-        _lib.check(lib.mst_gather_diagonals_band(_ptr(self.band), self.n, self.dpx, int(self.starts[b]), self.CH,
-                                                 _ptr(d_k), m, _ptr(out), _stream()))
-        return out.cpu().numpy()
+    def _features_launch(self, b, pix, half, m, cnt1, cnt2, cval):
+        _lib.check(self.engine.lib.mst_candidate_features_band(_ptr(self.band), self.n, self.dpx, int(self.starts[b]),
+                                                               self.CH, pix, half, m, cnt1, cnt2, cval, _stream()))
+
+    def _diagonals_launch(self, b, ks, m, out):
+        _lib.check(self.engine.lib.mst_gather_diagonals_band(_ptr(self.band), self.n, self.dpx, int(self.starts[b]),
+                                                             self.CH, ks, m, out, _stream()))
+
+    def _diag_means_launch(self, b, ks, m, out):
+        _lib.check(self.engine.lib.mst_diag_means_band(_ptr(self.band), self.n, self.dpx, int(self.starts[b]), self.CH,
+                                                       ks, m, out, _stream()))
 
 
 class ScaleSpaceEngine:

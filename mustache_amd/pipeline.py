@@ -14,7 +14,7 @@ from . import _lib
 from .engine import ScaleSpaceEngine, BlockBatch, BandBatch, _ptr, _stream
 from .normalize import band_from_coo, normalize_band
 from .sharding import shard_blocks, gather_loops, world
-from .tail import block_tail
+from .tail import batch_tail
 
 
 def block_tiling(n, distance_in_px):
@@ -76,9 +76,10 @@ class ChromosomePipeline:
                 batch = BandBatch(self.engine, band, n, dpx, starts_g, CH,
                                   nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
             t1 = time.time()
+            tails = batch_tail(batch, list(range(len(group))), starts_g, pt, st, intra=True)
             for j, i in enumerate(group):
                 mask = block_mask_size(i, start, end, dpx)
-                for lp in block_tail(batch, j, start[i], pt, st, intra=True):
+                for lp in tails[j]:
                     if lp[0] >= start[i] + mask or lp[1] >= start[i] + mask:      # mustache.py:957-959
                         loops.append([lp[0], lp[1], lp[2], lp[3]])
             t_dev += t1 - t0

@@ -205,3 +205,38 @@ def test_tiny_chromosomes_do_not_break_the_pipeline(n, dpx, res):
     exp = oracle.regulator_coo(x, y, v.copy(), res, dpx, OCT, 0.8, 0.2)
     got = sorted(ChromosomePipeline(OCT).run(x, y, v.copy(), res, dpx, 0.8, 0.2), key=lambda r: (int(r[0]), int(r[1])))
     assert [(int(a), int(b), s) for a, b, _, s in got] == [(int(a), int(b), s) for a, b, _, s in exp]
+
+
+def test_device_diagonal_means_equal_numpy_bitwise():
+    """mst_diag_means / mst_diag_means_band == np.mean(dg[dg != 0]) of the gathered diagonals, bit for bit (NumPy's
+    pairwise summation order is followed on the device), for both block sources; lengths from CH down to a handful,
+    the constant-2 diagonals, sparse diagonals and a diagonal without any non-zero entry (NaN, as np.mean)."""
+    import warnings
+    import torch
+    from mustache_amd.engine import BandBatch, BlockBatch
+    from mustache_amd.normalize import band_from_coo, normalize_band
+    from mustache_amd.pipeline import ChromosomePipeline, block_tiling
+    from mustache_amd.synth import synth_coo
+    n, dpx, res = 4300, 400, 5000
+    x, y, v = synth_coo(n, dpx, depth=3.0, seed=5)            # low depth: many zero entries on the far diagonals
+    keep = (y - x) != 37                                      # diagonal 37 carries no data at all
+    x, y, v = x[keep], y[keep], v[keep]
+    pipe = ChromosomePipeline(OCT)
+    dev = pipe.device
+    band = band_from_coo(*(torch.from_numpy(a).to(dev) for a in (x, y, v)), n, dpx)
+    band, _, _ = normalize_band(band, n, dpx, res)
+    CH, start, end = block_tiling(n, dpx)
+    c, nz, cnt = pipe.blocks_from_band(band, n, dpx, start, CH)
+    B = len(start)
+    dense = BlockBatch(pipe.engine, c, nz, CH, B, None, None, None)
+    direct = BandBatch(pipe.engine, band, n, dpx, start, CH, None, None, None)
+    ks = np.array([0, 3, 4, 5, 6, 7, 12, 37, 100, 129, 255, 399, 400, 401, 402, 1000, CH - 130, CH - 9, CH - 7, CH - 1])
+    for batch in (dense, direct):
+        got = batch.diagonal_means_multi(list(range(B)), [ks] * B)
+        for b in range(B):
+            dg_all = batch.diagonals(b, ks)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                want = np.array([np.mean(dg_all[i, :CH - k][dg_all[i, :CH - k] != 0]) for i, k in enumerate(ks)])
+            assert np.array_equal(got[b], want, equal_nan=True), (b, got[b], want)
+            assert np.isnan(want[list(ks).index(37)]) and want[0] == 2.0

@@ -1,0 +1,539 @@
+// libmustache_io.so -- native reader for Juicer `.hic` files (host only: g++ + zlib), see include/mustache_io.h.
+//
+// Replaces the hic-straw calls of reference mustache/mustache.py:300-396.  The file layout is restated from the
+// published format as implemented by straw (github.com/aidenlab/straw, straw.cpp); all integers little-endian:
+//   header  : "HIC\0", int32 version, int64 masterIndexPosition, genomeId\0, [v9: int64 nviPosition, int64 nviLength],
+//             int32 nAttributes {key\0 value\0}, int32 nChrs {name\0, v9 int64 / v8 int32 length},
+//             int32 nBpResolutions {int32}, int32 nFragResolutions {int32}
+//   footer  : (at masterIndexPosition) v9 int64 / v8 int32 nBytes, int32 nEntries {key\0 "c1_c2", int64 position,
+//             int32 size}; expected-value vectors; normalised expected-value vectors; then the normalisation-vector
+//             index: int32 nEntries {type\0, int32 chrIdx, unit\0, int32 binSize, int64 position, v9 int64 / v8 int32 size}
+//             (v9 files also give its position directly as nviPosition)
+//   matrix  : int32 c1, int32 c2, int32 nResolutions, per resolution: unit\0, int32 zoomIndex, 4 x float32 statistics,
+//             int32 binSize, int32 blockBinCount, int32 blockColumnCount, int32 nBlocks {int32 number, int64 position,
+//             int32 size}
+//   block   : zlib stream; int32 nRecords, int32 binXOffset, int32 binYOffset, byte useShort(0 = yes),
+//             [v9: byte useShortBinX(0 = yes), byte useShortBinY(0 = yes)], byte type;
+//             type 1 = list of rows {y, count {x, value}}, type 2 = dense w-wide grid with sentinels
+//             (v6: plain {int32 x, int32 y, float32 value} records)
+//   norm    : v9 int64 / v8 int32 nValues, then v9 float32 / v8 float64 values
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mustache_io.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+struct FormatError {
+    const char *what;
+};
+
+// bounds-checked little-endian cursor over a byte range
+struct Cursor {
+    const uint8_t *p, *end;
+    Cursor(const uint8_t *b, size_t n) : p(b), end(b + n) {}
+    void need(size_t n) const {
+        if ((size_t)(end - p) < n) throw FormatError{"truncated structure"};
+    }
+    template <class T>
+    T get() {
+        need(sizeof(T));
+        T v;
+        memcpy(&v, p, sizeof(T));
+        p += sizeof(T);
+        return v;
+    }
+    std::string str() {
+        const void *z = memchr(p, 0, (size_t)(end - p));
+        if (!z) throw FormatError{"unterminated string"};
+        std::string s((const char *)p, (const char *)z);
+        p = (const uint8_t *)z + 1;
+        return s;
+    }
+    void skip(uint64_t n) {
+        if ((uint64_t)(end - p) < n) throw FormatError{"truncated structure"};
+        p += n;
+    }
+};
+
+struct Chrom {
+    std::string name;
+    int64_t length;
+};
+struct BlockRef {
+    int32_t number;
+    int64_t pos;
+    int32_t size;
+};
+struct NormRef {
+    int64_t pos, size;
+};
+
+}  // namespace
+
+struct mst_hic {
+    int fd = -1;
+    const uint8_t *map = nullptr;
+    size_t size = 0;
+    int32_t version = 0;
+    int64_t master = 0, nvi_pos = 0, nvi_len = 0;
+    std::string genome;
+    std::vector<Chrom> chroms;
+    std::vector<int32_t> bp_res;
+    std::map<std::string, std::pair<int64_t, int32_t>> matrices;     // "c1_c2" -> (position, size)
+    size_t after_master = 0;                                          // file offset right behind the master index entries
+    bool norm_index_read = false;
+    std::map<std::string, NormRef> norm_index;                        // "TYPE|chrIdx|UNIT|binSize"
+
+    Cursor at(int64_t pos) const {
+        if (pos < 0 || (uint64_t)pos > size) throw FormatError{"file position outside the file"};
+        return Cursor(map + pos, size - (size_t)pos);
+    }
+};
+
+namespace {
+
+void parse_header(mst_hic *h) {
+    Cursor c = h->at(0);
+    if (c.str() != "HIC") throw FormatError{"missing HIC magic"};
+    h->version = c.get<int32_t>();
+    if (h->version < 6 || h->version > 9) throw FormatError{"unsupported .hic version (6-9 are handled)"};
+    h->master = c.get<int64_t>();
+    h->genome = c.str();
+    if (h->version > 8) {
+        h->nvi_pos = c.get<int64_t>();
+        h->nvi_len = c.get<int64_t>();
+    }
+    const int32_t n_attr = c.get<int32_t>();
+    if (n_attr < 0) throw FormatError{"negative attribute count"};
+    for (int32_t i = 0; i < n_attr; ++i) {
+        c.str();
+        c.str();
+    }
+    const int32_t n_chr = c.get<int32_t>();
+    if (n_chr < 0 || n_chr > 1000000) throw FormatError{"implausible chromosome count"};
+    for (int32_t i = 0; i < n_chr; ++i) {
+        Chrom ch;
+        ch.name = c.str();
+        ch.length = h->version > 8 ? c.get<int64_t>() : (int64_t)c.get<int32_t>();
+        h->chroms.push_back(ch);
+    }
+    const int32_t n_res = c.get<int32_t>();
+    if (n_res < 0 || n_res > 10000) throw FormatError{"implausible resolution count"};
+    for (int32_t i = 0; i < n_res; ++i) h->bp_res.push_back(c.get<int32_t>());
+    // fragment resolutions and restriction sites follow; nothing on this path needs them
+}
+
+void parse_master_index(mst_hic *h) {
+    Cursor c = h->at(h->master);
+    if (h->version > 8) c.get<int64_t>(); else c.get<int32_t>();          // nBytes
+    const int32_t n = c.get<int32_t>();
+    if (n < 0) throw FormatError{"negative master index size"};
+    for (int32_t i = 0; i < n; ++i) {
+        std::string key = c.str();
+        const int64_t pos = c.get<int64_t>();
+        const int32_t size = c.get<int32_t>();
+        h->matrices[key] = std::make_pair(pos, size);
+    }
+    h->after_master = (size_t)(c.p - h->map);
+}
+
+void skip_expected(mst_hic *h, Cursor &c, bool normalised) {
+    const int32_t n = c.get<int32_t>();
+    if (n < 0) throw FormatError{"negative expected-value count"};
+    for (int32_t i = 0; i < n; ++i) {
+        if (normalised) c.str();                                           // normalisation type
+        c.str();                                                           // unit
+        c.get<int32_t>();                                                  // bin size
+        const int64_t nv = h->version > 8 ? c.get<int64_t>() : (int64_t)c.get<int32_t>();
+        if (nv < 0) throw FormatError{"negative expected-value length"};
+        c.skip((uint64_t)nv * (h->version > 8 ? 4u : 8u));
+        const int32_t nf = c.get<int32_t>();
+        if (nf < 0) throw FormatError{"negative normalisation-factor count"};
+        c.skip((uint64_t)nf * (4u + (h->version > 8 ? 4u : 8u)));
+    }
+}
+
+std::string norm_key(const std::string &type, int32_t chr_idx, const std::string &unit, int32_t bin) {
+    return type + "|" + std::to_string(chr_idx) + "|" + unit + "|" + std::to_string(bin);
+}
+
+void read_norm_index(mst_hic *h) {
+    if (h->norm_index_read) return;
+    Cursor c = h->at(0);
+    if (h->version > 8 && h->nvi_pos > 0) {
+        c = h->at(h->nvi_pos);
+    } else {
+        c = h->at((int64_t)h->after_master);
+        skip_expected(h, c, false);
+        skip_expected(h, c, true);
+    }
+    const int32_t n = c.get<int32_t>();
+    if (n < 0) throw FormatError{"negative normalisation-vector count"};
+    for (int32_t i = 0; i < n; ++i) {
+        std::string type = c.str();
+        const int32_t chr_idx = c.get<int32_t>();
+        std::string unit = c.str();
+        const int32_t bin = c.get<int32_t>();
+        NormRef r;
+        r.pos = c.get<int64_t>();
+        r.size = h->version > 8 ? c.get<int64_t>() : (int64_t)c.get<int32_t>();
+        h->norm_index[norm_key(type, chr_idx, unit, bin)] = r;
+    }
+    h->norm_index_read = true;
+}
+
+std::vector<double> read_norm_vector(mst_hic *h, const NormRef &r) {
+    Cursor c = h->at(r.pos);
+    const int64_t n = h->version > 8 ? c.get<int64_t>() : (int64_t)c.get<int32_t>();
+    if (n < 0 || n > (int64_t)1 << 40) throw FormatError{"implausible normalisation-vector length"};
+    std::vector<double> v((size_t)n);
+    if (h->version > 8) {
+        for (int64_t i = 0; i < n; ++i) v[(size_t)i] = (double)c.get<float>();
+    } else {
+        for (int64_t i = 0; i < n; ++i) v[(size_t)i] = c.get<double>();
+    }
+    return v;
+}
+
+struct ZoomData {
+    int32_t bin_size = 0, block_bin_count = 0, block_column_count = 0;
+    std::vector<BlockRef> blocks;
+    bool found = false;
+};
+
+ZoomData read_zoom(mst_hic *h, int64_t matrix_pos, int32_t resolution) {
+    Cursor c = h->at(matrix_pos);
+    c.get<int32_t>();                                                     // c1
+    c.get<int32_t>();                                                     // c2
+    const int32_t n_res = c.get<int32_t>();
+    if (n_res < 0 || n_res > 10000) throw FormatError{"implausible zoom count"};
+    ZoomData z;
+    for (int32_t i = 0; i < n_res; ++i) {
+        const std::string unit = c.str();
+        c.get<int32_t>();                                                 // zoom index
+        c.skip(16);                                                       // sumCounts, occupiedCellCount, stdDev, percent95
+        const int32_t bin = c.get<int32_t>();
+        const int32_t bbc = c.get<int32_t>();
+        const int32_t bcc = c.get<int32_t>();
+        const int32_t nb = c.get<int32_t>();
+        if (nb < 0) throw FormatError{"negative block count"};
+        if (unit == "BP" && bin == resolution) {
+            z.bin_size = bin;
+            z.block_bin_count = bbc;
+            z.block_column_count = bcc;
+            z.blocks.resize((size_t)nb);
+            for (int32_t b = 0; b < nb; ++b) {
+                z.blocks[(size_t)b].number = c.get<int32_t>();
+                z.blocks[(size_t)b].pos = c.get<int64_t>();
+                z.blocks[(size_t)b].size = c.get<int32_t>();
+            }
+            z.found = true;
+            return z;
+        }
+        c.skip((uint64_t)nb * 16u);
+    }
+    return z;
+}
+
+// Can block `number` hold a record with |binX - binY| <= max_dist?  Errs on the side of reading the block.
+bool block_near_diagonal(int32_t version, int32_t number, int32_t bbc, int32_t bcc, int64_t max_dist) {
+    if (max_dist < 0 || bbc <= 0 || bcc <= 0) return true;
+    if (version > 8) {
+        // v9 intra-chromosomal blocks are indexed (depth, position along the diagonal):
+        //   depth = int(log2(1 + |binX - binY| / sqrt(2) / blockBinCount)),  number = depth * blockColumnCount + pad
+        const int64_t depth = number / bcc;
+        const int64_t far = (int64_t)std::log2(1.0 + (double)max_dist / std::sqrt(2.0) / (double)bbc) + 1;
+        return depth <= far;
+    }
+    const int64_t r = number / bcc, col = number % bcc;                    // number = row * blockColumnCount + column
+    const int64_t d = r > col ? r - col : col - r;
+    return d <= max_dist / bbc + 1;
+}
+
+struct Records {
+    std::vector<int64_t> x, y;
+    std::vector<double> v;
+};
+
+inline void emit(Records &out, int64_t bx, int64_t by, float counts, const std::vector<double> *norm, int64_t max_dist) {
+    if (bx > by) {                                                         // intra blocks store binX <= binY; be lenient
+        const int64_t t = bx;
+        bx = by;
+        by = t;
+    }
+    if (max_dist >= 0 && by - bx > max_dist) return;
+    float c = counts;
+    if (norm) {
+        if (bx < 0 || (size_t)by >= norm->size()) return;                  // straw would index out of range; drop
+        c = (float)((double)counts / ((*norm)[(size_t)bx] * (*norm)[(size_t)by]));
+    }
+    if (std::isnan(c) || !(c > 0.0f)) return;                              // mustache.py:370-373, :385-388
+    out.x.push_back(bx);
+    out.y.push_back(by);
+    out.v.push_back((double)c);
+}
+
+void decode_block(int32_t version, const uint8_t *comp, size_t comp_size, std::vector<uint8_t> &buf, Records &out,
+                  const std::vector<double> *norm, int64_t max_dist) {
+    // inflate (the uncompressed size is not stored: grow until it fits)
+    if (buf.size() < comp_size * 8 + 1024) buf.resize(comp_size * 8 + 1024);
+    size_t n_out = 0;
+    for (;;) {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit(&zs) != Z_OK) throw FormatError{"zlib init failed"};
+        zs.next_in = const_cast<Bytef *>(comp);
+        zs.avail_in = (uInt)comp_size;
+        zs.next_out = buf.data();
+        zs.avail_out = (uInt)buf.size();
+        const int rc = inflate(&zs, Z_FINISH);
+        n_out = zs.total_out;
+        inflateEnd(&zs);
+        if (rc == Z_STREAM_END) break;
+        if ((rc == Z_BUF_ERROR || rc == Z_OK) && buf.size() < ((size_t)1 << 31)) {
+            buf.resize(buf.size() * 2);
+            continue;
+        }
+        throw FormatError{"zlib inflate failed"};
+    }
+    Cursor c(buf.data(), n_out);
+    const int32_t n_rec = c.get<int32_t>();
+    if (n_rec < 0) throw FormatError{"negative record count in a block"};
+    const size_t room = (size_t)n_rec < n_out ? (size_t)n_rec : n_out;      // a record takes at least one byte
+    out.x.reserve(room);
+    out.y.reserve(room);
+    out.v.reserve(room);
+    if (version < 7) {
+        for (int32_t i = 0; i < n_rec; ++i) {
+            const int32_t bx = c.get<int32_t>();
+            const int32_t by = c.get<int32_t>();
+            const float v = c.get<float>();
+            emit(out, bx, by, v, norm, max_dist);
+        }
+        return;
+    }
+    const int32_t x_off = c.get<int32_t>();
+    const int32_t y_off = c.get<int32_t>();
+    const bool short_counts = c.get<uint8_t>() == 0;                      // 0 means "yes" in this format
+    bool short_x = true, short_y = true;
+    if (version > 8) {
+        short_x = c.get<uint8_t>() == 0;
+        short_y = c.get<uint8_t>() == 0;
+    }
+    const uint8_t type = c.get<uint8_t>();
+    if (type == 1) {
+        const int32_t rows = short_y ? (int32_t)c.get<int16_t>() : c.get<int32_t>();
+        for (int32_t r = 0; r < rows; ++r) {
+            const int32_t y = short_y ? (int32_t)c.get<int16_t>() : c.get<int32_t>();
+            const int32_t cols = short_x ? (int32_t)c.get<int16_t>() : c.get<int32_t>();
+            for (int32_t j = 0; j < cols; ++j) {
+                const int32_t x = short_x ? (int32_t)c.get<int16_t>() : c.get<int32_t>();
+                const float v = short_counts ? (float)c.get<int16_t>() : c.get<float>();
+                emit(out, (int64_t)x_off + x, (int64_t)y_off + y, v, norm, max_dist);
+            }
+        }
+    } else if (type == 2) {
+        const int32_t n_pts = c.get<int32_t>();
+        const int32_t w = (int32_t)c.get<int16_t>();
+        if (w <= 0) throw FormatError{"dense block of width 0"};
+        for (int32_t i = 0; i < n_pts; ++i) {
+            const int32_t row = i / w, col = i - row * w;
+            if (short_counts) {
+                const int16_t s = c.get<int16_t>();
+                if (s != -32768) emit(out, (int64_t)x_off + col, (int64_t)y_off + row, (float)s, norm, max_dist);
+            } else {
+                const float v = c.get<float>();
+                if (!std::isnan(v)) emit(out, (int64_t)x_off + col, (int64_t)y_off + row, v, norm, max_dist);
+            }
+        }
+    } else {
+        throw FormatError{"unknown block type"};
+    }
+}
+
+int find_chromosome(const mst_hic *h, const char *name) {
+    const std::string want(name);
+    const std::string bare = want.rfind("chr", 0) == 0 ? want.substr(3) : want;
+    for (int pass = 0; pass < 2; ++pass)
+        for (size_t i = 0; i < h->chroms.size(); ++i) {
+            const std::string &n = h->chroms[i].name;
+            if (pass == 0 ? n == want : (n == bare || n == "chr" + bare)) return (int)i;
+        }
+    return -1;
+}
+
+}  // namespace
+
+extern "C" int mst_io_abi_version(void) { return MST_IO_ABI_VERSION; }
+extern "C" const char *mst_io_last_error(void) { return g_err; }
+extern "C" void mst_io_free(void *p) { free(p); }
+
+extern "C" int mst_hic_open(const char *path, mst_hic **out) {
+    if (!path || !out) return fail(MST_IO_E_ARG, "mst_hic_open: null argument");
+    *out = nullptr;
+    mst_hic *h = new (std::nothrow) mst_hic();
+    if (!h) return fail(MST_IO_E_FILE, "out of memory");
+    h->fd = open(path, O_RDONLY);
+    struct stat st;
+    if (h->fd < 0 || fstat(h->fd, &st) != 0 || st.st_size <= 0) {
+        mst_hic_close(h);
+        return fail(MST_IO_E_FILE, "cannot open %s", path);
+    }
+    h->size = (size_t)st.st_size;
+    void *m = mmap(nullptr, h->size, PROT_READ, MAP_PRIVATE, h->fd, 0);
+    if (m == MAP_FAILED) {
+        mst_hic_close(h);
+        return fail(MST_IO_E_FILE, "cannot map %s", path);
+    }
+    h->map = (const uint8_t *)m;
+    try {
+        parse_header(h);
+        parse_master_index(h);
+    } catch (const FormatError &e) {
+        mst_hic_close(h);
+        return fail(MST_IO_E_FORMAT, "%s: %s", path, e.what);
+    } catch (...) {
+        mst_hic_close(h);
+        return fail(MST_IO_E_FORMAT, "%s: unreadable", path);
+    }
+    *out = h;
+    return MST_IO_OK;
+}
+
+extern "C" void mst_hic_close(mst_hic *h) {
+    if (!h) return;
+    if (h->map) munmap((void *)h->map, h->size);
+    if (h->fd >= 0) close(h->fd);
+    delete h;
+}
+
+extern "C" int32_t mst_hic_version(const mst_hic *h) { return h ? h->version : 0; }
+extern "C" int32_t mst_hic_n_chromosomes(const mst_hic *h) { return h ? (int32_t)h->chroms.size() : 0; }
+extern "C" int mst_hic_chromosome(const mst_hic *h, int32_t i, const char **name, int64_t *length) {
+    if (!h || i < 0 || (size_t)i >= h->chroms.size()) return fail(MST_IO_E_ARG, "mst_hic_chromosome: bad index");
+    if (name) *name = h->chroms[(size_t)i].name.c_str();
+    if (length) *length = h->chroms[(size_t)i].length;
+    return MST_IO_OK;
+}
+extern "C" int32_t mst_hic_n_resolutions(const mst_hic *h) { return h ? (int32_t)h->bp_res.size() : 0; }
+extern "C" int32_t mst_hic_resolution(const mst_hic *h, int32_t i) {
+    return (h && i >= 0 && (size_t)i < h->bp_res.size()) ? h->bp_res[(size_t)i] : 0;
+}
+
+extern "C" int64_t mst_hic_read_intra(mst_hic *h, const char *chrom, int32_t resolution, const char *norm,
+                                      int64_t max_dist_bins, int32_t n_threads, int64_t **x, int64_t **y, double **v) {
+    if (!h || !chrom || !x || !y || !v || resolution <= 0) return fail(MST_IO_E_ARG, "mst_hic_read_intra: bad argument");
+    *x = *y = nullptr;
+    *v = nullptr;
+    try {
+        const int ci = find_chromosome(h, chrom);
+        if (ci < 0) return fail(MST_IO_E_NOTFOUND, "chromosome %s is not in the file", chrom);
+        const std::string key = std::to_string(ci) + "_" + std::to_string(ci);
+        auto it = h->matrices.find(key);
+        if (it == h->matrices.end()) return fail(MST_IO_E_NOTFOUND, "no intra-chromosomal matrix for %s", chrom);
+        ZoomData z = read_zoom(h, it->second.first, resolution);
+        if (!z.found) return fail(MST_IO_E_NOTFOUND, "resolution %d is not in the file", resolution);
+
+        std::vector<double> norm_vec;
+        const bool use_norm = norm && *norm && strcmp(norm, "NONE") != 0;
+        if (use_norm) {
+            read_norm_index(h);
+            auto nit = h->norm_index.find(norm_key(norm, ci, "BP", resolution));
+            if (nit == h->norm_index.end())
+                return fail(MST_IO_E_NOTFOUND, "no %s normalisation vector for %s at %d bp", norm, chrom, resolution);
+            norm_vec = read_norm_vector(h, nit->second);
+        }
+
+        std::vector<const BlockRef *> todo;
+        for (const BlockRef &b : z.blocks) {
+            if (b.size <= 0) continue;
+            if (b.pos < 0 || (uint64_t)b.pos + (uint64_t)b.size > h->size) throw FormatError{"block outside the file"};
+            if (block_near_diagonal(h->version, b.number, z.block_bin_count, z.block_column_count, max_dist_bins))
+                todo.push_back(&b);
+        }
+        int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+        if (nt < 1) nt = 1;
+        if ((size_t)nt > todo.size()) nt = todo.empty() ? 1 : (int)todo.size();
+        std::vector<Records> part(todo.size());
+        std::atomic<size_t> next(0);
+        std::atomic<int> bad(0);
+        const char *bad_what = nullptr;
+        auto work = [&]() {
+            std::vector<uint8_t> buf;
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= todo.size() || bad.load()) return;
+                try {
+                    decode_block(h->version, h->map + todo[i]->pos, (size_t)todo[i]->size, buf, part[i],
+                                 use_norm ? &norm_vec : nullptr, max_dist_bins);
+                } catch (const FormatError &e) {
+                    bad_what = e.what;
+                    bad.store(1);
+                    return;
+                } catch (...) {
+                    bad_what = "out of memory";
+                    bad.store(1);
+                    return;
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        if (bad.load()) return fail(MST_IO_E_ZLIB, "block decode failed: %s", bad_what ? bad_what : "?");
+
+        size_t total = 0;
+        for (const Records &r : part) total += r.v.size();
+        int64_t *ox = (int64_t *)malloc((total ? total : 1) * sizeof(int64_t));
+        int64_t *oy = (int64_t *)malloc((total ? total : 1) * sizeof(int64_t));
+        double *ov = (double *)malloc((total ? total : 1) * sizeof(double));
+        if (!ox || !oy || !ov) {
+            free(ox);
+            free(oy);
+            free(ov);
+            return fail(MST_IO_E_FILE, "out of memory for %zu records", total);
+        }
+        size_t off = 0;
+        for (const Records &r : part) {
+            if (r.v.empty()) continue;
+            memcpy(ox + off, r.x.data(), r.v.size() * sizeof(int64_t));
+            memcpy(oy + off, r.y.data(), r.v.size() * sizeof(int64_t));
+            memcpy(ov + off, r.v.data(), r.v.size() * sizeof(double));
+            off += r.v.size();
+        }
+        *x = ox;
+        *y = oy;
+        *v = ov;
+        return (int64_t)total;
+    } catch (const FormatError &e) {
+        return fail(MST_IO_E_FORMAT, "%s", e.what);
+    } catch (...) {
+        return fail(MST_IO_E_FORMAT, "unreadable file (out of memory?)");
+    }
+}

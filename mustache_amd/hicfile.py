@@ -1,0 +1,113 @@
+"""ctypes binding of libmustache_io.so (include/mustache_io.h): the native `.hic` reader.
+
+Host-only (g++ + zlib): it loads without a GPU.  `HicFile` mirrors the two things the reference asks of hic-straw in
+read_hic_file() (reference mustache/mustache.py:308-312, :328-333): the chromosome table and the observed, normalised
+intra-chromosomal records near the diagonal.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+class HicError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmustache_io error %d: %s" % (code, msg))
+        self.code = code
+
+
+_P = ctypes.c_void_p
+_SIGNATURES = {
+    "mst_io_abi_version": (ctypes.c_int, []),
+    "mst_io_last_error": (ctypes.c_char_p, []),
+    "mst_io_free": (None, [_P]),
+    "mst_hic_open": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_P)]),
+    "mst_hic_close": (None, [_P]),
+    "mst_hic_version": (ctypes.c_int32, [_P]),
+    "mst_hic_n_chromosomes": (ctypes.c_int32, [_P]),
+    "mst_hic_chromosome": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p),
+                                          ctypes.POINTER(ctypes.c_int64)]),
+    "mst_hic_n_resolutions": (ctypes.c_int32, [_P]),
+    "mst_hic_resolution": (ctypes.c_int32, [_P, ctypes.c_int32]),
+    "mst_hic_read_intra": (ctypes.c_int64, [_P, ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64,
+                                            ctypes.c_int32, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_P)]),
+}
+
+
+def load():
+    """Load libmustache_io.so once; raise if it has not been built (`make -C mustache_amd/csrc`)."""
+    global _lib
+    if _lib is None:
+        path = os.environ.get("MUSTACHE_IO_LIB") or os.path.join(_HERE, "libmustache_io.so")
+        if not os.path.exists(path):
+            raise RuntimeError("libmustache_io.so is missing (%s): build it with `make -C mustache_amd/csrc`" % path)
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _check(lib, rc):
+    if rc < 0:
+        raise HicError(int(rc), lib.mst_io_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+class HicFile:
+    def __init__(self, path):
+        self._lib = load()
+        self._h = _P()
+        _check(self._lib, self._lib.mst_hic_open(os.fsencode(path), ctypes.byref(self._h)))
+        self.path = path
+
+    def close(self):
+        if self._h:
+            self._lib.mst_hic_close(self._h)
+            self._h = _P()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def version(self):
+        return int(self._lib.mst_hic_version(self._h))
+
+    def chromosomes(self):
+        """[(name, length)] in file order; entry 0 is usually the pseudo-chromosome "All"."""
+        out = []
+        for i in range(self._lib.mst_hic_n_chromosomes(self._h)):
+            name, length = ctypes.c_char_p(), ctypes.c_int64()
+            _check(self._lib, self._lib.mst_hic_chromosome(self._h, i, ctypes.byref(name), ctypes.byref(length)))
+            out.append((name.value.decode(), int(length.value)))
+        return out
+
+    def resolutions(self):
+        return [int(self._lib.mst_hic_resolution(self._h, i)) for i in range(self._lib.mst_hic_n_resolutions(self._h))]
+
+    def read_intra(self, chrom, resolution, norm="KR", max_dist_bins=-1, threads=0):
+        """(x, y, v): bin indices (x <= y, int64) and normalised observed values (float64 holding straw's float32) of the
+        records with y - x <= max_dist_bins, value > 0, not NaN."""
+        px, py, pv = _P(), _P(), _P()
+        n = _check(self._lib, self._lib.mst_hic_read_intra(self._h, str(chrom).encode(), int(resolution),
+                                                           str(norm).encode(), int(max_dist_bins), int(threads),
+                                                           ctypes.byref(px), ctypes.byref(py), ctypes.byref(pv)))
+        try:
+            if n == 0:
+                return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float64)
+            x = np.ctypeslib.as_array(ctypes.cast(px, ctypes.POINTER(ctypes.c_int64)), shape=(n,)).copy()
+            y = np.ctypeslib.as_array(ctypes.cast(py, ctypes.POINTER(ctypes.c_int64)), shape=(n,)).copy()
+            v = np.ctypeslib.as_array(ctypes.cast(pv, ctypes.POINTER(ctypes.c_double)), shape=(n,)).copy()
+        finally:
+            for p in (px, py, pv):
+                self._lib.mst_io_free(p)
+        return x, y, v

@@ -1,7 +1,9 @@
-"""Binary contact-map readers: `.hic` (hic-straw), `.cool` / `.mcool` (cooler) -> upper-triangular COO in bin units.
+"""Binary contact-map readers: `.hic` (native reader, or hic-straw), `.cool` / `.mcool` (cooler) -> upper-triangular COO
+in bin units.
 
-Host I/O, not part of the GPU hot path.  The third-party modules are imported lazily --
-they are optional and absent from the offline build image; a missing module raises an ImportError that names it.
+Host I/O, not part of the GPU hot path.  `.hic` files are read by libmustache_io.so
+(include/mustache_io.h) by default; the third-party modules (hic-straw as an optional cross-check backend, cooler) are
+imported lazily -- they are absent from the offline build image; a missing module raises an ImportError that names it.
 Semantics follow reference mustache/mustache.py:300-396 (read_hic_file), :399-493 (read_cooler), :496-592
 (read_mcooler): the chromosome is fetched in overlapping windows of max(2*dist/res, 2000) bins advancing by window - dist,
 records seen in several windows are kept once, and intra-chromosomal output keeps |x - y| <= dist/res with value > 0.
@@ -10,6 +12,7 @@ the (x, y) key with NumPy (same set of records; the reference's output order is 
 reproduced -- nothing downstream depends on it here).
 """
 import importlib
+import os
 
 import numpy as np
 
@@ -63,15 +66,41 @@ def _dedup(xs, ys, vs):
     return x[first], y[first], v[first]
 
 
+def hic_backend():
+    """"native" (default: libmustache_io.so, no third-party module) or "hicstraw" (MUSTACHE_HIC_BACKEND=hicstraw: the
+    reference's own dependency, kept for cross-checking the native reader wherever hic-straw is installed)."""
+    b = os.environ.get("MUSTACHE_HIC_BACKEND", "native").lower()
+    if b not in ("native", "hicstraw"):
+        raise ValueError("MUSTACHE_HIC_BACKEND must be 'native' or 'hicstraw'")
+    return b
+
+
+def _hic_chromosomes(f):
+    """[(name, length)] without the leading pseudo-chromosome (mustache.py:308-312 skips index 0)."""
+    if hic_backend() == "hicstraw":
+        return [(str(c.name), c.length) for c in _need("hicstraw").HiCFile(f).getChromosomes()[1:]]
+    from .hicfile import HicFile
+    with HicFile(f) as h:
+        return h.chromosomes()[1:]
+
+
 def read_hic_file(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, chr2, res):
-    hicstraw = _need("hicstraw")
     if not CHRM_SIZE:
-        sizes = {"chr" + str(c.name).replace("chr", ''): c.length for c in hicstraw.HiCFile(f).getChromosomes()[1:]}
+        sizes = {"chr" + name.replace("chr", ''): length for name, length in _hic_chromosomes(f)}
         key = "chr" + str(chr1).replace("chr", '')
         if key not in sizes:
             raise NameError('wrong chromosome name!')
         CHRM_SIZE = sizes[key]
     norm = "KR" if not norm_method else str(norm_method)          # (:328-333)
+    if hic_backend() == "native" and chr1 == chr2:
+        # one pass over the zlib blocks near the diagonal: the union of the reference's overlapping straw windows is every
+        # record with |x - y| <= dist/res (consecutive windows overlap by exactly `dist`), already de-duplicated
+        from .hicfile import HicFile
+        with HicFile(f) as h:
+            x, y, v = h.read_intra(chr1, res, norm, int(distance_in_bp // res))
+        keep = (x * res < CHRM_SIZE) & (y * res < CHRM_SIZE)      # straw never returns positions past the window end
+        return _finish(x[keep], y[keep], v[keep], distance_in_bp, res, True, chr1)
+    hicstraw = _need("hicstraw")
     xs, ys, vs = [], [], []
     for start, end in window_ranges(CHRM_SIZE, distance_in_bp, res):
         recs = hicstraw.straw("observed", norm, f, "%s:%d:%d" % (chr1, start, end), "%s:%d:%d" % (chr2, start, end),
@@ -136,8 +165,7 @@ def read_mcooler(f, distance_in_bp, chr1, chr2, res, cooler_balance):
 def list_chromosomes(f, res):
     """Chromosomes main() iterates when -ch is omitted (mustache.py:1019-1036)."""
     if f.endswith(".hic"):
-        hicstraw = _need("hicstraw")
-        return [c.name for c in hicstraw.HiCFile(f).getChromosomes()[1:]]
+        return [name for name, _ in _hic_chromosomes(f)]
     cooler = _need("cooler")
     clr = cooler.Cooler(f if f.endswith(".cool") else '%s::/resolutions/%s' % (f, res))
     return [name for i, name in enumerate(clr.chromnames) if clr.chromsizes[i] > 1000000]

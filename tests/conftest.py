@@ -16,9 +16,9 @@ def pytest_configure(config):
 
 
 def _ensure_library():
-    """The HIP library is git-ignored (built artefact); build it on first use so a fresh checkout can run the suite."""
-    lib = os.path.join(ROOT, "mustache_amd", "libmustache_hip.so")
-    if not os.path.exists(lib):
+    """The libraries are git-ignored (built artefacts); build them on first use so a fresh checkout can run the suite."""
+    libs = [os.path.join(ROOT, "mustache_amd", n) for n in ("libmustache_hip.so", "libmustache_io.so")]
+    if not all(os.path.exists(lib) for lib in libs):
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "mustache_amd", "csrc"), "-j4"])
 

@@ -1,0 +1,144 @@
+"""Native `.hic` reader (libmustache_io.so, include/mustache_io.h) against files written by tests/hic_writer.py -- an
+independent writer of the published layout (no `.hic` file and no hic-straw exist offline, so parity with hic-straw on a
+real file is unpinned; the hic-straw backend of mustache_amd.readers stays available for that cross-check)."""
+import ctypes
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from hic_writer import write_hic     # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _contacts(n, spread, m, seed, integer=True):
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, n, m)
+    y = np.minimum(x + rng.integers(0, spread, m), n - 1)
+    key = np.unique(x * 1000003 + y)
+    x, y = key // 1000003, key % 1000003
+    c = rng.integers(1, 900, len(x)).astype(np.float64) if integer else rng.uniform(0.25, 40, len(x)).astype(np.float32).astype(np.float64)
+    return x, y, c
+
+
+def _sorted(x, y, v):
+    o = np.lexsort((y, x))
+    return x[o], y[o], v[o]
+
+
+def test_io_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(os.path.join(ROOT, "mustache_amd", "libmustache_io.so"))
+    header = open(os.path.join(ROOT, "include", "mustache_io.h")).read()
+    names = set(re.findall(r"\b(mst_(?:io|hic)_\w+)\s*\(", header))
+    assert len(names) == 11
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.mst_io_abi_version() == 1
+
+
+@pytest.mark.parametrize("version,float_counts,dense,short_coords,bbc", [
+    (8, False, False, True, 64), (8, True, False, True, 37), (8, False, True, True, 16), (8, True, True, True, 16),
+    (9, False, False, True, 64), (9, True, False, False, 50), (9, True, False, True, 23)])
+def test_round_trip_all_block_encodings(tmp_path, version, float_counts, dense, short_coords, bbc):
+    from mustache_amd.hicfile import HicFile
+    n, res = 1500, 5000
+    x, y, c = _contacts(n, 400, 30000, version * 10 + bbc, integer=not float_counts)
+    rng = np.random.default_rng(3)
+    norm = rng.uniform(0.4, 2.5, n + 1)
+    norm[[5, 77]] = np.nan                               # bins without a normalisation factor -> records dropped
+    p = str(tmp_path / "a.hic")
+    write_hic(p, [("All", 7500), ("chr1", n * res), ("chrX", 12345)],
+              {1: {res: (x, y, c), 25000: (x[:50] // 5, np.maximum(y[:50] // 5, x[:50] // 5), c[:50])}},
+              {("KR", 1, res): norm, ("VC", 1, res): np.ones(n + 1)}, version=version, block_bin_count=bbc,
+              float_counts=float_counts, dense_blocks=dense, short_coords=short_coords)
+    with HicFile(p) as h:
+        assert h.version == version
+        assert h.chromosomes() == [("All", 7500), ("chr1", n * res), ("chrX", 12345)]
+        assert h.resolutions() == [25000, 5000]
+        nv = norm.astype(np.float32).astype(np.float64) if version == 9 else norm      # v9 stores float32 vectors
+        for name in ("chr1", "1"):                       # with or without the prefix, as users type it
+            for norm_name, want in (("NONE", c.astype(np.float32)), ("VC", c.astype(np.float32)),
+                                    ("KR", (c.astype(np.float32).astype(np.float64) / (nv[x] * nv[y])).astype(np.float32))):
+                for md in (-1, 0, 3, 150, 399, 10000):
+                    ok = ~np.isnan(want) & (want > 0) & ((y - x <= md) if md >= 0 else True)
+                    gx, gy, gv = _sorted(*h.read_intra(name, res, norm_name, md, threads=3))
+                    ex, ey, ev = _sorted(x[ok], y[ok], want[ok].astype(np.float64))
+                    assert np.array_equal(gx, ex) and np.array_equal(gy, ey) and np.array_equal(gv, ev), (norm_name, md)
+
+
+def test_error_codes(tmp_path):
+    from mustache_amd.hicfile import HicFile, HicError
+    p = str(tmp_path / "a.hic")
+    x, y, c = _contacts(300, 50, 2000, 1)
+    write_hic(p, [("All", 1), ("chr2", 300 * 1000)], {1: {1000: (x, y, c)}}, {("KR", 1, 1000): np.ones(301)})
+    with HicFile(p) as h:
+        for args, code in ((("chr9", 1000, "KR"), -4), (("chr2", 5000, "KR"), -4), (("chr2", 1000, "SCALE"), -4)):
+            with pytest.raises(HicError) as e:
+                h.read_intra(*args)
+            assert e.value.code == code
+    bad = str(tmp_path / "bad.hic")
+    open(bad, "wb").write(b"HDF\0" + bytes(100))
+    with pytest.raises(HicError) as e:
+        HicFile(bad)
+    assert e.value.code == -3
+    raw = open(p, "rb").read()
+    open(bad, "wb").write(raw[:len(raw) // 2])           # truncated: the master index lies outside the file
+    with pytest.raises(HicError) as e:
+        HicFile(bad)
+    assert e.value.code == -3
+    with pytest.raises(HicError) as e:
+        HicFile(str(tmp_path / "missing.hic"))
+    assert e.value.code == -2
+    # a corrupted zlib stream is reported, not crashed on
+    blk = bytearray(raw)
+    start = raw.index(b"\x78\x9c")                       # first zlib header
+    blk[start + 8:start + 24] = bytes(16)
+    open(bad, "wb").write(bytes(blk))
+    with HicFile(bad) as h:
+        with pytest.raises(HicError) as e:
+            h.read_intra("chr2", 1000, "NONE")
+        assert e.value.code in (-5, -3)
+
+
+def test_read_hic_file_native_equals_straw_backend(tmp_path, monkeypatch):
+    """mustache_amd.readers.read_hic_file through the native reader == through the hic-straw code path (served by an
+    in-memory stand-in that answers straw() window queries from the same contacts): same records, each once."""
+    from mustache_amd.readers import read_hic_file, list_chromosomes
+    n, res, dist = 5200, 5000, 2_000_000
+    x, y, c = _contacts(n, 460, 60000, 9)
+    norm = np.random.default_rng(4).uniform(0.5, 2.0, n + 1)
+    norm[100:110] = np.nan
+    p = str(tmp_path / "a.hic")
+    write_hic(p, [("All", 1), ("chr7", n * res), ("chr8", 999)], {1: {res: (x, y, c)}}, {("KR", 1, res): norm},
+              version=8, block_bin_count=128)
+    val = (c.astype(np.float32).astype(np.float64) / (norm[x] * norm[y])).astype(np.float32).astype(np.float64)
+
+    def straw(kind, nm, f, loc1, loc2, unit, r):
+        _, s, e = loc1.split(":")
+        s, e = int(s), int(e)
+        sel = (x * res >= s) & (x * res <= e) & (y * res >= s) & (y * res <= e)
+        return [types.SimpleNamespace(binX=int(a * res), binY=int(b * res), counts=float(v))
+                for a, b, v in zip(x[sel], y[sel], val[sel])]
+
+    fake = types.ModuleType("hicstraw")
+    fake.straw = straw
+    fake.HiCFile = lambda f: types.SimpleNamespace(getChromosomes=lambda: [
+        types.SimpleNamespace(name="All", length=1), types.SimpleNamespace(name="chr7", length=n * res),
+        types.SimpleNamespace(name="chr8", length=999)])
+    monkeypatch.setitem(sys.modules, "hicstraw", fake)
+    out = {}
+    for backend in ("native", "hicstraw"):
+        monkeypatch.setenv("MUSTACHE_HIC_BACKEND", backend)
+        assert list_chromosomes(p, res) == ["chr7", "chr8"]
+        out[backend] = _sorted(*read_hic_file(p, False, False, dist, "chr7", "chr7", res))
+    for a, b in zip(out["native"], out["hicstraw"]):
+        assert np.array_equal(a, b)
+    assert len(out["native"][0]) > 20000
+    monkeypatch.setenv("MUSTACHE_HIC_BACKEND", "native")
+    with pytest.raises(NameError):
+        read_hic_file(p, False, False, dist, "chr9", "chr9", res)

@@ -47,6 +47,7 @@ def test_read_hic_with_fake_straw(monkeypatch):
     fake.straw = straw
     fake.HiCFile = lambda f: types.SimpleNamespace(getChromosomes=lambda: chrom)
     monkeypatch.setitem(sys.modules, "hicstraw", fake)
+    monkeypatch.setenv("MUSTACHE_HIC_BACKEND", "hicstraw")
     from mustache_amd.readers import read_hic_file, list_chromosomes
     x, y, v = read_hic_file("x.hic", False, False, dist, "7", "7", res)
     assert calls[0][0] == "KR" and len(calls) > 3
@@ -90,6 +91,7 @@ def test_read_cooler_with_fake_cooler(monkeypatch):
 
 def test_missing_optional_module_is_named(monkeypatch):
     monkeypatch.setitem(sys.modules, "hicstraw", None)
+    monkeypatch.setenv("MUSTACHE_HIC_BACKEND", "hicstraw")
     from mustache_amd.readers import read_hic_file
     with pytest.raises(ImportError, match="hicstraw"):
         read_hic_file("x.hic", False, 1000, 2_000_000, "1", "1", 5000)

@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-procs", type=int, default=0,
+                    help="extra CPU leg: this many blocks in as many worker processes at once (SURVEY 8d (c): one process "
+                         "per physical core); off by default, it adds ~20 s")
     ap.add_argument("--small", action="store_true", help="debug: 12 blocks instead of 124")
     return ap.parse_args()
 
@@ -269,6 +272,13 @@ def main():
                                   "kind": "port", "sample": "4 blocks of the same workload in 4 worker processes (the "
                                   "reference's default -p 4), wall %.1f s incl. process start-up" % wall4}
         out["speedup_vs_cpu_p4"] = round(value / out["cpu_baseline_p4"]["value"], 1)
+        if args.cpu_procs > 0:
+            P = min(args.cpu_procs, len(w.start))
+            wallp, _ = cpu_baseline_p4(w, [(bi + j) % len(w.start) for j in range(P)])
+            out["cpu_baseline_node"] = {"value": round(P * w.CH * w.CH / 1e6 / wallp, 3), "unit": "Mpix/s", "cores": P,
+                                        "kind": "port", "sample": "%d blocks of the same workload in %d worker processes "
+                                        "at once, wall %.1f s incl. process start-up" % (P, P, wallp)}
+            out["speedup_vs_cpu_node"] = round(value / out["cpu_baseline_node"]["value"], 1)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

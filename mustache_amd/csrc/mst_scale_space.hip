@@ -541,7 +541,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
     double *vdst = vb + (v_rgp * K) * T::VP + v_col;
     const double *hsrc = vb + rr * T::VP + cg * K;
 
-    const int n_oct = lv->n_octaves, lpo = lv->levels_per_octave;
+    const int n_oct = (variant & 4) ? 0 : lv->n_octaves, lpo = lv->levels_per_octave;   // [timing ablation 4: staging + epilogue only]
     const int prot = (int)(blockIdx.x >> 3) * 2 + (int)(blockIdx.x >> 11);
     int tested = 0;
     for (int o = 0; o < n_oct; ++o) {

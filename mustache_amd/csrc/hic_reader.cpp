@@ -508,8 +508,9 @@ extern "C" int64_t mst_hic_read_intra(mst_hic *h, const char *chrom, int32_t res
         for (auto &t : pool) t.join();
         if (bad.load()) return fail(MST_IO_E_ZLIB, "block decode failed: %s", bad_what ? bad_what : "?");
 
-        size_t total = 0;
-        for (const Records &r : part) total += r.v.size();
+        std::vector<size_t> offs(part.size() + 1, 0);
+        for (size_t i = 0; i < part.size(); ++i) offs[i + 1] = offs[i] + part[i].v.size();
+        const size_t total = offs[part.size()];
         int64_t *ox = (int64_t *)malloc((total ? total : 1) * sizeof(int64_t));
         int64_t *oy = (int64_t *)malloc((total ? total : 1) * sizeof(int64_t));
         double *ov = (double *)malloc((total ? total : 1) * sizeof(double));
@@ -519,14 +520,26 @@ extern "C" int64_t mst_hic_read_intra(mst_hic *h, const char *chrom, int32_t res
             free(ov);
             return fail(MST_IO_E_FILE, "out of memory for %zu records", total);
         }
-        size_t off = 0;
-        for (const Records &r : part) {
-            if (r.v.empty()) continue;
-            memcpy(ox + off, r.x.data(), r.v.size() * sizeof(int64_t));
-            memcpy(oy + off, r.y.data(), r.v.size() * sizeof(int64_t));
-            memcpy(ov + off, r.v.data(), r.v.size() * sizeof(double));
-            off += r.v.size();
-        }
+        // concatenate in file block order (deterministic), the copies spread over the same worker threads
+        next.store(0);
+        auto gather = [&]() {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= part.size()) return;
+                Records &r = part[i];
+                if (r.v.empty()) continue;
+                memcpy(ox + offs[i], r.x.data(), r.v.size() * sizeof(int64_t));
+                memcpy(oy + offs[i], r.y.data(), r.v.size() * sizeof(int64_t));
+                memcpy(ov + offs[i], r.v.data(), r.v.size() * sizeof(double));
+                std::vector<int64_t>().swap(r.x);                      // release the block's buffers as we go
+                std::vector<int64_t>().swap(r.y);
+                std::vector<double>().swap(r.v);
+            }
+        };
+        pool.clear();
+        for (int t = 1; t < nt; ++t) pool.emplace_back(gather);
+        gather();
+        for (auto &t : pool) t.join();
         *x = ox;
         *y = oy;
         *v = ov;

@@ -98,8 +98,15 @@ def read_hic_file(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, chr2, res):
         from .hicfile import HicFile
         with HicFile(f) as h:
             x, y, v = h.read_intra(chr1, res, norm, int(distance_in_bp // res))
-        keep = (x * res < CHRM_SIZE) & (y * res < CHRM_SIZE)      # straw never returns positions past the window end
-        return _finish(x[keep], y[keep], v[keep], distance_in_bp, res, True, chr1)
+        # NaN rows, value > 0 and the distance filter (mustache.py:370-388) are already applied by the reader; what is left
+        # is straw's window end: no position past the chromosome size the caller gave
+        if len(v) and int(y.max()) * res >= CHRM_SIZE:
+            keep = y * res < CHRM_SIZE                                # x <= y
+            x, y, v = x[keep], y[keep], v[keep]
+        if len(v) == 0:
+            print(f'There is no contact in chrmosome {chr1} to work on.')
+            return [], [], []
+        return x, y, v
     hicstraw = _need("hicstraw")
     xs, ys, vs = [], [], []
     for start, end in window_ranges(CHRM_SIZE, distance_in_bp, res):

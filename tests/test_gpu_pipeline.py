@@ -240,3 +240,40 @@ def test_device_diagonal_means_equal_numpy_bitwise():
                 want = np.array([np.mean(dg_all[i, :CH - k][dg_all[i, :CH - k] != 0]) for i, k in enumerate(ks)])
             assert np.array_equal(got[b], want, equal_nan=True), (b, got[b], want)
             assert np.isnan(want[list(ks).index(37)]) and want[0] == 2.0
+
+
+@pytest.mark.parametrize("version", [8, 9])
+def test_cli_from_hic_file_equals_cli_from_text(golden_dir, tmp_path, version):
+    """`-f sample.hic` through the native reader (libmustache_io.so) gives the same TSV as the text input holding the same
+    contacts: KR-normalised inside the reader (float32, as straw returns them) vs the identical values written as text;
+    chromosome list taken from the file when -ch is omitted."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from hic_writer import write_hic
+    from mustache_amd.mustache import main
+    from mustache_amd.synth import synth_coo
+    g = _load(golden_dir, "regulator_3blocks.npz")
+    n, dpx, res = int(g["n"]), int(g["dpx"]), int(g["res"])
+    x, y, v = synth_coo(n, dpx, depth=float(g["depth"]), seed=int(g["seed"]))
+    near = (y - x) <= dpx               # the text reader also keeps diagonal dpx+1 (mustache.py:281 vs :385): the reference's
+    x, y, v = x[near], y[near], v[near]   # two readers differ there by design, so the comparison stays inside dpx
+    counts = np.round(v).astype(np.float64) + 1.0                       # integer counts, as a .hic stores them
+    kr = np.random.default_rng(5).uniform(0.6, 1.7, n + 1)
+    kr[[3, 40]] = np.nan                                                # bins without a KR factor: rows dropped
+    hic = str(tmp_path / "s.hic")
+    write_hic(hic, [("All", 1), ("chrS", n * res + 1200000)], {1: {res: (x, y, counts)}}, {("KR", 1, res): kr},
+              version=version, block_bin_count=200, float_counts=False)
+    krv = kr.astype(np.float32).astype(np.float64) if version == 9 else kr
+    val = (counts / (krv[x] * krv[y])).astype(np.float32).astype(np.float64)
+    ok = ~np.isnan(val) & (val > 0)
+    txt = str(tmp_path / "s.RAWobserved")
+    with open(txt, "w") as f:
+        for a, b, c in zip(x[ok], y[ok], val[ok]):
+            f.write("%d\t%d\t%r\n" % (a * res, b * res, float(c)))
+    out_h, out_t = str(tmp_path / "h.tsv"), str(tmp_path / "t.tsv")
+    common = ["-r", "10kb", "-pt", "0.1", "-st", "0.8", "-d", str(dpx * res)]
+    main(["-f", hic, "-o", out_h] + common)                             # no -ch: every chromosome of the file
+    main(["-f", txt, "-ch", "chrS", "-o", out_t] + common)
+    rows_h = sorted(open(out_h).read().strip().split("\n")[1:])
+    rows_t = sorted(open(out_t).read().strip().split("\n")[1:])
+    assert len(rows_h) > 10 and rows_h == rows_t

@@ -126,6 +126,15 @@ uint64_t mst_bh_workspace_bytes(int32_t B, uint32_t cap);
 int mst_bh_fdr(const double *pval, const uint32_t *count, int32_t B, uint32_t cap, double *q, void *workspace,
                uint64_t workspace_bytes, void *stream);
 
+/* mustache.py:789-797 (selection of the pixels with o < pt) on the device: the found records of each block whose q-value
+ * is below `threshold`, compacted into out_pixel / out_level / out_q [B][out_cap] (order within a block unspecified).
+ * out_count: dev [B], overwritten; a count > out_cap means records were dropped -> re-run with a larger capacity.
+ * Found pixels with q >= pt are never candidates and never a cluster's representative (mustache.py:843-848 takes the
+ * arg-min of o, and every cluster holds a candidate), so the host tail needs nothing else. */
+int mst_select_below(const mst_found *found, const double *q, const uint32_t *found_count, int32_t B,
+                     uint32_t found_cap, double threshold, uint32_t out_cap, uint32_t *out_pixel, uint32_t *out_level,
+                     double *out_q, uint32_t *out_count, void *stream);
+
 /* mustache.py:800-811 + :824 inputs for a list of candidate pixels of ONE block b:
  * cnt1[i] = sum nz[x-s:x+s+1, y-s:y+s+1], cnt2[i] = same with 2s (Python slice semantics: a window whose start
  * is negative is empty -> 0; windows are clipped at the far edge), cval[i] = c[x, y].

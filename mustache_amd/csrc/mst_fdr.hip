@@ -71,7 +71,54 @@ size_t sort_temp_bytes(int B, uint32_t cap) {
     return bytes;
 }
 
+
+// selection o < pt (mustache.py:789-797): the found records whose q-value is below the threshold, compacted per block.
+// Only these (a few hundred per block) are ever looked at by the filters and the clustering -- a not-found pixel has
+// o >= 1, and a found pixel with q >= pt can neither be a candidate nor the arg-min of a cluster that holds one.
+__global__ void __launch_bounds__(256)
+select_below_kernel(const mst_found *__restrict__ found, const double *__restrict__ q, const uint32_t *__restrict__ count,
+                    uint32_t cap, double threshold, uint32_t out_cap, uint32_t *__restrict__ out_pixel,
+                    uint32_t *__restrict__ out_level, double *__restrict__ out_q, uint32_t *__restrict__ out_count) {
+    const int b = blockIdx.y;
+    const uint32_t n = count[b] < cap ? count[b] : cap;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {      // whole waves stay together
+        const uint32_t i = i0 + threadIdx.x;
+        const double qi = i < n ? q[(size_t)b * cap + i] : 2.0;
+        const bool take = i < n && qi < threshold;
+        const unsigned long long bal = __ballot(take);
+        if (!bal) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(out_count + b, (uint32_t)__popcll(bal));             // one atomic per wave
+        base = __shfl(base, 0, 64);
+        if (take) {
+            const uint32_t slot = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (slot < out_cap) {
+                const mst_found r = found[(size_t)b * cap + i];
+                out_pixel[(size_t)b * out_cap + slot] = r.pixel;
+                out_level[(size_t)b * out_cap + slot] = r.level;
+                out_q[(size_t)b * out_cap + slot] = qi;
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int mst_select_below(const mst_found *found, const double *q, const uint32_t *found_count, int32_t B,
+                                uint32_t found_cap, double threshold, uint32_t out_cap, uint32_t *out_pixel,
+                                uint32_t *out_level, double *out_q, uint32_t *out_count, void *stream) {
+    if (!found || !q || !found_count || !out_pixel || !out_level || !out_q || !out_count || B <= 0 || B > 65535 ||
+        found_cap == 0 || out_cap == 0)
+        return mst::fail(MST_E_ARG, "mst_select_below: bad argument");
+    hipStream_t s = mst::as_stream(stream);
+    MST_HIP(hipMemsetAsync(out_count, 0, sizeof(uint32_t) * (size_t)B, s));
+    const int gx = (int)((found_cap + 255) / 256 < 256 ? (found_cap + 255) / 256 : 256);
+    select_below_kernel<<<dim3(gx, B), 256, 0, s>>>(found, q, found_count, found_cap, threshold, out_cap, out_pixel,
+                                                   out_level, out_q, out_count);
+    MST_LAUNCH_CHECK();
+    return MST_OK;
+}
 
 extern "C" uint64_t mst_bh_workspace_bytes(int32_t B, uint32_t cap) {
     if (B <= 0 || cap == 0 || (size_t)B * cap > 0x7FFFFFFFull) return 0;

@@ -174,6 +174,7 @@ class ScaleSpaceEngine:
         self.lib = require_gpu()
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.levels = LevelTable(octave_values, s)
+        self._select_cap = 4096
         self._lv_struct = self.levels.as_struct()
         self._found_cap = {}
         self._pin = {}
@@ -221,8 +222,10 @@ class ScaleSpaceEngine:
         return res + (nz_count,)
 
     def sigma_loop(self, c, nz, nz_count, skip_empty=True, found_cap=None, download=True, timing=None, sort=True,
-                   with_value=True, with_q=True, fma=False, band_src=None):
+                   with_value=True, with_q=True, fma=False, band_src=None, select_below=None):
         """The fused kernel + p-values.  Returns host records (download=True) or the device buffers.
+        `select_below=pt`: BH and the selection q < pt (mustache.py:778-797) run on the device and only those records
+        come back, as dict(pixel, level, q) sorted by pixel -- all the tail ever looks at; the full found set stays in HBM.
         `timing`: optional list; receives a (start, end) torch.cuda.Event pair bracketing the mst_scale_space launch
         on the launch stream.  `band_src` = (band, n, dpx, starts, CH) selects the band-direct kernel (c, nz unused;
         nz_count is then an OUTPUT)."""
@@ -269,6 +272,9 @@ class ScaleSpaceEngine:
                 timing.append((e0, e1))     # mst_found_pvalues synchronised the stream: the events are complete
         if not download:
             return found, pval, count, fit, found_cap
+        if select_below is not None:
+            return self._download_selected(found, self.fdr(pval, count, found_cap), count, fit, nt, found_cap,
+                                           float(select_below))
         extra = {"q": self.fdr(pval, count, found_cap)} if with_q else None
         return self._download(found, pval, count, fit, nt, sort=sort, with_value=with_value, extra=extra)
 
@@ -283,6 +289,34 @@ class ScaleSpaceEngine:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
             _lib.check(self.lib.mst_bh_fdr(_ptr(pval), _ptr(count), B, found_cap, _ptr(q), _ptr(ws), ws_bytes, _stream()))
         return q
+
+    def _download_selected(self, found, q, count, fit, nt, found_cap, pt):
+        B = count.shape[0]
+        cap = self._select_cap
+        with torch.cuda.device(self.device):
+            while True:
+                pix = torch.empty((B, cap), dtype=torch.int32, device=self.device)
+                lvl = torch.empty((B, cap), dtype=torch.int32, device=self.device)
+                qs = torch.empty((B, cap), dtype=torch.float64, device=self.device)
+                n_sel = torch.empty(B, dtype=torch.int32, device=self.device)
+                _lib.check(self.lib.mst_select_below(_ptr(found), _ptr(q), _ptr(count), B, found_cap, pt, cap, _ptr(pix),
+                                                     _ptr(lvl), _ptr(qs), _ptr(n_sel), _stream()))
+                n_h = n_sel.cpu().numpy().view(np.uint32).astype(np.int64)
+                if n_h.max(initial=0) <= cap:
+                    break
+                cap = self._select_cap = int(n_h.max()) * 2         # rare: re-run with room for every selected record
+            mx = int(n_h.max(initial=0))
+            pix_h = pix[:, :max(mx, 1)].cpu().numpy().view(np.uint32)
+            lvl_h = lvl[:, :max(mx, 1)].cpu().numpy().view(np.uint32)
+            q_h = qs[:, :max(mx, 1)].cpu().numpy()
+            fit_h = fit.cpu().numpy()
+        out, fits = [], []
+        for b in range(B):
+            m = int(n_h[b])
+            order = np.argsort(pix_h[b, :m], kind="stable")        # the kernel appends in arbitrary order; pixels are unique
+            out.append({"pixel": pix_h[b, :m][order], "level": lvl_h[b, :m][order], "q": q_h[b, :m][order]})
+            fits.append((fit_h[b, :nt, 0].copy(), fit_h[b, :nt, 1].copy()))
+        return out, fits
 
     def _pinned(self, key, shape, dtype):
         """Page-locked host staging buffers (D2H at PCIe rate).  Two sets alternate, so the arrays handed out by one

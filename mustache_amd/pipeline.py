@@ -66,13 +66,14 @@ class ChromosomePipeline:
             starts_g = [start[i] for i in group]
             if dense:       # materialise [B, CH, CH] blocks first (what mustache() gets from its caller) -- cross-check path
                 c, nz, nzc = self.blocks_from_band(band, n, dpx, starts_g, CH)
-                found, fits = self.engine.sigma_loop(c, nz, nzc, skip_empty=skip_empty, with_value=False)
+                found, fits = self.engine.sigma_loop(c, nz, nzc, skip_empty=skip_empty, with_value=False,
+                                                     select_below=pt)
                 batch = BlockBatch(self.engine, c, nz, CH, len(group),
                                    nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
             else:           # default: blocks are windows of the band, cut inside the fused kernel
                 c = nz = None
                 found, fits, nzc = self.engine.sigma_loop_band(band, n, dpx, starts_g, CH, skip_empty=skip_empty,
-                                                               with_value=False)
+                                                               with_value=False, select_below=pt)
                 batch = BandBatch(self.engine, band, n, dpx, starts_g, CH,
                                   nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
             t1 = time.time()

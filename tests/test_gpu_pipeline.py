@@ -277,3 +277,32 @@ def test_cli_from_hic_file_equals_cli_from_text(golden_dir, tmp_path, version):
     rows_h = sorted(open(out_h).read().strip().split("\n")[1:])
     rows_t = sorted(open(out_t).read().strip().split("\n")[1:])
     assert len(rows_h) > 10 and rows_h == rows_t
+
+
+def test_device_selection_equals_host_selection():
+    """mst_select_below (q < pt on the device, only those records downloaded) == the same selection applied on the host
+    to the full found set: pixels, levels and q-values identical, sorted by pixel; capacity overflow re-runs."""
+    import torch
+    from mustache_amd.normalize import band_from_coo, normalize_band
+    from mustache_amd.pipeline import ChromosomePipeline, block_tiling
+    from mustache_amd.synth import synth_coo
+    n, dpx, res = 4300, 400, 5000
+    x, y, v = synth_coo(n, dpx, depth=120.0, seed=33)
+    pipe = ChromosomePipeline(OCT)
+    band = band_from_coo(*(torch.from_numpy(a).to(pipe.device) for a in (x, y, v)), n, dpx)
+    band, _, _ = normalize_band(band, n, dpx, res)
+    CH, start, end = block_tiling(n, dpx)
+    full, fits, _ = pipe.engine.sigma_loop_band(band, n, dpx, start, CH)
+    for pt, cap in ((0.1, 4096), (0.9, 64)):                    # the second capacity is far too small on purpose
+        pipe.engine._select_cap = cap
+        sel, fits2, _ = pipe.engine.sigma_loop_band(band, n, dpx, start, CH, select_below=pt)
+        total = 0
+        for a, b in zip(full, sel):
+            keep = a["q"] < pt
+            total += int(keep.sum())
+            assert np.array_equal(a["pixel"][keep], b["pixel"]) and np.array_equal(a["level"][keep], b["level"])
+            assert np.array_equal(a["q"][keep], b["q"])
+        assert total > (100 if pt > 0.5 else 5)
+        for (la, sa), (lb, sb) in zip(fits, fits2):
+            assert np.array_equal(la, lb) and np.array_equal(sa, sb)
+    assert pipe.engine._select_cap > 64

@@ -201,10 +201,7 @@ def call_loops_coo(x, y, v, res, distance_in_px, octave_values, st, pt, chromoso
     return pipe.run(x, y, v, res, distance_in_px, st, pt, normalized=normalized, verbose=verbose, timings=timings)
 
 
-def regulator(f, norm_method, CHRM_SIZE, outdir, bed="", res=5000, sigma0=1.6, s=10, pt=0.1, st=0.88, octaves=2,
-              verbose=True, nprocesses=4, distance_filter=2000000, bias=False, chromosome='n', chromosome2=None):
-    """Loop calling for one chromosome (reference mustache.py:853-942).  `s` is accepted and ignored like in the
-    reference (s = 10 is hard-wired at :711); `nprocesses` is ignored: all blocks run as one GPU batch."""
+def _check_pair(f, chromosome, chromosome2):
     if not chromosome2 or chromosome2 == 'n':
         chromosome2 = chromosome
     if (chromosome != chromosome2) and not (('.hic' in f) or ('.cool' in f) or ('.mcool' in f)):
@@ -212,7 +209,13 @@ def regulator(f, norm_method, CHRM_SIZE, outdir, bed="", res=5000, sigma0=1.6, s
         raise FileNotFoundError
     if chromosome != chromosome2:
         raise NotImplementedError("inter-chromosomal mode is non-functional in the reference (mustache.py:939-942)")
-    octave_values = [sigma0 * (2 ** i) for i in range(octaves)]
+    return chromosome2
+
+
+def read_contacts(f, norm_method, CHRM_SIZE, res, distance_filter, bias, chromosome, chromosome2, verbose=True):
+    """The reading half of regulator() (reference mustache.py:866-889): host I/O only, so main() can fetch the next
+    chromosome while the GPU works on the current one.  Returns (x, y, v, res) or None when nothing was read."""
+    chromosome2 = _check_pair(f, chromosome, chromosome2)
     distance_in_bp = distance_filter
     if verbose:
         print("Reading contact map...")
@@ -228,13 +231,28 @@ def regulator(f, norm_method, CHRM_SIZE, outdir, bed="", res=5000, sigma0=1.6, s
     else:
         r = read_pd(f, distance_in_bp, bias, chromosome, res)
         if r is None:
-            return []
+            return None
         x, y, v = r
     if len(v) == 0:
-        return []
-    distance_in_px = int(math.ceil(distance_in_bp // res))
-    return call_loops_coo(np.asarray(x), np.asarray(y), np.asarray(v, dtype=np.float64), res, distance_in_px,
-                          octave_values, st, pt, chromosome, chromosome2, verbose=verbose)
+        return None
+    return np.asarray(x), np.asarray(y), np.asarray(v, dtype=np.float64), res
+
+
+def regulator(f, norm_method, CHRM_SIZE, outdir, bed="", res=5000, sigma0=1.6, s=10, pt=0.1, st=0.88, octaves=2,
+              verbose=True, nprocesses=4, distance_filter=2000000, bias=False, chromosome='n', chromosome2=None,
+              contacts=None):
+    """Loop calling for one chromosome (reference mustache.py:853-942).  `s` is accepted and ignored like in the
+    reference (s = 10 is hard-wired at :711); `nprocesses` is ignored: all blocks run as one GPU batch.
+    `contacts` (not in the reference): what read_contacts() returned for this chromosome, when the caller read ahead."""
+    chromosome2 = _check_pair(f, chromosome, chromosome2)
+    octave_values = [sigma0 * (2 ** i) for i in range(octaves)]
+    if contacts is None:
+        contacts = read_contacts(f, norm_method, CHRM_SIZE, res, distance_filter, bias, chromosome, chromosome2, verbose)
+        if contacts is None:
+            return []
+    x, y, v, res = contacts
+    distance_in_px = int(math.ceil(distance_filter // res))
+    return call_loops_coo(x, y, v, res, distance_in_px, octave_values, st, pt, chromosome, chromosome2, verbose=verbose)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -351,24 +369,43 @@ def main(argv=None):
         csz = pd.read_csv(args.chrSize_file, header=None, sep='\t')
         chrSize_in_bp = {"chr" + str(csz.iloc[i, 0]).replace('chr', ''): csz.iloc[i, 1] for i in range(csz.shape[0])}
 
-    for i, (chromosome, chromosome2) in enumerate(zip(chr_list, chr_list2)):
+    if args.biasfile and not os.path.exists(args.biasfile):
+        print("Error: Couldn't find specified bias file")
+        return
+    biasf = args.biasfile if args.biasfile else False
+    pairs = list(zip(chr_list, chr_list2))
+
+    def fetch(i):
+        chromosome, chromosome2 = pairs[i]
         CHRM_SIZE = chrSize_in_bp["chr" + str(chromosome).replace('chr', '')] if chrSize_in_bp else False
-        biasf = False
-        if args.biasfile:
-            if os.path.exists(args.biasfile):
-                biasf = args.biasfile
+        try:
+            return read_contacts(f, args.norm_method, CHRM_SIZE, res, distFilter, biasf, chromosome, chromosome2,
+                                 verbose=args.verbose)
+        except BaseException as e:          # re-raised in the main thread, at this chromosome's turn
+            return e
+
+    # the next chromosome is read (host I/O; the native .hic reader and pandas release the GIL) while the GPU works on
+    # the current one -- the reference reads and computes strictly in turn (mustache.py:1057-1080)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        ahead = pool.submit(fetch, 0) if pairs else None
+        for i, (chromosome, chromosome2) in enumerate(pairs):
+            contacts = ahead.result()
+            ahead = pool.submit(fetch, i + 1) if i + 1 < len(pairs) else None
+            if isinstance(contacts, BaseException):
+                raise contacts
+            if contacts is None:
+                o = []
             else:
-                print("Error: Couldn't find specified bias file")
-                return
-        o = regulator(f, args.norm_method, CHRM_SIZE, args.outdir, bed=args.bed, res=res, sigma0=args.s_z, s=args.s,
-                      verbose=args.verbose, pt=args.pt, st=args.st, distance_filter=distFilter,
-                      nprocesses=args.nprocesses, bias=biasf, chromosome=chromosome, chromosome2=chromosome2,
-                      octaves=args.octaves)
-        print("{0} loops found for chrmosome={1}, fdr<{2} in {3}sec".format(
-            len(o), chromosome, args.pt, "%.2f" % (time.time() - start_time)))
-        if rank == 0 and (i == 0 or o):
-            write_loops(args.outdir, chromosome, chromosome2, res, o, first=(i == 0))
-        start_time = time.time()
+                o = regulator(f, args.norm_method, False, args.outdir, bed=args.bed, res=contacts[3], sigma0=args.s_z,
+                              s=args.s, verbose=args.verbose, pt=args.pt, st=args.st, distance_filter=distFilter,
+                              nprocesses=args.nprocesses, bias=biasf, chromosome=chromosome, chromosome2=chromosome2,
+                              octaves=args.octaves, contacts=contacts)
+            print("{0} loops found for chrmosome={1}, fdr<{2} in {3}sec".format(
+                len(o), chromosome, args.pt, "%.2f" % (time.time() - start_time)))
+            if rank == 0 and (i == 0 or o):
+                write_loops(args.outdir, chromosome, chromosome2, res, o, first=(i == 0))
+            start_time = time.time()
 
 
 if __name__ == '__main__':

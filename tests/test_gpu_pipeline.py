@@ -261,7 +261,8 @@ def test_cli_from_hic_file_equals_cli_from_text(golden_dir, tmp_path, version):
     kr = np.random.default_rng(5).uniform(0.6, 1.7, n + 1)
     kr[[3, 40]] = np.nan                                                # bins without a KR factor: rows dropped
     hic = str(tmp_path / "s.hic")
-    write_hic(hic, [("All", 1), ("chrS", n * res + 1200000)], {1: {res: (x, y, counts)}}, {("KR", 1, res): kr},
+    write_hic(hic, [("All", 1), ("chrS", n * res + 1200000), ("chrT", n * res)],
+              {1: {res: (x, y, counts)}, 2: {res: (x, y, counts)}}, {("KR", 1, res): kr, ("KR", 2, res): kr},
               version=version, block_bin_count=200, float_counts=False)
     krv = kr.astype(np.float32).astype(np.float64) if version == 9 else kr
     val = (counts / (krv[x] * krv[y])).astype(np.float32).astype(np.float64)
@@ -272,11 +273,14 @@ def test_cli_from_hic_file_equals_cli_from_text(golden_dir, tmp_path, version):
             f.write("%d\t%d\t%r\n" % (a * res, b * res, float(c)))
     out_h, out_t = str(tmp_path / "h.tsv"), str(tmp_path / "t.tsv")
     common = ["-r", "10kb", "-pt", "0.1", "-st", "0.8", "-d", str(dpx * res)]
-    main(["-f", hic, "-o", out_h] + common)                             # no -ch: every chromosome of the file
-    main(["-f", txt, "-ch", "chrS", "-o", out_t] + common)
-    rows_h = sorted(open(out_h).read().strip().split("\n")[1:])
-    rows_t = sorted(open(out_t).read().strip().split("\n")[1:])
-    assert len(rows_h) > 10 and rows_h == rows_t
+    main(["-f", hic, "-o", out_h] + common)                             # no -ch: every chromosome of the file, read ahead
+    main(["-f", txt, "-ch", "chrS", "chrT", "-o", out_t] + common)      # the text file serves both names
+    rows_h = open(out_h).read().strip().split("\n")[1:]
+    rows_t = open(out_t).read().strip().split("\n")[1:]
+    assert len(rows_h) > 20 and sorted(rows_h) == sorted(rows_t)
+    assert {r.split("\t")[0] for r in rows_h} == {"chrS", "chrT"}
+    first_t = min(i for i, r in enumerate(rows_h) if r.startswith("chrT"))
+    assert all(r.startswith("chrS") for r in rows_h[:first_t]), "chromosomes are written in file order"
 
 
 def test_device_selection_equals_host_selection():

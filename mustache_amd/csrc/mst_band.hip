@@ -16,6 +16,7 @@
 // this stage.  We sum every window directly (no running/prefix sums), in a fixed order, which stays within a few
 // ulp of any such order; tests hold the result to 1e-9 relative on z-scores and require identical loop sets.
 #include <cmath>
+#include <cstdlib>
 #include "mst_common.h"
 
 namespace {
@@ -218,6 +219,153 @@ normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ 
     }
 }
 
+// Branch A, prefix-sum form (the default): one workgroup = kPSeg consecutive positions of one diagonal.  The kPSeg + W
+// samples it needs are read ONCE and turned into three exclusive prefix arrays in LDS -- count of non-zero samples
+// (exact, int32), sum of (v + 0.001), sum of squares -- so every window is two LDS reads per quantity instead of
+// ~W/16 block sums: the kernel becomes a streaming pass over the band (8 B read + 8 B written per sample).
+// Numerics: a window sum is P[end] - P[begin] with both prefixes accumulated from the tile start (at most kPSeg + W
+// terms), i.e. a relative error of a few 1e-16 on the window sums -- the same order as the difference between BLAS
+// builds of the reference's np.convolve; parity with the reference fixtures is held at 1e-9 (tests).  The summation
+// order is fixed by (diagonal, segment), so results are deterministic.
+constexpr int kPSeg = 1024;
+
+__device__ __forceinline__ void normalize_prefix_item(const double *__restrict__ band_in, double *__restrict__ band_out,
+                                                      int64_t n, int W, const double *__restrict__ diag_stats, int chunk,
+                                                      int nseg, int64_t item, double *lds, double *w1, double *w2, int *wc) {
+    const int d = (int)(item / nseg);
+    const int64_t L = n - d;
+    const int64_t seg0 = (item - (int64_t)d * nseg) * kPSeg;
+    double *orow = band_out + (int64_t)d * n;
+    if (seg0 >= L) {                                   // past the end of this diagonal: the output band is zero there
+        for (int k = threadIdx.x; k < kPSeg; k += kThreads)
+            if (seg0 + k < n) orow[seg0 + k] = 0.0;
+        return;
+    }
+    const int left = W / 2;                            // np.convolve(..., 'same'): window = [i - W/2, i - W/2 + W - 1]
+    const int64_t base = seg0 - left;                  // tile element t <-> absolute position base + t
+    const int tile = kPSeg + W - 1;                    // last window ends at seg0 + kPSeg - 1 - left + W - 1
+    const int cap = kThreads * chunk;                  // >= tile + 1 slots per array
+    double *P1 = lds, *P2 = P1 + cap;                  // exclusive prefixes: P[t] = sum of elements [0, t)
+    int *Pc = reinterpret_cast<int *>(P2 + cap);
+    const double *row = band_in + (int64_t)d * n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // coalesced staging of the shifted samples into P1's slots (each is overwritten by its prefix below); eight loads are
+    // in flight per thread before the first LDS store, otherwise the loop is one HBM round trip per sample
+    for (int t0s = tid; t0s < cap; t0s += kThreads * 8) {
+        double r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0s + u * kThreads;
+            const int64_t i = base + t;
+            r[u] = (t < tile && i >= 0 && i < L) ? row[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0s + u * kThreads;
+            if (t < cap) P1[t] = r[u] != 0.0 ? r[u] + 0.001 : 0.0;       // vals[x] = v + 0.001   (:635)
+        }
+    }
+    __syncthreads();
+    // thread-serial chunk (odd length: conflict-free LDS stride), then an inclusive scan of the thread totals
+    const int t0 = tid * chunk;
+    double a1 = 0.0, a2 = 0.0;
+    int ac = 0;
+    for (int j = 0; j < chunk; ++j) {
+        const double v = P1[t0 + j];
+        ac += (v != 0.0) ? 1 : 0;
+        a1 = a1 + v;
+        a2 = a2 + v * v;                               // vals ** 2             (:649)
+    }
+    double s1 = a1, s2 = a2;
+    int sc = ac;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double u1 = __shfl_up(s1, o, 64), u2 = __shfl_up(s2, o, 64);
+        const int uc = __shfl_up(sc, o, 64);
+        if (lane >= o) {
+            s1 = s1 + u1;
+            s2 = s2 + u2;
+            sc += uc;
+        }
+    }
+    if (lane == 63) {
+        w1[wave] = s1;
+        w2[wave] = s2;
+        wc[wave] = sc;
+    }
+    __syncthreads();
+    double o1 = 0.0, o2 = 0.0;
+    int oc = 0;
+    for (int w = 0; w < wave; ++w) {
+        o1 = o1 + w1[w];
+        o2 = o2 + w2[w];
+        oc += wc[w];
+    }
+    // exclusive prefix at the start of this thread's chunk = waves before + the previous lane's inclusive value; the
+    // chunk is walked again and every sample slot is replaced by the prefix in front of it
+    const double e1 = __shfl_up(s1, 1, 64), e2 = __shfl_up(s2, 1, 64);
+    const int ec = __shfl_up(sc, 1, 64);
+    double p1 = o1 + (lane ? e1 : 0.0), p2 = o2 + (lane ? e2 : 0.0);
+    int pc = oc + (lane ? ec : 0);
+    for (int j = 0; j < chunk; ++j) {
+        const int t = t0 + j;
+        const double v = P1[t];
+        P1[t] = p1;
+        P2[t] = p2;
+        Pc[t] = pc;
+        pc += (v != 0.0) ? 1 : 0;
+        p1 = p1 + v;
+        p2 = p2 + v * v;
+    }
+    __syncthreads();
+    const double mean = diag_stats[4 * d + 0], sd = diag_stats[4 * d + 1], wgt = diag_stats[4 * d + 2];
+    const double std2 = sd * sd;
+    for (int k = tid; k < kPSeg; k += kThreads) {
+        const int64_t i = seg0 + k;
+        if (i >= n) break;
+        double z = 0.0;
+        if (i < L) {
+            const double r = row[i];
+            if (r != 0.0) {
+                const double x = r + 0.001;
+                const int ta = k, tb = k + W;           // window = tile elements [k, k + W)
+                const int c = Pc[tb] - Pc[ta];
+                const double s1w = P1[tb] - P1[ta], s2w = P2[tb] - P2[ta];
+                const double cnt = (double)c;
+                double var = (s2w - s1w * s1w / cnt) / (cnt - 1.0);      // (:650)
+                if (!isfinite(var)) var = std2;                          // (:653-654)
+                double mu = s1w / cnt;                                   // (:656)
+                if (c < 30) {                                            // (:657-658)
+                    mu = mean;
+                    var = std2;
+                }
+                if (!isfinite(mu)) mu = mean;                            // (:660-661)
+                z = (x - mu) / sqrt(var);                                // (:663-665)
+                if (!isfinite(z)) z = 0.0;                               // (:666)
+                z = z * wgt;                                             // (:667)
+            }
+        }
+        orow[i] = z;
+    }
+}
+
+// Work item = (diagonal, segment), numbered diagonal-major.  Every workgroup walks a contiguous run of items, so the W
+// samples two neighbouring segments share are re-read from its own CU's / XCD's caches, and the grid is a few thousand
+// workgroups instead of one per item (488 k items for chr1 @ 1 kb would be workgroup-dispatch bound at ~18 ns each).
+__global__ void __launch_bounds__(kThreads)
+normalize_prefix_kernel(const double *__restrict__ band_in, double *__restrict__ band_out, int64_t n, int W,
+                        const double *__restrict__ diag_stats, int chunk, int nseg, int nd, int items_per_wg) {
+    extern __shared__ __align__(16) double lds[];
+    __shared__ double w1[kThreads / 64], w2[kThreads / 64];
+    __shared__ int wc[kThreads / 64];
+    const int64_t total = (int64_t)nseg * nd;
+    const int64_t first = (int64_t)blockIdx.x * items_per_wg;
+    for (int64_t item = first; item < first + items_per_wg && item < total; ++item) {
+        normalize_prefix_item(band_in, band_out, n, W, diag_stats, chunk, nseg, item, lds, w1, w2, wc);
+        __syncthreads();                               // the LDS arrays are reused by the next item
+    }
+}
+
 // Branch B (mustache.py:671-685): plain per-diagonal z-score for d < min(dpx, n); other diagonals pass through
 // (after the nan_to_num at :673).
 __global__ void __launch_bounds__(kThreads)
@@ -350,8 +498,32 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
     const int nd = dpx + 2;
     diag_stats_kernel<<<nd, kThreads, 0, s>>>(band_in, n, diag_stats);
     MST_LAUNCH_CHECK();
+    if (local && window >= 2) {
+        // default: prefix-sum kernel, as long as its tile (2 doubles + 1 int per sample) leaves room for two workgroups per CU
+        const int tile = kPSeg + window - 1;
+        const int chunk = ((tile + 1 + kThreads - 1) / kThreads) | 1;    // samples per thread, odd
+        const size_t plds = (sizeof(double) * 2 + sizeof(int)) * (size_t)kThreads * chunk + 16;
+        if (plds <= 80 * 1024 && !getenv("MST_NORMALIZE_BLOCKED")) {
+            static bool pattr_set = false;
+            if (!pattr_set) {
+                MST_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&normalize_prefix_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                pattr_set = true;
+            }
+            const int nseg = (int)((n + kPSeg - 1) / kPSeg);            // covers [0, n): the kernel also writes the zero tails
+            const int64_t total = (int64_t)nseg * nd;
+            const int64_t want_wgs = 256 * 2 * 8;                        // 8 waves of workgroups over 256 CUs x 2 resident
+            const int ipw = (int)((total + want_wgs - 1) / want_wgs);
+            const int64_t wgs = (total + ipw - 1) / ipw;
+            normalize_prefix_kernel<<<(unsigned)wgs, kThreads, plds, s>>>(band_in, band_out, n, window, diag_stats, chunk,
+                                                                         nseg, nd, ipw);
+            MST_LAUNCH_CHECK();
+            return MST_OK;
+        }
+    }
     if (local) {
-        // LDS: 2 doubles per staged sample + 2 doubles and an int per 16-sample block, for up to SEG + W + 2*16 samples
+        // wide windows: blocked-sum kernel.  LDS: 2 doubles per staged sample + 2 doubles and an int per 16-sample block,
+        // for up to SEG + W + 2*16 samples
         const size_t nblk = (size_t)(kSeg + window + 2 * kBlk + kBlk - 1) / kBlk;
         const size_t lds = sizeof(double) * (2 * nblk * kBlk + 2 * nblk) + sizeof(int) * nblk + 16;
         if (window < 2 || lds > 160 * 1024)

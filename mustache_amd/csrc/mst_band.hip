@@ -229,65 +229,107 @@ normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ 
 // order is fixed by (diagonal, segment), so results are deterministic.
 constexpr int kPSeg = 1024;
 
+// ---- wave-level inclusive scan with DPP moves (no LDS crossbar): Hillis-Steele inside the four 16-lane rows (row_shr 1, 2,
+// 4, 8; lanes without a source read 0), then row_bcast15 / row_bcast31 add the totals of the rows below.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double x) {
+    return __hiloint2double(dpp_i<CTRL, ROW_MASK>(__double2hiint(x)), dpp_i<CTRL, ROW_MASK>(__double2loint(x)));
+}
+__device__ __forceinline__ void wave_scan3(double &a, double &b, int &c) {
+#define MST_SCAN_STEP(CTRL, MASK)           \
+    {                                       \
+        const double ua = dpp_d<CTRL, MASK>(a); \
+        const double ub = dpp_d<CTRL, MASK>(b); \
+        const int uc = dpp_i<CTRL, MASK>(c);    \
+        a = a + ua;                         \
+        b = b + ub;                         \
+        c += uc;                            \
+    }
+    MST_SCAN_STEP(0x111, 0xf)   // row_shr:1
+    MST_SCAN_STEP(0x112, 0xf)   // row_shr:2
+    MST_SCAN_STEP(0x114, 0xf)   // row_shr:4
+    MST_SCAN_STEP(0x118, 0xf)   // row_shr:8
+    MST_SCAN_STEP(0x142, 0xa)   // row_bcast:15 -> rows 1 and 3
+    MST_SCAN_STEP(0x143, 0xc)   // row_bcast:31 -> rows 2 and 3
+#undef MST_SCAN_STEP
+}
+// inclusive scan value of the previous lane (0 for lane 0): wave_shr:1
+__device__ __forceinline__ double lane_before(double x) { return dpp_d<0x138, 0xf>(x); }
+__device__ __forceinline__ int lane_before_i(int x) { return dpp_i<0x138, 0xf>(x); }
+
+constexpr int kPThreads = 256;                         // (1024-thread workgroups were measured: 20 % slower)
+constexpr int kPMaxChunk = 17;                         // samples per thread a tile may need (W <= 3072); always odd
+
+// raw samples of one item's tile into registers: r[u] = element t = tid + u * kPThreads (0 outside the diagonal)
+template <int CHUNK>
+__device__ __forceinline__ void normalize_prefix_fetch(const double *__restrict__ band_in, int64_t n, int W,
+                                                       int nseg, int64_t item, double (&r)[CHUNK]) {
+    const int d = (int)(item / nseg);
+    const int64_t L = n - d;
+    const int64_t base = (item - (int64_t)d * nseg) * kPSeg - W / 2;
+    const int tile = kPSeg + W - 1;
+    const double *row = band_in + (int64_t)d * n;
+#pragma unroll
+    for (int u = 0; u < CHUNK; ++u) {
+        const int t = (int)threadIdx.x + u * kPThreads;
+        const int64_t i = base + t;
+        r[u] = (t < tile && i >= 0 && i < L) ? row[i] : 0.0;
+    }
+}
+
+template <int CHUNK>
 __device__ __forceinline__ void normalize_prefix_item(const double *__restrict__ band_in, double *__restrict__ band_out,
-                                                      int64_t n, int W, const double *__restrict__ diag_stats, int chunk,
-                                                      int nseg, int64_t item, double *lds, double *w1, double *w2, int *wc) {
+                                                      int64_t n, int W, const double *__restrict__ diag_stats,
+                                                      int nseg, int64_t item, int64_t next_item, double (&r)[CHUNK],
+                                                      double *lds, double *w1, double *w2, int *wc) {
     const int d = (int)(item / nseg);
     const int64_t L = n - d;
     const int64_t seg0 = (item - (int64_t)d * nseg) * kPSeg;
     double *orow = band_out + (int64_t)d * n;
     if (seg0 >= L) {                                   // past the end of this diagonal: the output band is zero there
-        for (int k = threadIdx.x; k < kPSeg; k += kThreads)
+        for (int k = threadIdx.x; k < kPSeg; k += kPThreads)
             if (seg0 + k < n) orow[seg0 + k] = 0.0;
+        if (next_item >= 0) normalize_prefix_fetch<CHUNK>(band_in, n, W, nseg, next_item, r);
         return;
     }
     const int left = W / 2;                            // np.convolve(..., 'same'): window = [i - W/2, i - W/2 + W - 1]
-    const int64_t base = seg0 - left;                  // tile element t <-> absolute position base + t
-    const int tile = kPSeg + W - 1;                    // last window ends at seg0 + kPSeg - 1 - left + W - 1
-    const int cap = kThreads * chunk;                  // >= tile + 1 slots per array
+    // tile element t <-> absolute position seg0 - left + t; the last window ends at tile element kPSeg + W - 2
+    constexpr int cap = kPThreads * CHUNK;                  // >= tile + 1 slots per array
     double *P1 = lds, *P2 = P1 + cap;                  // exclusive prefixes: P[t] = sum of elements [0, t)
     int *Pc = reinterpret_cast<int *>(P2 + cap);
-    const double *row = band_in + (int64_t)d * n;
+    double *X = reinterpret_cast<double *>(Pc + cap + (cap & 1));          // the segment's own (shifted) samples
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // coalesced staging of the shifted samples into P1's slots (each is overwritten by its prefix below); eight loads are
-    // in flight per thread before the first LDS store, otherwise the loop is one HBM round trip per sample
-    for (int t0s = tid; t0s < cap; t0s += kThreads * 8) {
-        double r[8];
+    // the tile's samples were fetched into registers while the previous item was being processed; they go to P1's slots
+    // (each is overwritten by its prefix below), then the NEXT item's fetch is issued so its HBM latency hides under this
+    // item's scans and outputs
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int t = t0s + u * kThreads;
-            const int64_t i = base + t;
-            r[u] = (t < tile && i >= 0 && i < L) ? row[i] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int t = t0s + u * kThreads;
-            if (t < cap) P1[t] = r[u] != 0.0 ? r[u] + 0.001 : 0.0;       // vals[x] = v + 0.001   (:635)
-        }
+    for (int u = 0; u < CHUNK; ++u) {
+        const int t = tid + u * kPThreads;
+        P1[t] = r[u] != 0.0 ? r[u] + 0.001 : 0.0;                          // vals[x] = v + 0.001   (:635)
     }
+    if (next_item >= 0) normalize_prefix_fetch<CHUNK>(band_in, n, W, nseg, next_item, r);
     __syncthreads();
-    // thread-serial chunk (odd length: conflict-free LDS stride), then an inclusive scan of the thread totals
-    const int t0 = tid * chunk;
+    // thread-serial chunk (odd length: conflict-free LDS stride; read in one batch), then an inclusive scan of the thread
+    // totals across the wave with DPP moves and across the four waves through LDS
+    const int t0 = tid * CHUNK;
+    double vv[CHUNK];
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) vv[j] = P1[t0 + j];
     double a1 = 0.0, a2 = 0.0;
     int ac = 0;
-    for (int j = 0; j < chunk; ++j) {
-        const double v = P1[t0 + j];
-        ac += (v != 0.0) ? 1 : 0;
-        a1 = a1 + v;
-        a2 = a2 + v * v;                               // vals ** 2             (:649)
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) {
+        ac += (vv[j] != 0.0) ? 1 : 0;
+        a1 = a1 + vv[j];
+        a2 = a2 + vv[j] * vv[j];                       // vals ** 2             (:649)
     }
     double s1 = a1, s2 = a2;
     int sc = ac;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double u1 = __shfl_up(s1, o, 64), u2 = __shfl_up(s2, o, 64);
-        const int uc = __shfl_up(sc, o, 64);
-        if (lane >= o) {
-            s1 = s1 + u1;
-            s2 = s2 + u2;
-            sc += uc;
-        }
-    }
+    wave_scan3(s1, s2, sc);
     if (lane == 63) {
         w1[wave] = s1;
         w2[wave] = s2;
@@ -301,46 +343,48 @@ __device__ __forceinline__ void normalize_prefix_item(const double *__restrict__
         o2 = o2 + w2[w];
         oc += wc[w];
     }
-    // exclusive prefix at the start of this thread's chunk = waves before + the previous lane's inclusive value; the
-    // chunk is walked again and every sample slot is replaced by the prefix in front of it
-    const double e1 = __shfl_up(s1, 1, 64), e2 = __shfl_up(s2, 1, 64);
-    const int ec = __shfl_up(sc, 1, 64);
-    double p1 = o1 + (lane ? e1 : 0.0), p2 = o2 + (lane ? e2 : 0.0);
-    int pc = oc + (lane ? ec : 0);
-    for (int j = 0; j < chunk; ++j) {
+    // exclusive prefix at the start of this thread's chunk = waves before + the lanes before (inclusive minus own); every
+    // sample slot is replaced by the prefix in front of it
+    double p1 = o1 + lane_before(s1), p2 = o2 + lane_before(s2);
+    int pc = oc + lane_before_i(sc);
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) {
         const int t = t0 + j;
-        const double v = P1[t];
         P1[t] = p1;
         P2[t] = p2;
         Pc[t] = pc;
-        pc += (v != 0.0) ? 1 : 0;
-        p1 = p1 + v;
-        p2 = p2 + v * v;
+        if (t >= left && t < left + kPSeg) X[t - left] = vv[j];
+        pc += (vv[j] != 0.0) ? 1 : 0;
+        p1 = p1 + vv[j];
+        p2 = p2 + vv[j] * vv[j];
     }
     __syncthreads();
     const double mean = diag_stats[4 * d + 0], sd = diag_stats[4 * d + 1], wgt = diag_stats[4 * d + 2];
     const double std2 = sd * sd;
-    for (int k = tid; k < kPSeg; k += kThreads) {
+    for (int k = tid; k < kPSeg; k += kPThreads) {
         const int64_t i = seg0 + k;
         if (i >= n) break;
         double z = 0.0;
         if (i < L) {
-            const double r = row[i];
-            if (r != 0.0) {
-                const double x = r + 0.001;
+            const double x = X[k];
+            if (x != 0.0) {
                 const int ta = k, tb = k + W;           // window = tile elements [k, k + W)
                 const int c = Pc[tb] - Pc[ta];
                 const double s1w = P1[tb] - P1[ta], s2w = P2[tb] - P2[ta];
+                // 1/cnt and 1/(cnt-1) from ONE division (FP64 divisions dominate this kernel's instruction count); a
+                // window with c < 30 -- including c = 1, where the product form gives NaN -- takes the fallback below
                 const double cnt = (double)c;
-                double var = (s2w - s1w * s1w / cnt) / (cnt - 1.0);      // (:650)
+                const double rcc = 1.0 / (cnt * (cnt - 1.0));
+                const double inv_c = rcc * (cnt - 1.0), inv_cm1 = rcc * cnt;
+                double var = (s2w - s1w * s1w * inv_c) * inv_cm1;        // (:650)
                 if (!isfinite(var)) var = std2;                          // (:653-654)
-                double mu = s1w / cnt;                                   // (:656)
+                double mu = s1w * inv_c;                                 // (:656)
                 if (c < 30) {                                            // (:657-658)
                     mu = mean;
                     var = std2;
                 }
                 if (!isfinite(mu)) mu = mean;                            // (:660-661)
-                z = (x - mu) / sqrt(var);                                // (:663-665)
+                z = (x - mu) * rsqrt(var);                               // (:663-665)
                 if (!isfinite(z)) z = 0.0;                               // (:666)
                 z = z * wgt;                                             // (:667)
             }
@@ -352,16 +396,21 @@ __device__ __forceinline__ void normalize_prefix_item(const double *__restrict__
 // Work item = (diagonal, segment), numbered diagonal-major.  Every workgroup walks a contiguous run of items, so the W
 // samples two neighbouring segments share are re-read from its own CU's / XCD's caches, and the grid is a few thousand
 // workgroups instead of one per item (488 k items for chr1 @ 1 kb would be workgroup-dispatch bound at ~18 ns each).
-__global__ void __launch_bounds__(kThreads)
+template <int CHUNK>
+__global__ void __launch_bounds__(kPThreads)
 normalize_prefix_kernel(const double *__restrict__ band_in, double *__restrict__ band_out, int64_t n, int W,
-                        const double *__restrict__ diag_stats, int chunk, int nseg, int nd, int items_per_wg) {
+                        const double *__restrict__ diag_stats, int nseg, int nd, int items_per_wg) {
     extern __shared__ __align__(16) double lds[];
-    __shared__ double w1[kThreads / 64], w2[kThreads / 64];
-    __shared__ int wc[kThreads / 64];
+    __shared__ double w1[kPThreads / 64], w2[kPThreads / 64];
+    __shared__ int wc[kPThreads / 64];
     const int64_t total = (int64_t)nseg * nd;
     const int64_t first = (int64_t)blockIdx.x * items_per_wg;
-    for (int64_t item = first; item < first + items_per_wg && item < total; ++item) {
-        normalize_prefix_item(band_in, band_out, n, W, diag_stats, chunk, nseg, item, lds, w1, w2, wc);
+    const int64_t last = first + items_per_wg < total ? first + items_per_wg : total;
+    double r[CHUNK];
+    if (first < last) normalize_prefix_fetch<CHUNK>(band_in, n, W, nseg, first, r);
+    for (int64_t item = first; item < last; ++item) {
+        normalize_prefix_item<CHUNK>(band_in, band_out, n, W, diag_stats, nseg, item, item + 1 < last ? item + 1 : -1, r,
+                              lds, w1, w2, wc);
         __syncthreads();                               // the LDS arrays are reused by the next item
     }
 }
@@ -499,24 +548,29 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
     diag_stats_kernel<<<nd, kThreads, 0, s>>>(band_in, n, diag_stats);
     MST_LAUNCH_CHECK();
     if (local && window >= 2) {
-        // default: prefix-sum kernel, as long as its tile (2 doubles + 1 int per sample) leaves room for two workgroups per CU
+        // default: prefix-sum kernel, as long as its tile (2 doubles + 1 int per sample, + the segment) fits the LDS
         const int tile = kPSeg + window - 1;
-        const int chunk = ((tile + 1 + kThreads - 1) / kThreads) | 1;    // samples per thread, odd
-        const size_t plds = (sizeof(double) * 2 + sizeof(int)) * (size_t)kThreads * chunk + 16;
-        if (plds <= 80 * 1024 && !getenv("MST_NORMALIZE_BLOCKED")) {
-            static bool pattr_set = false;
-            if (!pattr_set) {
-                MST_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&normalize_prefix_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-                pattr_set = true;
-            }
+        const int chunk = ((tile + 1 + kPThreads - 1) / kPThreads) | 1;  // samples per thread, odd
+        const size_t plds = (sizeof(double) * 2 + sizeof(int)) * (size_t)kPThreads * chunk + sizeof(double) * kPSeg + 16;
+        if (plds <= 80 * 1024 && chunk <= kPMaxChunk && !getenv("MST_NORMALIZE_BLOCKED")) {
             const int nseg = (int)((n + kPSeg - 1) / kPSeg);            // covers [0, n): the kernel also writes the zero tails
             const int64_t total = (int64_t)nseg * nd;
             const int64_t want_wgs = 256 * 2 * 8;                        // 8 waves of workgroups over 256 CUs x 2 resident
             const int ipw = (int)((total + want_wgs - 1) / want_wgs);
             const int64_t wgs = (total + ipw - 1) / ipw;
-            normalize_prefix_kernel<<<(unsigned)wgs, kThreads, plds, s>>>(band_in, band_out, n, window, diag_stats, chunk,
-                                                                         nseg, nd, ipw);
+#define MST_PREFIX_CASE(C_)                                                                                            \
+    case C_:                                                                                                           \
+        MST_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&normalize_prefix_kernel<C_>),                      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                           \
+        normalize_prefix_kernel<C_><<<(unsigned)wgs, kPThreads, plds, s>>>(band_in, band_out, n, window, diag_stats,  \
+                                                                          nseg, nd, ipw);                            \
+        break;
+            switch (chunk) {
+                MST_PREFIX_CASE(1) MST_PREFIX_CASE(3) MST_PREFIX_CASE(5) MST_PREFIX_CASE(7) MST_PREFIX_CASE(9)
+                MST_PREFIX_CASE(11) MST_PREFIX_CASE(13) MST_PREFIX_CASE(15) MST_PREFIX_CASE(17)
+                default: return mst::fail(MST_E_ARG, "mst_normalize_band: internal chunk %d", chunk);
+            }
+#undef MST_PREFIX_CASE
             MST_LAUNCH_CHECK();
             return MST_OK;
         }

@@ -242,7 +242,21 @@ def main():
         torch.cuda.synchronize()
         out["chr21_5kb"] = {"value": round(w5.total_mpix / ((time.time() - t0) / 10), 1), "unit": "Mpix/s",
                             "blocks": len(w5.start), "chunk": w5.CH}
-        del w5
+        # two-sample path (diff_mustache.py:260-569) on the same shape: both samples' blocks, the sigma
+        # loops of both, the difference image with its own blurs, the pair p-values, BH, records on the host
+        from mustache_amd.diff_mustache import _pairs_from_filled
+        band_b, _ = make_band(9630, 400, 260.0, 300, 7, 5000, device)
+        for _ in range(2):
+            _pairs_from_filled(w5.pipe.engine, w5.pipe, [w5.band, band_b], w5.n, w5.dpx, w5.start, w5.CH)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(5):
+            _pairs_from_filled(w5.pipe.engine, w5.pipe, [w5.band, band_b], w5.n, w5.dpx, w5.start, w5.CH)
+        torch.cuda.synchronize()
+        out["diff_chr21_5kb"] = {"value": round(w5.total_mpix / ((time.time() - t0) / 5), 1), "unit": "Mpix-pairs/s",
+                                 "block_pairs": len(w5.start), "chunk": w5.CH,
+                                 "note": "two-sample caller, rows 3-7 for both samples + difference image + pair p-values"}
+        del w5, band_b
     if rank == 0 and world == 1:
         # informational: the whole per-chromosome run from the normalised band (rows 2-9, empty tiles skipped as the
         # pipeline does by default), next to the untimed normalisation -- NOT part of `value`

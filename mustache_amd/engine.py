@@ -175,6 +175,7 @@ class ScaleSpaceEngine:
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.levels = LevelTable(octave_values, s)
         self._select_cap = 4096
+        self._side_streams = None
         self._lv_struct = self.levels.as_struct()
         self._found_cap = {}
         self._pin = {}
@@ -229,13 +230,17 @@ class ScaleSpaceEngine:
         `timing`: optional list; receives a (start, end) torch.cuda.Event pair bracketing the mst_scale_space launch
         on the launch stream.  `band_src` = (band, n, dpx, starts, CH) selects the band-direct kernel (c, nz unused;
         nz_count is then an OUTPUT)."""
+        st = self._ss_launch(c, nz, nz_count, skip_empty, found_cap, timing, fma, band_src)
+        return self._ss_results(self._ss_finish(st), download, sort, with_value, with_q, select_below)
+
+    def _ss_launch(self, c, nz, nz_count, skip_empty, found_cap, timing, fma, band_src):
+        """Allocate the outputs and enqueue the fused kernel on the current stream (no synchronisation)."""
         if band_src is not None:
             band, bn, bdpx, bstarts, CH = band_src
             B = len(bstarts)
             st_arr = (ctypes.c_int64 * B)(*bstarts)
         else:
             B, CH, _ = c.shape
-        nt = self.levels.n_tested
         if found_cap is None:
             found_cap = self._found_cap.get(CH, max(4096, (CH * CH) // 32))
         lv = ctypes.byref(self._lv_struct)
@@ -245,31 +250,47 @@ class ScaleSpaceEngine:
             stats = torch.empty((B, _lib.MST_MAX_TESTED, 2), dtype=torch.float64, device=self.device)
             fit = torch.empty((B, _lib.MST_MAX_TESTED, 2), dtype=torch.float64, device=self.device)
             count = torch.empty(B, dtype=torch.int32, device=self.device)
+            found = torch.empty((B, found_cap, 2), dtype=torch.int64, device=self.device)  # 16-byte records
+            pval = torch.empty((B, found_cap), dtype=torch.float64, device=self.device)
+            ev = None
+            if timing is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            flags = (1 if skip_empty else 0) | (2 if fma else 0)
+            if band_src is not None:
+                _lib.check(self.lib.mst_scale_space_band(_ptr(band), bn, bdpx, st_arr, B, CH, lv, _ptr(found),
+                                                         found_cap, _ptr(count), _ptr(stats), _ptr(nz_count), flags,
+                                                         _ptr(ws), ws_bytes, _stream()))
+            else:
+                _lib.check(self.lib.mst_scale_space(_ptr(c), _ptr(nz), B, CH, lv, _ptr(found), found_cap,
+                                                    _ptr(count), _ptr(stats), flags, _ptr(ws), ws_bytes, _stream()))
+            if ev is not None:
+                ev[1].record()
+        return dict(args=(c, nz, nz_count, skip_empty, timing, fma, band_src), B=B, CH=CH, found_cap=found_cap, ws=ws,
+                    stats=stats, fit=fit, count=count, found=found, pval=pval, ev=ev)
+
+    def _ss_finish(self, st):
+        """p-values of the found pixels (synchronises the launch stream); a record-capacity overflow re-runs the kernel."""
+        nt = self.levels.n_tested
+        with torch.cuda.device(self.device):
             while True:
-                found = torch.empty((B, found_cap, 2), dtype=torch.int64, device=self.device)  # 16-byte records
-                pval = torch.empty((B, found_cap), dtype=torch.float64, device=self.device)
-                if timing is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                flags = (1 if skip_empty else 0) | (2 if fma else 0)
-                if band_src is not None:
-                    _lib.check(self.lib.mst_scale_space_band(_ptr(band), bn, bdpx, st_arr, B, CH, lv, _ptr(found),
-                                                             found_cap, _ptr(count), _ptr(stats), _ptr(nz_count), flags,
-                                                             _ptr(ws), ws_bytes, _stream()))
-                else:
-                    _lib.check(self.lib.mst_scale_space(_ptr(c), _ptr(nz), B, CH, lv, _ptr(found), found_cap,
-                                                        _ptr(count), _ptr(stats), flags, _ptr(ws), ws_bytes, _stream()))
-                if timing is not None:
-                    e1.record()
                 try:
-                    _lib.check(self.lib.mst_found_pvalues(_ptr(found), found_cap, _ptr(count), _ptr(nz_count),
-                                                          _ptr(stats), B, nt, _ptr(pval), _ptr(fit), _stream()))
+                    _lib.check(self.lib.mst_found_pvalues(_ptr(st["found"]), st["found_cap"], _ptr(st["count"]),
+                                                          _ptr(st["args"][2]), _ptr(st["stats"]), st["B"], nt,
+                                                          _ptr(st["pval"]), _ptr(st["fit"]), _stream()))
                     break
                 except _lib.MstOverflow:
-                    found_cap *= 4          # rare: a block with an unusually dense set of local maxima
-                    self._found_cap[CH] = found_cap
-            if timing is not None:
-                timing.append((e0, e1))     # mst_found_pvalues synchronised the stream: the events are complete
+                    c, nz, nz_count, skip_empty, timing, fma, band_src = st["args"]
+                    cap = st["found_cap"] * 4   # rare: a block with an unusually dense set of local maxima
+                    self._found_cap[st["CH"]] = cap
+                    st = self._ss_launch(c, nz, nz_count, skip_empty, cap, timing, fma, band_src)
+        if st["ev"] is not None:
+            st["args"][4].append(st["ev"])      # mst_found_pvalues synchronised the stream: the events are complete
+        return st
+
+    def _ss_results(self, st, download, sort, with_value, with_q, select_below):
+        found, pval, count, fit, found_cap = st["found"], st["pval"], st["count"], st["fit"], st["found_cap"]
+        nt = self.levels.n_tested
         if not download:
             return found, pval, count, fit, found_cap
         if select_below is not None:
@@ -277,6 +298,42 @@ class ScaleSpaceEngine:
                                            float(select_below))
         extra = {"q": self.fdr(pval, count, found_cap)} if with_q else None
         return self._download(found, pval, count, fit, nt, sort=sort, with_value=with_value, extra=extra)
+
+    def sigma_loop_band_overlapped(self, band, n, dpx, groups, CH, skip_empty=True, timing=None, fma=False, download=True,
+                                   sort=True, with_value=True, with_q=True, select_below=None):
+        """sigma_loop_band over several groups of blocks with copy/compute overlap: the groups' fused kernels run back
+        to back on two alternating side streams, and the p-values / BH / selection / download of group i run while the
+        kernel of group i + 1 is executing.  Yields, per group, what sigma_loop_band returns."""
+        cur = torch.cuda.current_stream(self.device)
+        ready = cur.record_event()              # the band was produced on the caller's stream
+        if self._side_streams is None:
+            self._side_streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+
+        def finish(st):
+            with torch.cuda.stream(st["stream"]):
+                st2 = self._ss_finish(st)
+                res = self._ss_results(st2, download, sort, with_value, with_q, select_below)
+            return res + (st["nzc"],)
+
+        pending = None
+        for gi, starts in enumerate(groups):
+            s = self._side_streams[gi % 2]
+            s.wait_event(ready)
+            if pending is not None:
+                s.wait_event(pending["kernel_done"])        # one fused kernel at a time
+            with torch.cuda.stream(s):
+                nzc = torch.empty(len(starts), dtype=torch.int32, device=self.device)
+                st = self._ss_launch(None, None, nzc, skip_empty, None, timing, fma,
+                                     (band, int(n), int(dpx), [int(v) for v in starts], int(CH)))
+                st["kernel_done"] = s.record_event()
+            st["stream"], st["nzc"] = s, nzc
+            if pending is not None:
+                yield finish(pending)
+            pending = st
+        if pending is not None:
+            yield finish(pending)
+        cur.wait_stream(self._side_streams[0])
+        cur.wait_stream(self._side_streams[1])
 
     def fdr(self, pval, count, found_cap):
         """Benjamini-Hochberg q-values per block on the device (reference mustache.py:778); same record order as pval."""

@@ -32,6 +32,7 @@ class ChromosomePipeline:
         self.engine = ScaleSpaceEngine(octave_values, device=device)
         self.device = self.engine.device
         self.max_batch_bytes = max_batch_bytes
+        self.overlap_blocks = 16        # blocks per fused-kernel launch on the band path (copy / host-tail overlap)
 
     # ---- device stages --------------------------------------------------------------------------------------------
     def blocks_from_band(self, band, n, dpx, starts, CH):
@@ -61,31 +62,44 @@ class ChromosomePipeline:
         mine = shard_blocks(len(start), rank, ws)
         loops = []
         t_dev = t_tail = 0.0
-        for group in self.batches(mine, CH, dense):
-            t0 = time.time()
-            starts_g = [start[i] for i in group]
-            if dense:       # materialise [B, CH, CH] blocks first (what mustache() gets from its caller) -- cross-check path
-                c, nz, nzc = self.blocks_from_band(band, n, dpx, starts_g, CH)
-                found, fits = self.engine.sigma_loop(c, nz, nzc, skip_empty=skip_empty, with_value=False,
-                                                     select_below=pt)
-                batch = BlockBatch(self.engine, c, nz, CH, len(group),
-                                   nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
-            else:           # default: blocks are windows of the band, cut inside the fused kernel
-                c = nz = None
-                found, fits, nzc = self.engine.sigma_loop_band(band, n, dpx, starts_g, CH, skip_empty=skip_empty,
-                                                               with_value=False, select_below=pt)
-                batch = BandBatch(self.engine, band, n, dpx, starts_g, CH,
-                                  nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
-            t1 = time.time()
+
+        def tail(batch, group, starts_g):
             tails = batch_tail(batch, list(range(len(group))), starts_g, pt, st, intra=True)
             for j, i in enumerate(group):
                 mask = block_mask_size(i, start, end, dpx)
                 for lp in tails[j]:
                     if lp[0] >= start[i] + mask or lp[1] >= start[i] + mask:      # mustache.py:957-959
                         loops.append([lp[0], lp[1], lp[2], lp[3]])
-            t_dev += t1 - t0
-            t_tail += time.time() - t1
-            del c, nz, batch
+
+        if dense:           # materialise [B, CH, CH] blocks first (what mustache() gets from its caller) -- cross-check path
+            for group in self.batches(mine, CH, dense):
+                t0 = time.time()
+                starts_g = [start[i] for i in group]
+                c, nz, nzc = self.blocks_from_band(band, n, dpx, starts_g, CH)
+                found, fits = self.engine.sigma_loop(c, nz, nzc, skip_empty=skip_empty, with_value=False,
+                                                     select_below=pt)
+                batch = BlockBatch(self.engine, c, nz, CH, len(group),
+                                   nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
+                t1 = time.time()
+                tail(batch, group, starts_g)
+                t_dev += t1 - t0
+                t_tail += time.time() - t1
+                del c, nz, batch
+        else:
+            # default: blocks are windows of the band, cut inside the fused kernel.  The blocks go through it in groups of
+            # `overlap_blocks`; BH + selection + download AND the host tail of one group run under the kernel of the next
+            groups = [mine[i:i + self.overlap_blocks] for i in range(0, len(mine), self.overlap_blocks)]
+            starts = [[start[i] for i in g] for g in groups]
+            t0 = time.time()
+            for group, starts_g, (found, fits, nzc) in zip(groups, starts, self.engine.sigma_loop_band_overlapped(
+                    band, n, dpx, starts, CH, skip_empty=skip_empty, with_value=False, select_below=pt)):
+                t1 = time.time()
+                batch = BandBatch(self.engine, band, n, dpx, starts_g, CH,
+                                  nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
+                tail(batch, group, starts_g)
+                t_tail += time.time() - t1
+                del batch
+            t_dev = time.time() - t0 - t_tail
         if timings is not None:
             timings.update(scale_space_s=t_dev, tail_s=t_tail, blocks=len(mine), chunk=CH,
                            mpix=len(mine) * CH * CH / 1e6)

@@ -13,7 +13,8 @@ out_md = os.path.join("profiles", tag + "_summary.md")
 lines = ["# rocprofv3 summary `%s`" % tag, "",
          "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu` "
          "(scripts/profile_bench.sh); PMC passes: `rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --small "
-         "--steps 1 --warmup 0 --no-cpu` (12 blocks of 4000x4000), one pass per counter group.", ""]
+         "--steps 1 --warmup 0 --no-cpu` with `MST_BENCH_OVERLAP=1` (12 blocks of 4000x4000 in ONE launch), one pass per counter "
+         "group.  The traced run uses bench.py's default of 4 launches per step (31 blocks each) on alternating streams.", ""]
 
 # ---- kernel stats ------------------------------------------------------------------------------------------------
 st = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))

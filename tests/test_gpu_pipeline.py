@@ -310,3 +310,31 @@ def test_device_selection_equals_host_selection():
         for (la, sa), (lb, sb) in zip(fits, fits2):
             assert np.array_equal(la, lb) and np.array_equal(sa, sb)
     assert pipe.engine._select_cap > 64
+
+
+def test_overlapped_launches_equal_one_launch():
+    """sigma_loop_band_overlapped (groups of blocks on alternating streams, post-processing of one group under the kernel
+    of the next) returns, group by group, exactly what one sigma_loop_band call over all blocks returns."""
+    import torch
+    from mustache_amd.normalize import band_from_coo, normalize_band
+    from mustache_amd.pipeline import ChromosomePipeline, block_tiling
+    from mustache_amd.synth import synth_coo
+    n, dpx, res = 7400, 400, 5000
+    x, y, v = synth_coo(n, dpx, depth=60.0, seed=44)
+    pipe = ChromosomePipeline(OCT)
+    band = band_from_coo(*(torch.from_numpy(a).to(pipe.device) for a in (x, y, v)), n, dpx)
+    band, _, _ = normalize_band(band, n, dpx, res)
+    CH, start, end = block_tiling(n, dpx)
+    assert len(start) >= 5
+    one, fits, nzc = pipe.engine.sigma_loop_band(band, n, dpx, start, CH)
+    one = [{k: a[k].copy() for k in a} for a in one]                      # the arrays are views of reused pinned buffers
+    groups = [start[0:2], start[2:3], start[3:]]
+    b = 0
+    for starts_g, (recs, fits_g, nzc_g) in zip(groups, pipe.engine.sigma_loop_band_overlapped(band, n, dpx, groups, CH)):
+        assert torch.equal(nzc_g, nzc[b:b + len(starts_g)])
+        for j in range(len(starts_g)):
+            for k in ("pixel", "level", "value", "pval", "q"):
+                assert np.array_equal(recs[j][k], one[b + j][k]), (b + j, k)
+            assert np.array_equal(fits_g[j][0], fits[b + j][0]) and np.array_equal(fits_g[j][1], fits[b + j][1])
+        b += len(starts_g)
+    assert b == len(start)

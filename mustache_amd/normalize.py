@@ -2,8 +2,6 @@
 
 Device layout: the diagonal-major band (see csrc/mst_band.hip).  `normalize_band` works on device tensors and is
 what the pipeline uses; `normalize_sparse_device` is the drop-in with the reference's host-array signature."""
-import ctypes
-
 import numpy as np
 import torch
 

@@ -4,8 +4,6 @@ Mirrors reference mustache/mustache.py:774-850 on the compacted "found" records 
 pixels per block), so no dense CH x CH array is ever built on the host.  The window densities, c[x, y] and the
 diagonals come from small device gathers (BlockBatch.candidate_features / .diagonals).
 """
-import math
-
 import numpy as np
 
 

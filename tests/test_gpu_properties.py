@@ -8,9 +8,9 @@ pytestmark = pytest.mark.gpu
 def _normalised_block(n, dpx, seed, res):
     """A dense near-diagonal block cut from a synthetic chromosome, normalised on the GPU."""
     import torch
-    from mustache_amd.normalize import band_from_coo, normalize_band
+    from mustache_amd.normalize import normalize_band
     from mustache_amd.pipeline import ChromosomePipeline
-    from mustache_amd.synth import band_counts, band_to_coo
+    from mustache_amd.synth import band_counts
     dev = "cuda"
     N = n + dpx
     band = band_counts(N, dpx, 300.0, max(N // 32, 1), seed, device=dev)

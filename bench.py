@@ -116,23 +116,30 @@ def _dense_raw_block(w, block_index):
 
 def _oracle_block(args):
     """one block through the oracle's rows 3-7 (runs in a worker process for the -p 4 leg)"""
-    c, dpx = args
+    c, dpx, want_set = args
+    import numpy as np
     import oracle
     t0 = time.time()
     nz = oracle.block_prologue(c, dpx)
     ss = oracle.scale_space_levels(c, nz, [1.6, 3.2], blur="scipy")
-    return time.time() - t0, int((ss.pval != 2).sum()), int(nz.sum())
+    dt = time.time() - t0
+    # (after the clock) the found set in the GPU records' terms: row-major pixel index, 1-based tested level, vAll, p-value
+    hit = ss.pval != 2
+    if not want_set:
+        return dt, int(hit.sum()), int(nz.sum()), None
+    pix = np.flatnonzero(nz.ravel())[hit].astype(np.uint32)
+    return dt, int(hit.sum()), int(nz.sum()), (pix, ss.level[hit].astype(np.uint32), ss.best[hit], ss.pval[hit])
 
 
 def cpu_baseline(w, block_index):
     """The oracle (reference arithmetic: SciPy gaussian_filter / maximum_filter / expm1) on one block, 1 core."""
-    return _oracle_block((_dense_raw_block(w, block_index), w.dpx))
+    return _oracle_block((_dense_raw_block(w, block_index), w.dpx, True))
 
 
 def cpu_baseline_p4(w, block_indices):
     """The reference's default parallelism (-p 4, mustache.py:146): 4 blocks in 4 processes at once."""
     import multiprocessing as mp
-    blocks = [(_dense_raw_block(w, i), w.dpx) for i in block_indices]
+    blocks = [(_dense_raw_block(w, i), w.dpx, False) for i in block_indices]
     ctx = mp.get_context("spawn")
     t0 = time.time()
     with ctx.Pool(len(blocks)) as pool:
@@ -279,16 +286,20 @@ def main():
                              "note": "synthetic chr1@1kb from the normalised band to the final loop list, 1 GPU"}
     if rank == 0 and world == 1 and not args.no_cpu:
         bi = len(w.start) // 2
-        cpu_s, cpu_found, cpu_nz = cpu_baseline(w, bi)
-        found_gpu = None
-        for grp, res in zip(w.groups, last):
-            if bi in grp:
-                found_gpu = len(res[0][grp.index(bi)]["pixel"])
+        import numpy as np
+        cpu_s, cpu_found, cpu_nz, (cpix, clvl, cval, cp) = cpu_baseline(w, bi)
+        # the same block alone through the HIP path, records ordered by pixel: the checker compares the whole found set
+        g = w.pipe.engine.sigma_loop_band(w.band, w.n, w.dpx, [w.start[bi]], w.CH, skip_empty=False, with_q=False)[0][0]
+        found_gpu = len(g["pixel"])
+        same = (found_gpu == cpu_found and np.array_equal(g["pixel"], cpix) and np.array_equal(g["level"], clvl)
+                and np.array_equal(g["value"], cval))
+        p_err = float(np.max(np.abs(g["pval"] - cp) / np.maximum(cp, 1e-300))) if same and found_gpu else None
         out["cpu_baseline"] = {"value": round(w.CH * w.CH / 1e6 / cpu_s, 4), "unit": "Mpix/s", "cores": 1,
                                "kind": "port",
                                "sample": "block %d of the same workload (one 4000x4000 block, %.1f s), rows 3-7 of the "
                                          "oracle = the reference's SciPy calls, single process" % (bi, cpu_s),
                                "found_pixels_cpu": cpu_found, "found_pixels_gpu": found_gpu,
+                               "found_set_pixels_levels_values_identical": bool(same), "pvalue_max_rel_err": p_err,
                                "cpu_model": _cpu_model(), "host_cores": os.cpu_count()}
         out["speedup_vs_cpu_1core"] = round(value / out["cpu_baseline"]["value"], 1)
         wall4, _ = cpu_baseline_p4(w, [bi - 2, bi - 1, bi + 1, bi + 2])

@@ -150,6 +150,30 @@ def make_block(ref, name, n, dpx, seed, start, st, pt, depth=300.0, nloops=None,
           "pzero", int((locs["pAll"] == 0).sum()) if "pAll" in locs else None)
 
 
+def make_big_block(ref):
+    """One block of BASELINE's 5 kb geometry (2000 x 2000, distance limit 400 px).  The input is the raw synthetic map
+    (regenerated from the seed by the tests, so only its checksum is stored) and the outputs are kept compact: loops,
+    the 18 expon fits, per-level Gaussian sums, and order-independent checksums of the found set."""
+    n, dpx, seed, start, st, pt = 2000, 400, 3, 3200, 0.8, 0.1
+    x, y, v = synth_coo(n, dpx, depth=300.0, seed=seed)
+    c = dense(x, y, v, n)
+    loops, cap, locs = run_mustache_traced(ref, c, start, dpx, st, pt)
+    nz = locs["nz"]
+    found = locs["pAll"] != 2
+    pix = np.flatnonzero(nz.ravel())[found].astype(np.int64)
+    sig = locs["Scales"][found]
+    np.savez_compressed(os.path.join(HERE, "block_2000.npz"), n=n, dpx=dpx, seed=seed, depth=300.0, start=start, st=st,
+                        pt=pt, in_nnz=len(v), in_checksum=float(v.sum()), nz_count=int(nz.sum()),
+                        loops=loops_array(loops), fit=np.array(cap["fit"]).reshape(-1, 3),
+                        g_sum=np.array([g[2] for g in cap["gauss"]]), found_count=int(found.sum()),
+                        found_pixel_sum=int(pix.sum()), found_pixel_xor=int(np.bitwise_xor.reduce(pix)),
+                        found_sigma_sum=float(np.sum(sig)), found_value_sum=float(np.sum(locs["vAll"][found])),
+                        found_value_max=float(np.max(locs["vAll"][found])),
+                        found_pvalue_sum=float(np.sum(locs["pAll"][found])),
+                        found_pixels_head=pix[:4096].astype(np.int32), found_values_head=locs["vAll"][found][:4096])
+    print("block_2000 nz", int(nz.sum()), "found", int(found.sum()), "loops", len(loops))
+
+
 def make_edges(ref):
     # < 50 tested pixels -> [] (mustache.py:701); 50 <= nz < 10000 -> [] (mustache.py:775)
     n, dpx = 200, 60
@@ -313,12 +337,14 @@ if __name__ == "__main__":
         make_diff()
         sys.exit(0)
     ref = load_reference("mustache")
-    which = sys.argv[1:] or ["norm", "blocks", "edges", "tiling", "regulator"]
+    which = sys.argv[1:] or ["norm", "blocks", "big", "edges", "tiling", "regulator"]
     if "norm" in which:
         make_normalize(ref)
     if "blocks" in which:
         make_block(ref, "block_320", 320, 80, seed=1, start=1600, st=0.8, pt=0.2, nloops=30)
         make_block(ref, "block_512", 512, 128, seed=2, start=0, st=0.7, pt=0.2, depth=200.0, nloops=40)
+    if "big" in which:
+        make_big_block(ref)
     if "edges" in which:
         make_edges(ref)
     if "tiling" in which:

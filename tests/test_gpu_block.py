@@ -146,3 +146,42 @@ def test_device_bh_equals_numpy_bh(eng, golden_dir):
     assert "q" in found
     assert np.array_equal(found["q"], benjamini_hochberg(found["pval"]))
     np.testing.assert_allclose(found["q"], g["bh_out"], rtol=1e-9)
+
+
+def _big_block(g):
+    from mustache_amd.synth import synth_coo
+    n, dpx = int(g["n"]), int(g["dpx"])
+    x, y, v = synth_coo(n, dpx, depth=float(g["depth"]), seed=int(g["seed"]))
+    assert len(v) == int(g["in_nnz"]) and v.sum() == float(g["in_checksum"]), "synthetic generator drifted"
+    c = np.zeros((n, n))
+    c[x, y] = v
+    return c, n, dpx
+
+
+def test_baseline_size_block_vs_reference_fixture(eng, golden_dir):
+    """BASELINE's 5 kb block geometry (2000 x 2000, distance limit 400 px) against outputs of the REFERENCE ITSELF
+    (tests/golden/block_2000.npz, made by make_golden.py): tested-pixel count, the whole found set through order-independent
+    checksums plus its first 4096 records, the 18 expon fits, and the final loop list of the drop-in mustache()."""
+    from mustache_amd.mustache import mustache
+    g = _load(golden_dir, "block_2000.npz")
+    c, n, dpx = _big_block(g)
+    dev, nz_d, nzc, found, fit = _run_block(eng, c.copy(), dpx, True)
+    assert nzc == int(g["nz_count"])
+    pix = found["pixel"].astype(np.int64)
+    assert len(pix) == int(g["found_count"])
+    assert int(pix.sum()) == int(g["found_pixel_sum"]) and int(np.bitwise_xor.reduce(pix)) == int(g["found_pixel_xor"])
+    assert np.array_equal(pix[:4096], g["found_pixels_head"].astype(np.int64))
+    assert np.array_equal(found["value"][:4096], g["found_values_head"])
+    assert float(np.max(found["value"])) == float(g["found_value_max"])
+    sig = np.asarray(eng.levels.tested_sigma)[found["level"].astype(int) - 1]
+    np.testing.assert_allclose(float(np.sum(sig)), float(g["found_sigma_sum"]), rtol=1e-13)
+    np.testing.assert_allclose(float(np.sum(found["value"])), float(g["found_value_sum"]), rtol=1e-12)
+    assert np.array_equal(fit[0], g["fit"][:, 0])
+    np.testing.assert_allclose(fit[1], g["fit"][:, 1], rtol=1e-12)
+    start = int(g["start"])
+    loops = mustache(c, "1", "1", 5000, [], start, start + n, 0, dpx, OCT, float(g["st"]), float(g["pt"]))
+    exp = g["loops"]
+    got = np.array([[float(a), float(b), q, s] for a, b, q, s in loops])
+    assert got.shape == exp.shape and len(exp) > 100
+    assert np.array_equal(got[:, :2], exp[:, :2]) and np.array_equal(got[:, 3], exp[:, 3])
+    np.testing.assert_allclose(got[:, 2], exp[:, 2], rtol=1e-9)

@@ -168,3 +168,29 @@ def test_diff_block_vs_reference(golden_dir):
         arr = np.array([[float(a), float(b), q, s] for a, b, q, s in got]).reshape(-1, 4)
         assert np.array_equal(arr, g[key]), key
     assert len(g["loops1"]) > 5 and len(g["diff1"]) > 0
+
+
+@pytest.mark.slow
+def test_baseline_size_block_vs_reference(golden_dir):
+    """The oracle on BASELINE's 5 kb block geometry (2000 x 2000, dpx 400) against the reference's own outputs
+    (block_2000.npz): fits, found-set checksums, loops -- bit for bit."""
+    from mustache_amd.synth import synth_coo
+    g = _load(golden_dir, "block_2000.npz")
+    n, dpx = int(g["n"]), int(g["dpx"])
+    x, y, v = synth_coo(n, dpx, depth=float(g["depth"]), seed=int(g["seed"]))
+    assert len(v) == int(g["in_nnz"]) and v.sum() == float(g["in_checksum"])
+    c = np.zeros((n, n))
+    c[x, y] = v
+    loops, mid = oracle.mustache_block(c, int(g["start"]), dpx, OCT, float(g["st"]), float(g["pt"]), return_intermediate=True)
+    ss = mid["ss"]
+    assert int(mid["nz"].sum()) == int(g["nz_count"])
+    assert np.array_equal(np.array([t["loc"] for t in ss.tested]), g["fit"][:, 0])
+    assert np.array_equal(np.array([t["scale"] for t in ss.tested]), g["fit"][:, 1])
+    found = ss.pval != 2
+    pix = np.flatnonzero(mid["nz"].ravel())[found].astype(np.int64)
+    assert len(pix) == int(g["found_count"]) and int(pix.sum()) == int(g["found_pixel_sum"])
+    assert int(np.bitwise_xor.reduce(pix)) == int(g["found_pixel_xor"])
+    assert float(np.sum(ss.best[found])) == float(g["found_value_sum"])
+    assert float(np.sum(ss.scale[found])) == float(g["found_sigma_sum"])
+    got = np.array([[float(a), float(b), q_, s_] for a, b, q_, s_ in loops]).reshape(-1, 4)
+    assert np.array_equal(got, g["loops"])

@@ -338,3 +338,27 @@ def test_overlapped_launches_equal_one_launch():
             assert np.array_equal(fits_g[j][0], fits[b + j][0]) and np.array_equal(fits_g[j][1], fits[b + j][1])
         b += len(starts_g)
     assert b == len(start)
+
+
+@pytest.mark.parametrize("n,dpx,res,depth", [(4600, 2000, 1000, 3.0), (9630, 400, 5000, 40.0), (2300, 150, 2000, 20.0)])
+def test_normalisation_kernel_vs_oracle_at_real_window_sizes(n, dpx, res, depth):
+    """mst_normalize_band (prefix-sum kernel: several segments per diagonal, windows 2000 / 400 / 1000 = the 1 kb, 5 kb and 2 kb
+    cases, sparse and dense diagonals) against the oracle's restatement of normalize_sparse: 1e-9 (the reference's own
+    window sums depend on the BLAS build), and the blocked-sum fallback kernel gives the same."""
+    import oracle
+    from mustache_amd.mustache import normalize_sparse
+    from mustache_amd.synth import synth_coo
+    x, y, v = synth_coo(n, dpx, depth=depth, seed=9)
+    exp = v.copy()
+    oracle.normalize_sparse(x, y, exp, res, dpx)
+    got = v.copy()
+    normalize_sparse(x, y, got, res, dpx)
+    np.testing.assert_allclose(got, exp, rtol=1e-9, atol=1e-9)
+    assert np.count_nonzero(got) > 0.9 * len(got)
+    os.environ["MST_NORMALIZE_BLOCKED"] = "1"
+    try:
+        alt = v.copy()
+        normalize_sparse(x, y, alt, res, dpx)
+    finally:
+        del os.environ["MST_NORMALIZE_BLOCKED"]
+    np.testing.assert_allclose(alt, exp, rtol=1e-9, atol=1e-9)

@@ -193,12 +193,13 @@ def normalize_sparse(x, y, v, resolution, distance_in_px):
 # per-chromosome driver (reference mustache.py:853-942)
 # --------------------------------------------------------------------------------------------------------------
 def call_loops_coo(x, y, v, res, distance_in_px, octave_values, st, pt, chromosome='n', chromosome2=None,
-                   verbose=True, normalized=False, timings=None):
+                   verbose=True, normalized=False, timings=None, distributed=True):
     """regulator's body after the reader: normalise, tile, run every block, de-duplicate the overlaps.
     x, y, v are host arrays (the reference's COO).  Returns the reference's list of [x, y, fdr, sigma]."""
     from .pipeline import ChromosomePipeline
     pipe = ChromosomePipeline(octave_values)
-    return pipe.run(x, y, v, res, distance_in_px, st, pt, normalized=normalized, verbose=verbose, timings=timings)
+    return pipe.run(x, y, v, res, distance_in_px, st, pt, normalized=normalized, verbose=verbose, timings=timings,
+                    distributed=distributed)
 
 
 def _check_pair(f, chromosome, chromosome2):
@@ -240,10 +241,11 @@ def read_contacts(f, norm_method, CHRM_SIZE, res, distance_filter, bias, chromos
 
 def regulator(f, norm_method, CHRM_SIZE, outdir, bed="", res=5000, sigma0=1.6, s=10, pt=0.1, st=0.88, octaves=2,
               verbose=True, nprocesses=4, distance_filter=2000000, bias=False, chromosome='n', chromosome2=None,
-              contacts=None):
+              contacts=None, shard_blocks=True):
     """Loop calling for one chromosome (reference mustache.py:853-942).  `s` is accepted and ignored like in the
     reference (s = 10 is hard-wired at :711); `nprocesses` is ignored: all blocks run as one GPU batch.
-    `contacts` (not in the reference): what read_contacts() returned for this chromosome, when the caller read ahead."""
+    `contacts` (not in the reference): what read_contacts() returned for this chromosome, when the caller read ahead;
+    `shard_blocks=False`: in a multi-GPU job this rank runs the whole chromosome alone (whole-genome sharding by chromosome)."""
     chromosome2 = _check_pair(f, chromosome, chromosome2)
     octave_values = [sigma0 * (2 ** i) for i in range(octaves)]
     if contacts is None:
@@ -252,7 +254,8 @@ def regulator(f, norm_method, CHRM_SIZE, outdir, bed="", res=5000, sigma0=1.6, s
             return []
     x, y, v, res = contacts
     distance_in_px = int(math.ceil(distance_filter // res))
-    return call_loops_coo(x, y, v, res, distance_in_px, octave_values, st, pt, chromosome, chromosome2, verbose=verbose)
+    return call_loops_coo(x, y, v, res, distance_in_px, octave_values, st, pt, chromosome, chromosome2, verbose=verbose,
+                          distributed=shard_blocks)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -384,14 +387,29 @@ def main(argv=None):
         except BaseException as e:          # re-raised in the main thread, at this chromosome's turn
             return e
 
+    # Multi-GPU: a single chromosome (or fewer chromosomes than GPUs) is sharded by BLOCKS, every rank reading the same
+    # input; a whole-genome run is sharded by CHROMOSOME (largest first, sharding.assign_chromosomes), each rank reading and
+    # running only its own -- small chromosomes would otherwise be cut into launches of a few blocks per GPU.
+    by_chromosome = _world > 1 and len(pairs) >= _world
+    mine = list(range(len(pairs)))
+    if by_chromosome:
+        from .readers import chromosome_sizes
+        from .sharding import assign_chromosomes
+        sizes = chromosome_sizes(f, res)
+        weights = [sizes.get(str(c), sizes.get("chr" + str(c).replace("chr", ""), 1)) for c, _ in pairs]
+        owner = assign_chromosomes(weights, _world)
+        mine = [i for i in range(len(pairs)) if owner[i] == rank]
+
     # the next chromosome is read (host I/O; the native .hic reader and pandas release the GIL) while the GPU works on
     # the current one -- the reference reads and computes strictly in turn (mustache.py:1057-1080)
     from concurrent.futures import ThreadPoolExecutor
+    results = {}
     with ThreadPoolExecutor(max_workers=1) as pool:
-        ahead = pool.submit(fetch, 0) if pairs else None
-        for i, (chromosome, chromosome2) in enumerate(pairs):
+        ahead = pool.submit(fetch, mine[0]) if mine else None
+        for k, i in enumerate(mine):
+            chromosome, chromosome2 = pairs[i]
             contacts = ahead.result()
-            ahead = pool.submit(fetch, i + 1) if i + 1 < len(pairs) else None
+            ahead = pool.submit(fetch, mine[k + 1]) if k + 1 < len(mine) else None
             if isinstance(contacts, BaseException):
                 raise contacts
             if contacts is None:
@@ -400,12 +418,27 @@ def main(argv=None):
                 o = regulator(f, args.norm_method, False, args.outdir, bed=args.bed, res=contacts[3], sigma0=args.s_z,
                               s=args.s, verbose=args.verbose, pt=args.pt, st=args.st, distance_filter=distFilter,
                               nprocesses=args.nprocesses, bias=biasf, chromosome=chromosome, chromosome2=chromosome2,
-                              octaves=args.octaves, contacts=contacts)
+                              octaves=args.octaves, contacts=contacts, shard_blocks=not by_chromosome)
             print("{0} loops found for chrmosome={1}, fdr<{2} in {3}sec".format(
                 len(o), chromosome, args.pt, "%.2f" % (time.time() - start_time)))
-            if rank == 0 and (i == 0 or o):
+            if by_chromosome:
+                results[i] = o
+            elif rank == 0 and (i == 0 or o):
                 write_loops(args.outdir, chromosome, chromosome2, res, o, first=(i == 0))
             start_time = time.time()
+    if by_chromosome:
+        # one gather of (chromosome index, x, y, fdr, sigma) records; rank 0 writes the chromosomes in their order
+        from .sharding import gather_records
+        rec = np.array([[i, float(a), float(b), float(q), float(sg)] for i, o in results.items() for a, b, q, sg in o],
+                       dtype=np.float64).reshape(-1, 5)
+        parts = gather_records(rec)
+        if rank == 0:
+            allrec = np.concatenate(parts) if parts else np.zeros((0, 5))
+            for i, (chromosome, chromosome2) in enumerate(pairs):
+                rows = allrec[allrec[:, 0] == i]
+                o = [[np.int64(a), np.int64(b), np.float64(q), np.float64(sg)] for _, a, b, q, sg in rows]
+                if i == 0 or o:
+                    write_loops(args.outdir, chromosome, chromosome2, res, o, first=(i == 0))
 
 
 if __name__ == '__main__':

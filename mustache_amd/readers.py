@@ -169,6 +169,21 @@ def read_mcooler(f, distance_in_bp, chr1, chr2, res, cooler_balance):
         raise NameError('Reading from the file failed!') from e
 
 
+def chromosome_sizes(f, res):
+    """{name: length in bp} for a .hic / .cool / .mcool file ({} when it cannot be told) -- only used to balance a
+    whole-genome run over several GPUs."""
+    try:
+        if f.endswith(".hic"):
+            return dict(_hic_chromosomes(f))
+        if f.endswith(".cool") or f.endswith(".mcool"):
+            cooler = _need("cooler")
+            clr = cooler.Cooler(f if f.endswith(".cool") else '%s::/resolutions/%s' % (f, res))
+            return {name: int(clr.chromsizes[name]) for name in clr.chromnames}
+    except Exception:
+        pass
+    return {}
+
+
 def list_chromosomes(f, res):
     """Chromosomes main() iterates when -ch is omitted (mustache.py:1019-1036)."""
     if f.endswith(".hic"):

@@ -19,30 +19,51 @@ def shard_blocks(nblocks, rank, world_size):
     return list(range(rank, nblocks, world_size))
 
 
+def assign_chromosomes(weights, world_size):
+    """Whole-genome runs: which rank owns which chromosome.  Longest-processing-time-first: chromosomes by decreasing
+    weight (size in bins; the work is ~ proportional to it), each to the least loaded rank so far; ties go to the lower
+    rank / earlier chromosome, so every rank computes the same table.  Returns owner[i] for chromosome i."""
+    load = [0.0] * world_size
+    owner = [0] * len(weights)
+    for i in sorted(range(len(weights)), key=lambda k: (-float(weights[k]), k)):
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        owner[i] = r
+        load[r] += float(weights[i])
+    return owner
+
+
+def gather_records(rec, device=None, group=None):
+    """all_gather of a float64 [m, w] array per rank (m differs per rank) -> list of the ranks' arrays, on every rank."""
+    rank, ws = world()
+    rec = np.ascontiguousarray(rec, dtype=np.float64)
+    if ws == 1:
+        return [rec]
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+    width = rec.shape[1]
+    cnt = torch.tensor([len(rec)], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(cnt) for _ in range(ws)]
+    dist.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    pad = torch.zeros((max(max(counts), 1), width), dtype=torch.float64, device=device)
+    if len(rec):
+        pad[:len(rec)] = torch.from_numpy(rec).to(device)
+    parts = [torch.zeros_like(pad) for _ in range(ws)]
+    dist.all_gather(parts, pad, group=group)
+    return [parts[r][:counts[r]].cpu().numpy() for r in range(ws)]
+
+
 def gather_loops(loops, device=None, group=None):
     """All ranks pass their list of [x, y, fdr, sigma]; every rank gets the concatenation in rank order
     (rank 0 writes the TSV).  Two collectives: all_gather of the counts, all_gather of the padded records."""
     rank, ws = world()
     if ws == 1:
         return list(loops)
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
     rec = np.zeros((len(loops), 4), dtype=np.float64)
     for i, lp in enumerate(loops):
         rec[i] = (float(lp[0]), float(lp[1]), float(lp[2]), float(lp[3]))   # bin indices < 2^53: exact
-    cnt = torch.tensor([len(loops)], dtype=torch.int64, device=device)
-    counts = [torch.zeros_like(cnt) for _ in range(ws)]
-    dist.all_gather(counts, cnt, group=group)
-    counts = [int(c.item()) for c in counts]
-    mx = max(max(counts), 1)
-    pad = torch.zeros((mx, 4), dtype=torch.float64, device=device)
-    if len(loops):
-        pad[:len(loops)] = torch.from_numpy(rec).to(device)
-    parts = [torch.zeros_like(pad) for _ in range(ws)]
-    dist.all_gather(parts, pad, group=group)
     out = []
-    for r in range(ws):
-        arr = parts[r][:counts[r]].cpu().numpy()
+    for arr in gather_records(rec, device, group):
         out.extend([[np.int64(a), np.int64(b), np.float64(q), np.float64(s)] for a, b, q, s in arr])
     return out
 
@@ -56,8 +77,13 @@ def init_from_env():
     if ws <= 1 or (dist.is_available() and dist.is_initialized()):
         return world()
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MUSTACHE_ONE_DEVICE"):            # test hook: all ranks on GPU 0 (single-GPU boxes)
+        local = 0
     torch.cuda.set_device(local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", rank=int(os.environ["RANK"]), world_size=ws,
-                            device_id=torch.device("cuda", local))
+    if os.environ.get("MUSTACHE_DIST_BACKEND", "nccl") == "gloo":      # test hook, pairs with MUSTACHE_ONE_DEVICE
+        dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=ws)
+    else:
+        dist.init_process_group("nccl", rank=int(os.environ["RANK"]), world_size=ws,
+                                device_id=torch.device("cuda", local))
     return world()

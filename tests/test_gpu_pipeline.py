@@ -362,3 +362,39 @@ def test_normalisation_kernel_vs_oracle_at_real_window_sizes(n, dpx, res, depth)
     finally:
         del os.environ["MST_NORMALIZE_BLOCKED"]
     np.testing.assert_allclose(alt, exp, rtol=1e-9, atol=1e-9)
+
+
+def test_two_rank_cli_equals_one_process(golden_dir, tmp_path):
+    """`torchrun --nproc-per-node 2 -m mustache_amd ...` (both ranks on this box's one GPU, gloo process group -- the test
+    hooks of sharding.init_from_env) writes the same TSV as the plain single-process CLI, for both sharding modes: three
+    chromosomes over two ranks = by chromosome (largest first, one gather at the end), one chromosome = by blocks."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from hic_writer import write_hic
+    from mustache_amd.mustache import main
+    from mustache_amd.synth import synth_coo
+    res, dpx = 10000, 100
+    mats, chroms = {}, [("All", 1)]
+    for ci, (name, n, seed) in enumerate((("chrA", 2600, 1), ("chrB", 3400, 2), ("chrC", 1900, 3)), start=1):
+        x, y, v = synth_coo(n, dpx, depth=200.0, seed=seed)
+        near = (y - x) <= dpx
+        mats[ci] = {res: (x[near], y[near], np.round(v[near]) + 1.0)}
+        chroms.append((name, n * res))
+    hic = str(tmp_path / "g.hic")
+    write_hic(hic, chroms, mats, {}, version=8, block_bin_count=256, float_counts=False)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MUSTACHE_DIST_BACKEND="gloo", MUSTACHE_ONE_DEVICE="1", PYTHONPATH=root)
+    for extra, tag in (([], "genome"), (["-ch", "chrB"], "one")):
+        common = ["-f", hic, "-r", "10kb", "-pt", "0.2", "-st", "0.7", "-d", str(dpx * res), "-norm", "NONE"] + extra
+        single, multi = str(tmp_path / (tag + "_1.tsv")), str(tmp_path / (tag + "_2.tsv"))
+        main(common + ["-o", single])
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", "29533", "-m", "mustache_amd"] + common + ["-o", multi]
+        r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        a, b = open(single).read().strip().split("\n"), open(multi).read().strip().split("\n")
+        assert a[0] == b[0] and len(a) > 10
+        assert sorted(a[1:]) == sorted(b[1:])
+        if tag == "genome":
+            assert [l.split("\t")[0] for l in a[1:]] == [l.split("\t")[0] for l in b[1:]], "chromosomes in file order"

@@ -67,3 +67,45 @@ def test_gather_with_an_empty_rank():
     res = _run(1)
     assert res[0][1] == [0] and res[1][1] == []
     assert len(res[0][2]) == 1 and res[0][2] == res[1][2]
+
+
+def test_assign_chromosomes_lpt():
+    from mustache_amd.sharding import assign_chromosomes
+    sizes = [248, 242, 198, 190, 181, 170, 159, 145, 138, 133, 135, 133, 114, 107, 101, 90, 83, 80, 58, 64, 46, 50, 156]
+    for ws in (1, 2, 4, 8):
+        owner = assign_chromosomes(sizes, ws)
+        assert len(owner) == len(sizes) and set(owner) <= set(range(ws))
+        load = [sum(s for s, o in zip(sizes, owner) if o == r) for r in range(ws)]
+        assert max(load) <= sum(sizes) / ws + max(sizes) * (1 - 1 / ws) + 1e-9       # the LPT bound
+        assert max(load) - min(load) <= max(sizes)
+        assert owner == assign_chromosomes(sizes, ws), "deterministic: every rank computes the same table"
+    assert assign_chromosomes([5, 5, 5], 3) == [0, 1, 2]
+    assert assign_chromosomes([], 4) == []
+
+
+def _records_worker(rank, ws, port, q):
+    import numpy as np
+    import torch.distributed as dist
+    from mustache_amd.sharding import gather_records
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=ws)
+    rec = np.array([[rank, 10.0 * rank + k, 0.5 ** k, 7, 1e-300] for k in range(rank * 2)], dtype=np.float64).reshape(-1, 5)
+    parts = gather_records(rec)
+    q.put((rank, [p.tolist() for p in parts]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_records_five_columns_with_an_empty_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_records_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == res[2][1]
+    parts = res[0][1]
+    assert [len(p) for p in parts] == [0, 2, 4] and parts[2][3] == [2.0, 23.0, 0.125, 7.0, 1e-300]

@@ -202,6 +202,9 @@ int mst_gather_diagonals_band(const double *band, int64_t n, int32_t dpx, int64_
                               const int32_t *diag_k, int32_t nd, double *out, void *stream);
 int mst_diag_means_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH, const int32_t *diag_k,
                         int32_t nd, double *mean_out, void *stream);
+/* the same for diagonals of several blocks in ONE launch: starts: dev [nd], the block origin of each requested diagonal */
+int mst_diag_means_band_multi(const double *band, int64_t n, int32_t dpx, const int64_t *starts, int32_t CH,
+                              const int32_t *diag_k, int32_t nd, double *mean_out, void *stream);
 
 /* ---- two-sample (differential) caller, reference mustache/diff_mustache.py:260-569 ------------------------------------
  * The per-sample sigma loops are mst_scale_space on both samples' blocks.  The entry points below add what

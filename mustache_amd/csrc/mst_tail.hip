@@ -236,11 +236,12 @@ __device__ double np_pairwise_sum(const double *a, int n) {
 // one 64-lane workgroup per diagonal: ordered compaction of the non-zero entries into LDS, then lane 0 sums them
 template <bool BAND>
 __global__ void __launch_bounds__(64)
-diag_mean_kernel(const double *__restrict__ src, int64_t n, int dpx, int64_t start, int CH, int b,
-                 const int32_t *__restrict__ diag_k, double *__restrict__ mean_out) {
+diag_mean_kernel(const double *__restrict__ src, int64_t n, int dpx, int64_t start, const int64_t *__restrict__ starts,
+                 int CH, int b, const int32_t *__restrict__ diag_k, double *__restrict__ mean_out) {
     extern __shared__ double dm_buf[];
     const int i = blockIdx.x, lane = threadIdx.x;
     const int k = diag_k[i];
+    if (BAND && starts) start = starts[i];             // one launch for the diagonals of many blocks
     const int L = (k >= 0 && k < CH) ? CH - k : 0;
     const double *cb = BAND ? src : src + (size_t)b * CH * CH;
     int base = 0;
@@ -261,14 +262,14 @@ diag_mean_kernel(const double *__restrict__ src, int64_t n, int dpx, int64_t sta
 }
 
 template <bool BAND>
-int diag_means_launch(const double *src, int64_t n, int dpx, int64_t start, int CH, int b, const int32_t *diag_k, int nd,
-                      double *mean_out, hipStream_t s) {
+int diag_means_launch(const double *src, int64_t n, int dpx, int64_t start, const int64_t *starts, int CH, int b,
+                      const int32_t *diag_k, int nd, double *mean_out, hipStream_t s) {
     const size_t lds = (size_t)CH * sizeof(double);
     if (lds > 160 * 1024 - 256) return mst::fail(MST_E_ARG, "diagonal means: CH %d does not fit the LDS", CH);
     if (lds > 64 * 1024)
         MST_HIP(hipFuncSetAttribute((const void *)diag_mean_kernel<BAND>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
-    diag_mean_kernel<BAND><<<nd, 64, lds, s>>>(src, n, dpx, start, CH, b, diag_k, mean_out);
+    diag_mean_kernel<BAND><<<nd, 64, lds, s>>>(src, n, dpx, start, starts, CH, b, diag_k, mean_out);
     MST_LAUNCH_CHECK();
     return MST_OK;
 }
@@ -280,7 +281,7 @@ extern "C" int mst_diag_means(const double *c, int32_t CH, int32_t b, const int3
     if (nd == 0) return MST_OK;
     if (!c || !diag_k || !mean_out || CH <= 0 || b < 0 || nd < 0)
         return mst::fail(MST_E_ARG, "mst_diag_means: bad argument");
-    return diag_means_launch<false>(c, 0, 0, 0, CH, b, diag_k, nd, mean_out, mst::as_stream(stream));
+    return diag_means_launch<false>(c, 0, 0, 0, nullptr, CH, b, diag_k, nd, mean_out, mst::as_stream(stream));
 }
 
 extern "C" int mst_diag_means_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,
@@ -288,7 +289,15 @@ extern "C" int mst_diag_means_band(const double *band, int64_t n, int32_t dpx, i
     if (nd == 0) return MST_OK;
     if (!band || !diag_k || !mean_out || CH <= 0 || n <= 0 || dpx < 0 || nd < 0)
         return mst::fail(MST_E_ARG, "mst_diag_means_band: bad argument");
-    return diag_means_launch<true>(band, n, dpx, start, CH, 0, diag_k, nd, mean_out, mst::as_stream(stream));
+    return diag_means_launch<true>(band, n, dpx, start, nullptr, CH, 0, diag_k, nd, mean_out, mst::as_stream(stream));
+}
+
+extern "C" int mst_diag_means_band_multi(const double *band, int64_t n, int32_t dpx, const int64_t *starts, int32_t CH,
+                                         const int32_t *diag_k, int32_t nd, double *mean_out, void *stream) {
+    if (nd == 0) return MST_OK;
+    if (!band || !starts || !diag_k || !mean_out || CH <= 0 || n <= 0 || dpx < 0 || nd < 0)
+        return mst::fail(MST_E_ARG, "mst_diag_means_band_multi: bad argument");
+    return diag_means_launch<true>(band, n, dpx, 0, starts, CH, 0, diag_k, nd, mean_out, mst::as_stream(stream));
 }
 
 extern "C" int mst_candidate_features_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,

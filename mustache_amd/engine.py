@@ -95,17 +95,21 @@ class _MultiGather:
         dev = self._device()
         d_k = torch.from_numpy(np.concatenate([np.asarray(k, dtype=np.int32) for k in kss])).to(dev)
         out = torch.empty(total, dtype=torch.float64, device=dev)
-        off = 0
-        for b, m in zip(bs, sizes):
-            if m:
-                self._diag_means_launch(b, _off(d_k, off), m, _off(out, off))
-            off += m
+        if not self._diag_means_one_launch(bs, sizes, d_k, out):
+            off = 0
+            for b, m in zip(bs, sizes):
+                if m:
+                    self._diag_means_launch(b, _off(d_k, off), m, _off(out, off))
+                off += m
         host = out.cpu().numpy()
         res, off = [], 0
         for m in sizes:
             res.append(host[off:off + m])
             off += m
         return res
+
+    def _diag_means_one_launch(self, bs, sizes, d_k, out):
+        return False                        # overridden where all blocks share one source buffer
 
     def candidate_features(self, b, pixel, half):
         """(cnt1, cnt2, cval) for candidate pixels of block b (reference mustache.py:800-807, :824)."""
@@ -161,6 +165,13 @@ class BandBatch(_MultiGather):
     def _diagonals_launch(self, b, ks, m, out):
         _lib.check(self.engine.lib.mst_gather_diagonals_band(_ptr(self.band), self.n, self.dpx, int(self.starts[b]),
                                                              self.CH, ks, m, out, _stream()))
+
+    def _diag_means_one_launch(self, bs, sizes, d_k, out):
+        starts = np.repeat(np.array([int(self.starts[b]) for b in bs], dtype=np.int64), sizes)
+        d_s = torch.from_numpy(starts).to(self.band.device)
+        _lib.check(self.engine.lib.mst_diag_means_band_multi(_ptr(self.band), self.n, self.dpx, _ptr(d_s), self.CH,
+                                                             _ptr(d_k), int(starts.size), _ptr(out), _stream()))
+        return True
 
     def _diag_means_launch(self, b, ks, m, out):
         _lib.check(self.engine.lib.mst_diag_means_band(_ptr(self.band), self.n, self.dpx, int(self.starts[b]), self.CH,

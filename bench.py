@@ -245,7 +245,11 @@ def main():
                                       "sigma loop, sieve, level statistics) -> p-values -> found records on host; "
                                       "%d launches per step, the download of one under the kernel of the next" % OVERLAP},
            "roofline": roof, "band_skip": band_skip, "fma_mode": fma_mode,
-           "normalize_ms_untimed": round(w.normalize_s * 1e3, 1)}
+           "normalize_ms_untimed": round(w.normalize_s * 1e3, 1),
+           # row 1 of SURVEY 8a next to it: 16 B per band sample (8 read + 8 written) over the wall time of mst_normalize_band
+           "normalize_roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                  "achieved": round(16.0 * (w.dpx + 2) * w.n / w.normalize_s / 1e9, 1),
+                                  "frac": round(16.0 * (w.dpx + 2) * w.n / w.normalize_s / 1e9 / HBM_PEAK_GBS, 4)}}
 
     if rank == 0 and world == 1:
         # second half of the metric's name: chr21 @ 5 kb on 1 GPU (6 blocks of 2000 x 2000), same timed region

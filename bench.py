@@ -91,8 +91,13 @@ class Workload:
         for batch in pipe.batches(self.mine, self.CH, dense=False):
             # launches of at least ~120 Mpix: smaller ones pay more in launch tails than the overlap wins back
             k = max(1, min(OVERLAP, len(batch), int(len(batch) * self.CH * self.CH / 120e6)))
-            step = (len(batch) + k - 1) // k
-            groups += [batch[i:i + step] for i in range(0, len(batch), step)]
+            # the last launch's post-processing is the only one not hidden under a kernel: make that launch the smallest
+            share = {1: [1.0], 2: [0.6, 0.4], 3: [0.4, 0.35, 0.25], 4: [0.29, 0.29, 0.29, 0.13]}.get(k, [1.0 / k] * k)
+            cuts = [0]
+            for f in share[:-1]:
+                cuts.append(min(len(batch) - 1, max(cuts[-1] + 1, int(round(cuts[-1] + f * len(batch))))))
+            cuts.append(len(batch))
+            groups += [batch[a:b] for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
         self.groups = groups
         # blocks are windows of the band: cut, filled (mustache.py:703-706) and masked (:699) inside the fused kernel;
         # records = (pixel, level, p-value); the tail orders them by pixel when it needs look-ups

@@ -1,6 +1,6 @@
 /*
- * mustache_io.h -- C ABI of libmustache_io.so: a host-side (no GPU, no third-party module) reader for Juicer `.hic`
- * contact maps, versions 6-9, feeding the loop caller's COO input.
+ * mustache_io.h -- C ABI of libmustache_io.so: host-side (no GPU, no third-party module) readers feeding the loop caller's
+ * COO input: Juicer `.hic` contact maps, versions 6-9, and the reference's text layouts (end of this file).
  *
  * It replaces what the reference does through the hic-straw Python module in read_hic_file()
  * (reference mustache/mustache.py:300-396): `hicstraw.HiCFile(f).getChromosomes()` (:308-312) and the windowed
@@ -63,6 +63,24 @@ int32_t mst_hic_resolution(const mst_hic *h, int32_t i);
  * n_threads <= 0 picks the hardware concurrency.  Record order is file block order (deterministic). */
 int64_t mst_hic_read_intra(mst_hic *h, const char *chrom, int32_t resolution, const char *norm, int64_t max_dist_bins,
                            int32_t n_threads, int64_t **x, int64_t **y, double **v);
+
+/* ---- text contact maps ------------------------------------------------------------------------------------------------
+ * The parse step of read_pd() (reference mustache/mustache.py:254-258): `pd.read_csv(f, sep=sep, header=None)` followed
+ * by `df.dropna()`, for the two layouts the reference accepts -- 3 columns (pos1 pos2 count) or 5 columns (chr1 pos1 chr2
+ * pos2 count) -- and, for 5 columns, the two `is_chr` row filters (:260-265).  pandas is a third-party dependency of the
+ * reference (unpinned; 2.3.3 in the build image); its C parser's number conversion is restated here: the default
+ * `float_precision` converter `precise_xstrtod` (pandas/_libs/src/parser/tokenizer.c: at most 17 significant digits are
+ * accumulated, then ONE multiplication or division by an exact power of ten), the default NA strings (a row holding one
+ * is dropped, as dropna() does), blank lines skipped, surrounding blanks of a field ignored.  PINNED: tests compare the
+ * returned doubles bit for bit with pandas.read_csv on randomised files (tests/test_text_reader.py).
+ *
+ * Returns the number of rows (>= 0) with the three numeric columns as malloc'ed float64 arrays (integers below 2^53 are
+ * exact, so pandas' int64-or-float64 column inference makes no difference downstream), n_cols = 3 or 5.
+ * MST_IO_E_FORMAT is returned for anything this restatement does not cover (quotes, a line with more fields than the first,
+ * a token that is neither a number nor an NA string): the caller then lets pandas itself read the file.
+ * `chrom`: only used for 5-column files (rows are kept when both chromosome fields match it the way is_chr() does). */
+int64_t mst_text_read_contacts(const char *path, char sep, const char *chrom, int32_t n_threads, int32_t *n_cols,
+                               double **pos1, double **pos2, double **count);
 
 #ifdef __cplusplus
 }

@@ -40,10 +40,15 @@ namespace {
 
 thread_local char g_err[512] = "";
 
+int vfail(int code, const char *fmt, va_list ap) {
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    return code;
+}
+
 int fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    vfail(code, fmt, ap);
     va_end(ap);
     return code;
 }
@@ -51,6 +56,19 @@ int fail(int code, const char *fmt, ...) {
 struct FormatError {
     const char *what;
 };
+}  // namespace
+
+namespace mst_io {
+int fail(int code, const char *fmt, ...) {          // the error buffer is shared with text_reader.cpp
+    va_list ap;
+    va_start(ap, fmt);
+    vfail(code, fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace mst_io
+
+namespace {
 
 // bounds-checked little-endian cursor over a byte range
 struct Cursor {

@@ -34,6 +34,9 @@ _SIGNATURES = {
     "mst_hic_resolution": (ctypes.c_int32, [_P, ctypes.c_int32]),
     "mst_hic_read_intra": (ctypes.c_int64, [_P, ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64,
                                             ctypes.c_int32, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_P)]),
+    "mst_text_read_contacts": (ctypes.c_int64, [ctypes.c_char_p, ctypes.c_char, ctypes.c_char_p, ctypes.c_int32,
+                                                ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_P), ctypes.POINTER(_P),
+                                                ctypes.POINTER(_P)]),
 }
 
 
@@ -111,3 +114,25 @@ class HicFile:
             for p in (px, py, pv):
                 self._lib.mst_io_free(p)
         return x, y, v
+
+
+def read_text_contacts(path, sep, chromosome=None, threads=0):
+    """(n_cols, pos1, pos2, count): the numeric columns of a 3- or 5-column contact text file as float64 arrays, the rows
+    pandas.read_csv(path, sep=sep, header=None).dropna() keeps (5 columns: those whose two chromosome fields match
+    `chromosome`), parsed bit for bit like pandas' default converter.  Raises HicError(code -3) for files the native parser
+    does not cover -- the caller then uses pandas itself."""
+    lib = load()
+    ncols = ctypes.c_int32()
+    pa, pb, pc = _P(), _P(), _P()
+    chrom = None if chromosome is None else str(chromosome).encode()
+    n = _check(lib, lib.mst_text_read_contacts(os.fsencode(path), str(sep).encode()[:1], chrom, int(threads),
+                                               ctypes.byref(ncols), ctypes.byref(pa), ctypes.byref(pb), ctypes.byref(pc)))
+    try:
+        if n == 0:
+            z = np.zeros(0, np.float64)
+            return int(ncols.value), z, z.copy(), z.copy()
+        out = [np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_double)), shape=(n,)).copy() for p in (pa, pb, pc)]
+    finally:
+        for p in (pa, pb, pc):
+            lib.mst_io_free(p)
+    return (int(ncols.value),) + tuple(out)

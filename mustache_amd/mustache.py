@@ -148,11 +148,42 @@ def read_bias(f, chromosome, res):
     return d
 
 
+def _parse_contacts_native(f, sep, chromosome):
+    """(n_cols, pos1, pos2, count) through libmustache_io.so's text parser (bit for bit what pandas' C parser yields, see
+    include/mustache_io.h), or None when the file needs pandas itself / MUSTACHE_TEXT_BACKEND=pandas asks for it."""
+    if os.environ.get("MUSTACHE_TEXT_BACKEND", "native").lower() == "pandas":
+        return None
+    from .hicfile import HicError, read_text_contacts
+    try:
+        return read_text_contacts(f, sep, chromosome)
+    except HicError as e:
+        if e.code == -3:                    # a construct the native parser does not cover: let pandas decide
+            return None
+        raise
+
+
 def read_pd(f, distance_in_bp, bias, chromosome, res):
     """3-column (pos1 pos2 count) or 5-column (chr1 pos1 chr2 pos2 count) text -> upper-triangular COO in bin
     units, counts divided by bias[x]*bias[y], non-positive rows dropped (reference mustache.py:254-297)."""
-    import pandas as pd
     sep = get_sep(f)
+    native = _parse_contacts_native(f, sep, chromosome)
+    if native is not None:
+        ncols, p1, p2, cnt = native                                        # read_csv + dropna (+ the is_chr filters)
+        if ncols == 5 and len(cnt) == 0:
+            print('Could\'t read any interaction for this chromosome!')
+            return
+        keep = np.abs(p1 - p2) <= ((distance_in_bp / res + 1) * res)       # (:267, :283)
+        a = np.floor_divide(p1[keep], res)                                 # df[1] //= res
+        b = np.floor_divide(p2[keep], res)
+        cnt = cnt[keep]
+        bias = read_bias(bias, chromosome, res)
+        if bias:
+            cnt = np.divide(cnt, np.vectorize(bias.get)(a, 1)) if len(a) else cnt
+            cnt = np.divide(cnt, np.vectorize(bias.get)(b, 1)) if len(b) else cnt
+        pos = cnt > 0
+        a, b, cnt = a[pos].astype(np.int64), b[pos].astype(np.int64), cnt[pos]
+        return np.minimum(a, b), np.maximum(a, b), cnt
+    import pandas as pd
     df = pd.read_csv(f, sep=sep, header=None)
     df.dropna(inplace=True)
     if df.shape[1] == 5:

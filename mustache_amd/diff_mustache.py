@@ -278,22 +278,30 @@ def main(argv=None):
         print("Error: the same number of chromosome1 and chromosome2 should be provided.")
         return
     distFilter = resolve_distance_filter(args.distFilter, res)
-    for i, (chromosome, chromosome2) in enumerate(zip(chr_list, chr_list2)):
-        biasf1 = False        # reference quirk (:824-827): -b1 is checked for existence but never passed on
-        if args.biasfile1 and not os.path.exists(args.biasfile1):
-            print("Error: Couldn't find the specified bias file1")
-            return
-        biasf2 = False
-        if args.biasfile2:
-            if os.path.exists(args.biasfile2):
-                biasf2 = args.biasfile2
-            else:
-                print("Error: Couldn't find the specified bias file2")
-                return
-        o = regulator(f1, f2, args.norm_method, False, args.outdir, bed1=args.bed1, bed2=args.bed2, res=res,
-                      sigma0=args.s_z, s=args.s, verbose=args.verbose, pt=args.pt, pt2=args.pt2, st=args.st,
-                      distance_filter=distFilter, nprocesses=args.nprocesses, bias1=biasf1, bias2=biasf2,
-                      chromosome=chromosome, chromosome2=chromosome2, octaves=args.octaves)
+    if args.biasfile1 and not os.path.exists(args.biasfile1):
+        print("Error: Couldn't find the specified bias file1")
+        return
+    if args.biasfile2 and not os.path.exists(args.biasfile2):
+        print("Error: Couldn't find the specified bias file2")
+        return
+    biasf1 = False            # reference quirk (:824-827): -b1 is checked for existence but never passed on
+    biasf2 = args.biasfile2 if args.biasfile2 else False
+    pairs = list(zip(chr_list, chr_list2))
+
+    # multi-GPU (`torchrun -m mustache_amd.diff_mustache ...`): chromosomes are dealt to the ranks largest first, each rank
+    # reads and runs its own, ONE gather of (chromosome, x, y, fdr, sigma, list tag) records, rank 0 writes the four files
+    from .sharding import assign_chromosomes, gather_records, init_from_env
+    rank, world_size = init_from_env()
+    mine = list(range(len(pairs)))
+    if world_size > 1:
+        from .readers import chromosome_sizes
+        sizes = chromosome_sizes(f1, res)
+        weights = [sizes.get(str(c), sizes.get("chr" + str(c).replace("chr", ""), 1)) for c, _ in pairs]
+        owner = assign_chromosomes(weights, world_size)
+        mine = [i for i in range(len(pairs)) if owner[i] == rank]
+
+    def write(i, o):
+        chromosome, chromosome2 = pairs[i]
         if i == 0:
             for suf in SUFFIX.values():
                 with open(args.outdir + suf, 'w') as fh:
@@ -309,9 +317,32 @@ def main(argv=None):
         finally:
             for fh in files.values():
                 fh.close()
+        return counts
+
+    results = {}
+    for i in mine:
+        chromosome, chromosome2 = pairs[i]
+        o = regulator(f1, f2, args.norm_method, False, args.outdir, bed1=args.bed1, bed2=args.bed2, res=res,
+                      sigma0=args.s_z, s=args.s, verbose=args.verbose, pt=args.pt, pt2=args.pt2, st=args.st,
+                      distance_filter=distFilter, nprocesses=args.nprocesses, bias1=biasf1, bias2=biasf2,
+                      chromosome=chromosome, chromosome2=chromosome2, octaves=args.octaves)
+        if world_size > 1:
+            results[i] = o
+            counts = {t: sum(1 for r in o if r[4] == t) for t in (1, 2, 3, 4)}
+        else:
+            counts = write(i, o)
         print(f"({counts[1]},{counts[3]}) loops and ({counts[2]},{counts[4]}) differential-loops found in "
               f"chrmosome={chromosome} for detection-fdr<{args.pt} and difference-fdr<{args.pt2} in {time.time() - t0:.2f}sec")
         t0 = time.time()
+    if world_size > 1:
+        rec = np.array([[i, float(r[0]), float(r[1]), float(r[2]), float(r[3]), float(r[4])]
+                        for i, o in results.items() for r in o], dtype=np.float64).reshape(-1, 6)
+        parts = gather_records(rec)
+        if rank == 0:
+            allrec = np.concatenate(parts)
+            for i in range(len(pairs)):
+                rows = allrec[allrec[:, 0] == i]
+                write(i, [[np.int64(a), np.int64(b), np.float64(q), np.float64(sg), int(t)] for _, a, b, q, sg, t in rows])
 
 
 if __name__ == '__main__':

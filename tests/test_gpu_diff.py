@@ -90,3 +90,37 @@ def test_diff_regulator_equals_blockwise_oracle(tmp_path):
                     exp.append((int(lp[0]), int(lp[1]), lp[3], tag))
     assert len(exp) > 10
     assert sorted((int(r[0]), int(r[1]), r[3], r[4]) for r in got) == sorted(exp)
+
+
+def test_diff_cli_two_ranks_equal_one_process(tmp_path):
+    """`torchrun --nproc-per-node 2 -m mustache_amd.diff_mustache ...` (both ranks on this box's GPU, gloo group: the test
+    hooks of sharding.init_from_env) writes the same four files as the single-process CLI."""
+    import subprocess
+    import sys
+    from mustache_amd.diff_mustache import main, SUFFIX
+    from mustache_amd.synth import synth_coo
+    n, dpx, res = 2300, 200, 10000
+    files = []
+    for seed in (61, 62):
+        x, y, v = synth_coo(n, dpx, depth=300.0, seed=seed)
+        f = str(tmp_path / ("s%d.txt" % seed))
+        with open(f, "w") as fh:
+            for a, b, c in zip(x, y, v):
+                fh.write("%d\t%d\t%r\n" % (a * res, b * res, float(c)))
+        files.append(f)
+    common = ["-f1", files[0], "-f2", files[1], "-ch", "chrS", "chrT", "chrU", "-r", "10kb", "-pt", "0.2", "-pt2", "0.2", "-st",
+              "0.8", "-d", str(dpx * res)]
+    single, multi = str(tmp_path / "one"), str(tmp_path / "two")
+    main(common + ["-o", single])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MUSTACHE_DIST_BACKEND="gloo", MUSTACHE_ONE_DEVICE="1", PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", "-m", "mustache_amd.diff_mustache"] + common + ["-o", multi]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    total = 0
+    for suf in SUFFIX.values():
+        a, b = open(single + suf).read(), open(multi + suf).read()
+        assert a == b, suf
+        total += a.count("\n") - 1
+    assert total > 30

@@ -232,3 +232,27 @@ def test_exact_zero_pvalue_and_top_edge_candidates():
     q = oracle.benjamini_hochberg(ss.pval[f])
     rows = np.flatnonzero(nz.ravel())[f] // n
     assert ((rows < 8) & (q < 0.2)).any()
+
+
+def test_large_distance_limit_blocks_of_10000():
+    """-d 5 Mb at 1 kb: dpx = 5000 -> blocks of 10000 x 10000 (54k tiles per block, 80 KB of LDS for a diagonal mean).  Too big
+    for the oracle in test time, so size-independent properties: the band-direct kernel and the dense-block path give the
+    same loops, skipping empty tiles changes nothing, two runs are identical, every loop lies inside the distance limit."""
+    import torch
+    from mustache_amd.normalize import band_from_coo, normalize_band
+    from mustache_amd.pipeline import ChromosomePipeline, block_tiling
+    from mustache_amd.synth import synth_coo
+    n, dpx, res = 12000, 5000, 1000
+    x, y, v = synth_coo(n, dpx, depth=60.0, seed=71, nloops=600)
+    pipe = ChromosomePipeline([1.6, 3.2])
+    band = band_from_coo(*(torch.from_numpy(a).to(pipe.device) for a in (x, y, v)), n, dpx)
+    band, _, _ = normalize_band(band, n, dpx, res)
+    CH, start, end = block_tiling(n, dpx)
+    assert CH == 10000 and len(start) == 2
+    key = lambda r: (int(r[0]), int(r[1]), float(r[2]), float(r[3]))
+    a = sorted(key(r) for r in pipe.run_band(band, n, dpx, 0.3, 0.3, distributed=False))
+    b = sorted(key(r) for r in pipe.run_band(band, n, dpx, 0.3, 0.3, distributed=False, skip_empty=False))
+    c = sorted(key(r) for r in pipe.run_band(band, n, dpx, 0.3, 0.3, distributed=False, dense=True))
+    d = sorted(key(r) for r in pipe.run_band(band, n, dpx, 0.3, 0.3, distributed=False))
+    assert a == b == c == d and len(a) > 50
+    assert all(0 <= r[1] - r[0] <= dpx for r in a)

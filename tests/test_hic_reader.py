@@ -142,3 +142,20 @@ def test_read_hic_file_native_equals_straw_backend(tmp_path, monkeypatch):
     monkeypatch.setenv("MUSTACHE_HIC_BACKEND", "native")
     with pytest.raises(NameError):
         read_hic_file(p, False, False, dist, "chr9", "chr9", res)
+
+
+def test_integration_md_hic_snippet_runs(tmp_path):
+    """INTEGRATION.md section 3's ctypes example, executed as written against a file made by tests/hic_writer.py."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 3."):]
+    code = re.search(r"```python\n(.*?)```", sec, re.S).group(1)
+    n, res = 3000, 1000
+    x, y, c = _contacts(n, 2500, 40000, 5)
+    p = str(tmp_path / "sample.hic")
+    write_hic(p, [("All", 1), ("chr1", n * res)], {1: {res: (x, y, c)}}, {("KR", 1, res): np.full(n + 1, 2.0)})
+    code = code.replace('ctypes.CDLL("mustache_amd/libmustache_io.so")',
+                        'ctypes.CDLL(os.path.join(ROOT, "mustache_amd", "libmustache_io.so"))').replace('b"sample.hic"', "PATH")
+    ns = dict(os=os, ROOT=ROOT, PATH=os.fsencode(p))
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    keep = (y - x) <= 2000
+    assert ns["n"] == int(keep.sum()) and sorted(ns["x"].tolist()) == sorted(x[keep].tolist())

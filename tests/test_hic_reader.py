@@ -159,3 +159,38 @@ def test_integration_md_hic_snippet_runs(tmp_path):
     exec(compile(code, "INTEGRATION.md", "exec"), ns)
     keep = (y - x) <= 2000
     assert ns["n"] == int(keep.sum()) and sorted(ns["x"].tolist()) == sorted(x[keep].tolist())
+
+
+def test_corrupted_files_never_crash(tmp_path):
+    """Random byte / word flips and truncations of a valid file: the reader either returns records or a HicError -- it must
+    not crash or hang (every structure is read through a bounds-checked cursor)."""
+    import random
+    from mustache_amd.hicfile import HicFile, HicError
+    n, res = 700, 5000
+    x, y, c = _contacts(n, 300, 6000, 12)
+    good = str(tmp_path / "g.hic")
+    write_hic(good, [("All", 1), ("chr1", n * res)], {1: {res: (x, y, c)}}, {("KR", 1, res): np.full(n + 1, 1.5)}, version=9,
+              block_bin_count=64)
+    raw = open(good, "rb").read()
+    rnd = random.Random(4)
+    outcomes = {"ok": 0, "err": 0}
+    for i in range(120):
+        b = bytearray(raw)
+        for _ in range(rnd.randint(1, 5)):
+            pos = rnd.randrange(len(b) - 4)
+            if rnd.random() < 0.5:
+                b[pos] = rnd.randrange(256)
+            else:
+                b[pos:pos + 4] = rnd.randrange(2 ** 32).to_bytes(4, "little")
+        if rnd.random() < 0.15:
+            b = b[:rnd.randrange(8, len(b))]
+        p = str(tmp_path / "m.hic")
+        open(p, "wb").write(bytes(b))
+        try:
+            with HicFile(p) as h:
+                h.chromosomes()
+                h.read_intra("chr1", res, "KR", 100, threads=2)
+            outcomes["ok"] += 1
+        except HicError:
+            outcomes["err"] += 1
+    assert outcomes["ok"] + outcomes["err"] == 120 and outcomes["err"] > 20

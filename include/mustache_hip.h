@@ -169,6 +169,9 @@ int mst_band_to_coo(const double *band, const int64_t *x, const int64_t *y, int6
 
 /* normalize_sparse (mustache.py:622-686) on the band, out of place (band_in != band_out).
  *   local != 0 : branch A (:628-669), taken by the caller when (n - dpx) * res > 2e6; `window` = int(2e6 / res).
+ *                (local == 1: the library picks the kernel -- prefix sums per 1024-sample segment for windows up to
+ *                ~3000, blocked sums above; local == 2: the blocked-sum kernel whatever the window, a second
+ *                implementation of the same sums kept selectable so the two can be cross-checked.)
  *                Per diagonal d <= dpx+1: vals = v + 0.001; counts / sum / sum of squares over the zero-padded
  *                window [i - window/2, i - window/2 + window - 1] (np.convolve 'same'); local variance and mean
  *                with the global fallback below 30 samples or when non-finite; z = (vals - mean)/sqrt(var),

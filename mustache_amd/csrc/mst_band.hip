@@ -552,7 +552,7 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
         const int tile = kPSeg + window - 1;
         const int chunk = ((tile + 1 + kPThreads - 1) / kPThreads) | 1;  // samples per thread, odd
         const size_t plds = (sizeof(double) * 2 + sizeof(int)) * (size_t)kPThreads * chunk + sizeof(double) * kPSeg + 16;
-        if (plds <= 80 * 1024 && chunk <= kPMaxChunk && !getenv("MST_NORMALIZE_BLOCKED")) {
+        if (plds <= 80 * 1024 && chunk <= kPMaxChunk && local != 2) {
             const int nseg = (int)((n + kPSeg - 1) / kPSeg);            // covers [0, n): the kernel also writes the zero tails
             const int64_t total = (int64_t)nseg * nd;
             const int64_t want_wgs = 256 * 2 * 8;                        // 8 waves of workgroups over 256 CUs x 2 resident
@@ -582,12 +582,9 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
         const size_t lds = sizeof(double) * (2 * nblk * kBlk + 2 * nblk) + sizeof(int) * nblk + 16;
         if (window < 2 || lds > 160 * 1024)
             return mst::fail(MST_E_ARG, "mst_normalize_band: window %d outside [2, ~8800]", window);
-        static bool attr_set = false;
-        if (!attr_set) {
-            MST_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&normalize_local_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        static unsigned long long lds_allowed = 0;      // per device (mst_common.h)
+        MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&normalize_local_kernel), 160 * 1024,
+                                       &lds_allowed));
         // rows are written for i < n - d only; clear the tails so the output band is fully defined
         MST_HIP(hipMemsetAsync(band_out, 0, sizeof(double) * (size_t)nd * n, s));
         dim3 grid((unsigned)((n + kSeg - 1) / kSeg), nd);

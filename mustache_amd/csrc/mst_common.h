@@ -22,4 +22,17 @@ int fail(int code, const char *fmt, ...);   // formats into error_buffer(), retu
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: raise it once per (call site, device),
+// so a process that drives several GPUs gets it on each of them.  `done` = the call site's static bit mask of devices.
+inline hipError_t allow_dynamic_lds(const void *kernel, int bytes, unsigned long long *done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(done, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) __atomic_fetch_or(done, bit, __ATOMIC_RELEASE);
+    return e;
+}
+
 }  // namespace mst

@@ -37,7 +37,16 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include "mst_common.h"
+
+// Timing ablations (blur only, no wave reductions, staging only) exist in PROFILE builds only (make PROFILE=1 ->
+// libmustache_hip_profile.so); the product library has no run-time switch that could change a result.
+#ifdef MST_PROFILE
+#define MST_VARIANT(bit_) (variant & (bit_))
+#else
+#define MST_VARIANT(bit_) 0
+#endif
 
 #ifndef MST_KC8_BELOW
 #define MST_KC8_BELOW 11      // radii below this use one 8-output window per item, wider ones two 4-output windows
@@ -250,7 +259,7 @@ __device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const do
 template <class T, int R>
 __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__restrict__ vb,
                                       const double (&wall)[T::RMAX + 1], int ptid, const double *__restrict__ vsrc,
-                                      double *__restrict__ vdst) {
+                                      double *__restrict__ vdst, int variant) {
     constexpr int K = T::K, KC = Chunk<T::K, R>::KC;
     constexpr int NC = T::RGC + 2 * R;               // columns to produce
     constexpr int NRG = T::RGR / K;                  // 8-row groups
@@ -260,7 +269,7 @@ __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__r
 #pragma unroll
     for (int j = 0; j <= R; ++j) w[j] = wall[j];
     static_assert(MAINC == T::NT / NRG, "the main-item mapping below is radius independent");
-    {
+    if (!MST_VARIANT(16)) {                          // [ablation 16] no main V items
         // vsrc = ct + col * CTP + row0, vdst = vb + row0 * VP + col for this thread's (8-row group, column): computed once
         // per tile; the radius only adds a compile-time constant that folds into the ds_read offset field
         const double *p = vsrc + (T::RMAX - R) * T::CTP + (T::RMAX - R - OFF);
@@ -273,7 +282,7 @@ __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__r
             for (int k = 0; k < KC; ++k) q[(h * KC + k) * T::VP] = t[k];
         }
     }
-    if constexpr (MAINC < NC) {
+    if constexpr (MAINC < NC) if (!MST_VARIANT(8)) {  // [ablation 8] no leftover pieces
         constexpr int XC = NC - MAINC;               // leftover columns
         constexpr int XRG = T::RGR / 4;              // 4-row pieces per column
         for (int it = ptid; it < XRG * XC; it += T::NT) {
@@ -309,8 +318,9 @@ __device__ __forceinline__ void hpass(const double *__restrict__ p, const double
 
 template <class T, int R>
 __device__ __forceinline__ void blur_level(const double *ct, double *vb, const double (&w)[T::RMAX + 1], int tid,
-                                           const double *vsrc, double *vdst, const double *hsrc, double (&g)[T::K]) {
-    vpass<T, R>(ct, vb, w, tid, vsrc, vdst);
+                                           const double *vsrc, double *vdst, const double *hsrc, double (&g)[T::K],
+                                           int variant) {
+    vpass<T, R>(ct, vb, w, tid, vsrc, vdst, variant);
     __syncthreads();
     hpass<T, R>(hsrc, w, g);
 }
@@ -318,10 +328,10 @@ __device__ __forceinline__ void blur_level(const double *ct, double *vb, const d
 template <class T>
 __device__ __forceinline__ void blur_dispatch(int r, const double *ct, double *vb, const double (&wg)[T::RMAX + 1],
                                               int tid, const double *vsrc, double *vdst, const double *hsrc,
-                                              double (&g)[T::K]) {
+                                              double (&g)[T::K], int variant) {
 #define MST_CASE(R_)                                                  \
     case R_:                                                          \
-        if constexpr (R_ <= T::RMAX) blur_level<T, R_>(ct, vb, wg, tid, vsrc, vdst, hsrc, g); \
+        if constexpr (R_ <= T::RMAX) blur_level<T, R_>(ct, vb, wg, tid, vsrc, vdst, hsrc, g, variant); \
         break;
     switch (r) {
         MST_CASE(1) MST_CASE(2) MST_CASE(3) MST_CASE(4) MST_CASE(5) MST_CASE(6) MST_CASE(7)
@@ -349,7 +359,7 @@ __global__ void __launch_bounds__(T::NT, T::MINW)
 scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz, BandSrc src, int CH,
                    const DevLevels *__restrict__ lv, mst_found *__restrict__ found, uint32_t found_cap,
                    uint32_t *__restrict__ found_count, double *__restrict__ partial, int tiles_x, int tiles_y,
-                   int n_tested, int skip_empty, int variant) {
+                   int n_tested, int skip_empty, const int32_t *__restrict__ tile_list, int n_slots, int variant) {
     constexpr int K = T::K, RGR = T::RGR, RGC = T::RGC, RMAX = T::RMAX;
     extern __shared__ __align__(16) double lds[];
     double *ct = lds;
@@ -359,12 +369,19 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
 
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-    const int ntiles = tiles_x * tiles_y;
+#ifdef MST_EXP_PRIO
+    // the two waves that share a SIMD get different static priorities (hardware wave slot parity, HW_REG_HW_ID[3:0])
+    if (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) __builtin_amdgcn_s_setprio(MST_EXP_PRIO);
+#endif
     // XCD-aware order: hardware places workgroup i on XCD i % 8 (gridDim.x is a multiple of 8), so give each XCD a
-    // contiguous run of tiles -- neighbouring tiles share their halo through that XCD's L2.
+    // contiguous run of slots -- neighbouring tiles share their halo through that XCD's L2.  A slot is a tile, or, when
+    // the host passes the list of tiles that can reach the tested band (skip_empty on the band source), an entry of
+    // that list: every XCD then gets the same number of tiles WITH work (with all tiles in the grid the dispatcher, which
+    // hands out workgroups in order, waits for the XCD that holds the widest part of the band while the others idle).
     const int per_xcd = gridDim.x >> 3;
-    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= ntiles) return;
+    const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (slot >= n_slots) return;
+    const int tile = tile_list ? tile_list[slot] : slot;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int y0 = ty * T::ITR - 1, x0 = tx * T::ITC - 1;  // block coordinates of region (0, 0)
 
@@ -373,7 +390,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
     const int gy = y0 + rr;
     const bool row_in = gy >= 0 && gy < CH;
     const bool row_own = row_in && rr >= 1 && rr <= T::ITR;
-    double *part = partial + ((size_t)b * ntiles + tile) * n_tested * 2;
+    double *part = partial + ((size_t)b * n_slots + slot) * n_tested * 2;
 
     uint32_t in_mask = 0, nz_mask = 0;  // per-k bits: column inside the block / tested pixel owned by this thread
 #pragma unroll
@@ -544,7 +561,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
     double *vdst = vb + (v_rgp * K) * T::VP + v_col;
     const double *hsrc = vb + rr * T::VP + cg * K;
 
-    const int n_oct = (variant & 4) ? 0 : lv->n_octaves, lpo = lv->levels_per_octave;   // [timing ablation 4: staging + epilogue only]
+    const int n_oct = MST_VARIANT(4) ? 0 : lv->n_octaves, lpo = lv->levels_per_octave;   // [ablation 4: staging + epilogue only]
     const int prot = (int)(blockIdx.x >> 3) * 2 + (int)(blockIdx.x >> 11);
     int tested = 0;
     for (int o = 0; o < n_oct; ++o) {
@@ -563,7 +580,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
             // the leftover V-pass pieces occupy the first ceil(R/4) waves of a rotated wave order, so that over the
             // levels (and between the workgroups sharing a CU) every SIMD carries the same share of them
             const int ptid = (tid + 64 * ((l + prot) & 3)) & (T::NT - 1);
-            blur_dispatch<T>(r, ct, vb, taps, ptid, vsrc, vdst, hsrc, g);
+            blur_dispatch<T>(r, ct, vb, taps, ptid, vsrc, vdst, hsrc, g, variant);
             double d[K];
             if (kl >= 2) {
 #pragma unroll
@@ -580,7 +597,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
             for (int k = 0; k < K; ++k) gprev[k] = g[k];
             __syncthreads();   // edge strip visible; every H-pass read of vb is done before the next V pass writes it
             if (kl < 2) continue;
-            if (variant & 1) continue;     // [timing ablation] blur + DoG only
+            if (MST_VARIANT(1)) continue;     // [ablation 1] blur + DoG only
 
             // zero-padded 3x3 max at the owned pixels: 3-max along the row in registers, then across rows via lane shifts
             const double dl = de_left[0], dr = de_right[0];
@@ -623,7 +640,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
                     }
                 }
                 // fixed-order DPP reduction inside the wave (total lands in lane 63), one slot per (level, wave)
-                if (!(variant & 2)) wave_reduce_min_sum(lmin, lsum);
+                if (!MST_VARIANT(2)) wave_reduce_min_sum(lmin, lsum);
                 if (lane == 63) {
                     st[(tested * T::NW + wave) * 2] = lmin;
                     st[(tested * T::NW + wave) * 2 + 1] = lsum;
@@ -765,6 +782,19 @@ template <class T>
 int tiles_total(int CH) { return tiles_x<T>(CH) * tiles_y<T>(CH); }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+int nt_tiles_max(int CH) {
+    const int a = tiles_total<TileDefault>(CH), b = tiles_total<TileWide>(CH);
+    return a > b ? a : b;
+}
+
+// level_stats of blocks without any tested tile: {min, sum} = {inf, 0}, what the reduction of zero tiles yields
+__global__ void fill_stats_kernel(double *level_stats, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        level_stats[2 * i] = INFINITY;
+        level_stats[2 * i + 1] = 0.0;
+    }
+}
 
 }  // namespace
 
@@ -773,29 +803,46 @@ extern "C" uint64_t mst_scale_space_workspace_bytes(int32_t B, int32_t CH, const
     if (B <= 0 || CH <= 0 || check_levels(lv, &mr, &nt) != MST_OK) return 0;
     const int nt_tiles = mr <= TileDefault::RMAX ? tiles_total<TileDefault>(CH) : tiles_total<TileWide>(CH);
     return align_up(sizeof(DevLevels), 256) + align_up(sizeof(int64_t) * (size_t)B, 256) +
-           sizeof(double) * 2 * (size_t)B * nt_tiles * nt;
+           align_up(sizeof(int32_t) * (size_t)nt_tiles_max(CH), 256) + sizeof(double) * 2 * (size_t)B * nt_tiles * nt;
 }
 
 template <class T, bool BAND>
 static int launch_scale_space(const double *c, const uint8_t *nz, BandSrc src, int B, int CH, const DevLevels *d_lv,
                               mst_found *found, uint32_t found_cap, uint32_t *found_count, double *partial,
-                              int n_tested, int skip_empty, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        MST_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scale_space_kernel<T, BAND>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES));
-        attr_set = true;
-    }
+                              int n_tested, int skip_empty, const int32_t *tile_list, int n_slots, hipStream_t s) {
+    static unsigned long long lds_allowed = 0;      // per device (mst_common.h)
+    MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&scale_space_kernel<T, BAND>), (int)T::LDS_BYTES,
+                                   &lds_allowed));
     const int tx = tiles_x<T>(CH), ty = tiles_y<T>(CH);
-    const int ntiles = tx * ty;
-    const int gx = (ntiles + 7) / 8 * 8;
-    const char *venv = getenv("MST_ABLATE");          // timing ablations for profiling only (results invalid)
-    const int variant = venv ? atoi(venv) : 0;
+    const int gx = (n_slots + 7) / 8 * 8;
+    int variant = 0;
+#ifdef MST_PROFILE
+    const char *venv = getenv("MST_ABLATE");          // timing ablations (results invalid), PROFILE builds only
+    variant = venv ? atoi(venv) : 0;
+#endif
     scale_space_kernel<T, BAND><<<dim3(gx, B), T::NT, T::LDS_BYTES, s>>>(c, nz, src, CH, d_lv, found, found_cap,
                                                                        found_count, partial, tx, ty, n_tested,
-                                                                       skip_empty, variant);
+                                                                       skip_empty, tile_list, n_slots, variant);
     MST_LAUNCH_CHECK();
     return MST_OK;
+}
+
+// Tiles whose owned pixels can reach the tested band 4 <= col - row <= dpx + 1 (the kernel's own geometric test), in
+// row-major order.  The same list serves every block of a launch: the test depends on (CH, dpx) only.
+template <class T>
+static int band_tile_list(int CH, int dpx, int32_t *out) {
+    const int tx = tiles_x<T>(CH), ty = tiles_y<T>(CH);
+    int m = 0;
+    for (int j = 0; j < ty; ++j) {
+        const int y0 = j * T::ITR - 1;
+        const int r_lo = y0 + 1 > 0 ? y0 + 1 : 0, r_hi = y0 + T::ITR < CH - 1 ? y0 + T::ITR : CH - 1;
+        for (int i = 0; i < tx; ++i) {
+            const int x0 = i * T::ITC - 1;
+            const int c_lo = x0 + 1 > 0 ? x0 + 1 : 0, c_hi = x0 + T::ITC < CH - 1 ? x0 + T::ITC : CH - 1;
+            if ((c_hi - r_lo >= 4) && (c_lo - r_hi <= dpx + 1)) out[m++] = j * tx + i;
+        }
+    }
+    return m;
 }
 
 // shared body of mst_scale_space (dense blocks) and mst_scale_space_band (blocks cut out of the band on the fly)
@@ -831,7 +878,10 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
     const int lpo = lv->levels_per_octave;
     for (int o = 0; o < lv->n_octaves; ++o) {
         h.first_level[o] = 1;
-        if (o == 0 || getenv("MST_NO_LEVEL_REUSE")) continue;
+        if (o == 0) continue;
+#ifdef MST_PROFILE
+        if (getenv("MST_NO_LEVEL_REUSE")) continue;       // PROFILE builds only: time the 24-blur form
+#endif
         bool same = true;
         for (int q = 0; q < 2 && same; ++q) {
             const int a = (o - 1) * lpo + lpo - 2 + q, b = o * lpo + q;      // (prev octave, k = lpo-1+q) vs (this, k = 1+q)
@@ -845,6 +895,8 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
     w += align_up(sizeof(DevLevels), 256);
     int64_t *d_starts = reinterpret_cast<int64_t *>(w);
     w += align_up(sizeof(int64_t) * (size_t)B, 256);
+    int32_t *d_tiles = reinterpret_cast<int32_t *>(w);
+    w += align_up(sizeof(int32_t) * (size_t)nt_tiles_max(CH), 256);
     double *partial = reinterpret_cast<double *>(w);
     MST_HIP(hipMemcpyAsync(d_lv, &h, sizeof(h), hipMemcpyHostToDevice, s));
     MST_HIP(hipMemsetAsync(found_count, 0, sizeof(uint32_t) * B, s));
@@ -854,22 +906,34 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
         src.starts = d_starts;
     }
 
-    int ntiles;
     if (fma && mr > TileDefault::RMAX)
         return mst::fail(MST_E_ARG, "%s: MST_FLAG_FMA is only built for blur radii <= %d", who, TileDefault::RMAX);
-    if (fma) {
-        rc = launch_scale_space<TileDefaultFma, BAND>(c, nz, src, B, CH, d_lv, found, found_cap, found_count, partial,
-                                                      nt, skip_empty, s);
-        ntiles = tiles_total<TileDefault>(CH);
-    } else if (mr <= TileDefault::RMAX) {
-        rc = launch_scale_space<TileDefault, BAND>(c, nz, src, B, CH, d_lv, found, found_cap, found_count, partial, nt,
-                                                   skip_empty, s);
-        ntiles = tiles_total<TileDefault>(CH);
-    } else {
-        rc = launch_scale_space<TileWide, BAND>(c, nz, src, B, CH, d_lv, found, found_cap, found_count, partial, nt,
-                                                skip_empty, s);
-        ntiles = tiles_total<TileWide>(CH);
+    const bool wide = mr > TileDefault::RMAX;
+    int ntiles = wide ? tiles_total<TileWide>(CH) : tiles_total<TileDefault>(CH);
+    const int32_t *tile_list = nullptr;
+    if (BAND && skip_empty) {
+        // only the tiles that can reach the tested band are launched (identical results: the others would return at once)
+        static thread_local std::vector<int32_t> host_list;
+        host_list.resize((size_t)ntiles);
+        ntiles = wide ? band_tile_list<TileWide>(CH, src.dpx, host_list.data())
+                      : band_tile_list<TileDefault>(CH, src.dpx, host_list.data());
+        if (ntiles == 0) {          // no tile reaches the band: nothing is tested, nothing is found
+            fill_stats_kernel<<<(B * MST_MAX_TESTED + 255) / 256, 256, 0, s>>>(level_stats, B * MST_MAX_TESTED);
+            MST_LAUNCH_CHECK();
+            return MST_OK;
+        }
+        MST_HIP(hipMemcpyAsync(d_tiles, host_list.data(), sizeof(int32_t) * (size_t)ntiles, hipMemcpyHostToDevice, s));
+        tile_list = d_tiles;
     }
+    if (fma)
+        rc = launch_scale_space<TileDefaultFma, BAND>(c, nz, src, B, CH, d_lv, found, found_cap, found_count, partial,
+                                                      nt, skip_empty, tile_list, ntiles, s);
+    else if (!wide)
+        rc = launch_scale_space<TileDefault, BAND>(c, nz, src, B, CH, d_lv, found, found_cap, found_count, partial, nt,
+                                                   skip_empty, tile_list, ntiles, s);
+    else
+        rc = launch_scale_space<TileWide, BAND>(c, nz, src, B, CH, d_lv, found, found_cap, found_count, partial, nt,
+                                                skip_empty, tile_list, ntiles, s);
     if (rc != MST_OK) return rc;
     stats_reduce_kernel<<<dim3(nt, B), 256, 0, s>>>(partial, ntiles, nt, level_stats);
     MST_LAUNCH_CHECK();

@@ -343,7 +343,10 @@ extern "C" int mst_found_pvalues(const mst_found *found, uint32_t found_cap, con
     MST_HIP(hipFreeAsync(d_flags, s));
     if (flags & 1)
         return mst::fail(MST_E_OVERFLOW, "found-pixel capacity %u exceeded in at least one block", found_cap);
-    if ((flags & 2) && !getenv("MST_IGNORE_NONFINITE"))     // (the env hook exists for timing ablations only)
+#ifdef MST_PROFILE
+    if (getenv("MST_IGNORE_NONFINITE")) flags &= ~2;        // PROFILE builds only: timing ablations produce garbage statistics
+#endif
+    if (flags & 2)
         return mst::fail(MST_E_NONFINITE, "non-finite DoG statistics (input block holds NaN/inf)");
     return MST_OK;
 }

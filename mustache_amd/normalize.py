@@ -27,21 +27,22 @@ def band_to_coo(band, x, y, v_out, n, dpx):
     return v_out
 
 
-def normalize_band(band, n, dpx, resolution):
+def normalize_band(band, n, dpx, resolution, blocked=False):
     """Returns (normalised band, diag_stats [dpx+2, 4] = mean, std, weight, count).  Branch selection and window
-    size follow mustache.py:628, :631."""
+    size follow mustache.py:628, :631.  `blocked=True` asks for the blocked-sum kernel of branch A whatever the window
+    (mst_normalize_band's local == 2; the tests cross-check the two kernels)."""
     lib = require_gpu()
     local = (n - dpx) * resolution > 2000000
     window = int(2000000 / resolution)
     out = torch.empty_like(band)
     stats = torch.empty((dpx + 2, 4), dtype=torch.float64, device=band.device)
     with torch.cuda.device(band.device):
-        _lib.check(lib.mst_normalize_band(_ptr(band), _ptr(out), int(n), int(dpx), window, 1 if local else 0,
+        _lib.check(lib.mst_normalize_band(_ptr(band), _ptr(out), int(n), int(dpx), window, (2 if blocked else 1) if local else 0,
                                           _ptr(stats), _stream()))
     return out, stats, local
 
 
-def normalize_sparse_device(x, y, v, resolution, distance_in_px):
+def normalize_sparse_device(x, y, v, resolution, distance_in_px, blocked=False):
     """Host COO in, `v` overwritten in place, weights returned -- the reference's call shape."""
     require_gpu()
     xh = np.ascontiguousarray(np.asarray(x), dtype=np.int64)
@@ -51,7 +52,7 @@ def normalize_sparse_device(x, y, v, resolution, distance_in_px):
     xd, yd = torch.from_numpy(xh).to(dev), torch.from_numpy(yh).to(dev)
     vd = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(dev)
     band = band_from_coo(xd, yd, vd, n, distance_in_px)
-    out, stats, local = normalize_band(band, n, distance_in_px, resolution)
+    out, stats, local = normalize_band(band, n, distance_in_px, resolution, blocked=blocked)
     band_to_coo(out, xd, yd, vd, n, distance_in_px)
     v[...] = vd.cpu().numpy()
     st = stats.cpu().numpy()

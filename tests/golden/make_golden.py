@@ -150,11 +150,11 @@ def make_block(ref, name, n, dpx, seed, start, st, pt, depth=300.0, nloops=None,
           "pzero", int((locs["pAll"] == 0).sum()) if "pAll" in locs else None)
 
 
-def make_big_block(ref):
-    """One block of BASELINE's 5 kb geometry (2000 x 2000, distance limit 400 px).  The input is the raw synthetic map
-    (regenerated from the seed by the tests, so only its checksum is stored) and the outputs are kept compact: loops,
-    the 18 expon fits, per-level Gaussian sums, and order-independent checksums of the found set."""
-    n, dpx, seed, start, st, pt = 2000, 400, 3, 3200, 0.8, 0.1
+def make_big_block(ref, name="block_2000", n=2000, dpx=400, seed=3, start=3200, st=0.8, pt=0.1):
+    """One block of BASELINE's 5 kb geometry (2000 x 2000, distance limit 400 px) -- or, as `block_4000`, of the headline
+    1 kb geometry (4000 x 4000, distance limit 2000 px; the reference needs ~80 s and ~3 GB for it).  The input is the raw
+    synthetic map (regenerated from the seed by the tests, so only its checksum is stored) and the outputs are kept
+    compact: loops, the 18 expon fits, per-level Gaussian sums, and order-independent checksums of the found set."""
     x, y, v = synth_coo(n, dpx, depth=300.0, seed=seed)
     c = dense(x, y, v, n)
     loops, cap, locs = run_mustache_traced(ref, c, start, dpx, st, pt)
@@ -162,7 +162,7 @@ def make_big_block(ref):
     found = locs["pAll"] != 2
     pix = np.flatnonzero(nz.ravel())[found].astype(np.int64)
     sig = locs["Scales"][found]
-    np.savez_compressed(os.path.join(HERE, "block_2000.npz"), n=n, dpx=dpx, seed=seed, depth=300.0, start=start, st=st,
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), n=n, dpx=dpx, seed=seed, depth=300.0, start=start, st=st,
                         pt=pt, in_nnz=len(v), in_checksum=float(v.sum()), nz_count=int(nz.sum()),
                         loops=loops_array(loops), fit=np.array(cap["fit"]).reshape(-1, 3),
                         g_sum=np.array([g[2] for g in cap["gauss"]]), found_count=int(found.sum()),
@@ -171,7 +171,7 @@ def make_big_block(ref):
                         found_value_max=float(np.max(locs["vAll"][found])),
                         found_pvalue_sum=float(np.sum(locs["pAll"][found])),
                         found_pixels_head=pix[:4096].astype(np.int32), found_values_head=locs["vAll"][found][:4096])
-    print("block_2000 nz", int(nz.sum()), "found", int(found.sum()), "loops", len(loops))
+    print(name, "nz", int(nz.sum()), "found", int(found.sum()), "loops", len(loops))
 
 
 def make_edges(ref):
@@ -285,15 +285,17 @@ def make_regulator(ref):
     print("regulator loops", len(la))
 
 
-def make_diff():
-    """Two-sample path: run the reference's diff_mustache() on one 320x320 block pair and keep its locals."""
+def make_diff(name="diff_320", n=320, dpx=80, start=640, res=50000, nloops=30, pt=0.3, pt2=0.3, compact=False):
+    """Two-sample path: run the reference's diff_mustache() on one block pair and keep its locals.  `diff_320`: a small
+    pair with full inputs and locals; `diff_2000` (compact=True): BASELINE config 5's 5 kb block geometry (2000 x 2000,
+    distance limit 400 px), inputs regenerated from the seeds by the tests, outputs as checksums + the four loop lists."""
     ref = load_reference("mustache")
     dref = load_reference("diff_mustache")
-    n, dpx, start = 320, 80, 640
-    xa, ya, va = synth_coo(n, dpx, depth=300.0, seed=51, nloops=30)
-    xb, yb, vb = synth_coo(n, dpx, depth=260.0, seed=52, nloops=30)
-    ref.normalize_sparse(xa, ya, va, 50000, dpx)
-    ref.normalize_sparse(xb, yb, vb, 50000, dpx)
+    xa, ya, va = synth_coo(n, dpx, depth=300.0, seed=51, nloops=nloops)
+    xb, yb, vb = synth_coo(n, dpx, depth=260.0, seed=52, nloops=nloops)
+    sums = (float(va.sum()), float(vb.sum()), len(va), len(vb))
+    ref.normalize_sparse(xa, ya, va, res, dpx)
+    ref.normalize_sparse(xb, yb, vb, res, dpx)
     c1, c2 = dense(xa, ya, va, n), dense(xb, yb, vb, n)
     fits = []
     fit0 = dref.norm.fit
@@ -311,7 +313,7 @@ def make_diff():
 
         def local(frame, event, arg):
             if event == "return":
-                for k in ("pAll1", "pAll2", "pPair1", "pPair2", "vAll1", "vAll2", "Scales1", "Scales2"):
+                for k in ("nz1", "nz2", "pAll1", "pAll2", "pPair1", "pPair2", "vAll1", "vAll2", "Scales1", "Scales2"):
                     if k in frame.f_locals:
                         locs[k] = np.array(frame.f_locals[k], copy=True)
             return local
@@ -320,21 +322,41 @@ def make_diff():
     dref.norm.fit = nfit
     sys.settrace(tracer)
     try:
-        out = dref.diff_mustache(c1.copy(), c2.copy(), "1", "1", 5000, start, start + n, 0, dpx, OCTAVES, 0.8, 0.3, 0.3)
+        out = dref.diff_mustache(c1.copy(), c2.copy(), "1", "1", 5000, start, start + n, 0, dpx, OCTAVES, 0.8, pt, pt2)
     finally:
         sys.settrace(None)
         dref.norm.fit = fit0
-    np.savez_compressed(os.path.join(HERE, "diff_320.npz"), xa=xa.astype(np.int32), ya=ya.astype(np.int32), va=va,
-                        xb=xb.astype(np.int32), yb=yb.astype(np.int32), vb=vb, n=n, dpx=dpx, start=start,
-                        st=0.8, pt=0.3, pt2=0.3, norm_fit=np.array(fits),
-                        loops1=loops_array(out[0]), diff1=loops_array(out[1]), loops2=loops_array(out[2]),
-                        diff2=loops_array(out[3]), **{"loc_" + k: v for k, v in locs.items()})
-    print("diff", [len(o) for o in out], {k: v.shape for k, v in locs.items()})
+    lists = dict(loops1=loops_array(out[0]), diff1=loops_array(out[1]), loops2=loops_array(out[2]),
+                 diff2=loops_array(out[3]))
+    if compact:
+        extra = {}
+        for s_ in ("1", "2"):
+            f = locs["pAll" + s_] != 2
+            pix = np.flatnonzero(locs["nz" + s_].ravel())[f].astype(np.int64)
+            extra.update({"found_count" + s_: int(f.sum()), "found_pixel_sum" + s_: int(pix.sum()),
+                          "found_pixel_xor" + s_: int(np.bitwise_xor.reduce(pix)),
+                          "found_value_sum" + s_: float(np.sum(locs["vAll" + s_][f])),
+                          "found_pvalue_sum" + s_: float(np.sum(locs["pAll" + s_][f])),
+                          "found_pair_sum" + s_: float(np.sum(locs["pPair" + s_][f])),
+                          "found_sigma_sum" + s_: float(np.sum(locs["Scales" + s_][f])),
+                          "nz_count" + s_: int(locs["nz" + s_].sum())})
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), n=n, dpx=dpx, start=start, res=res, nloops=nloops,
+                            st=0.8, pt=pt, pt2=pt2, in_sums=np.array(sums), norm_fit=np.array(fits), **lists, **extra)
+    else:
+        locs.pop("nz1", None), locs.pop("nz2", None)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), xa=xa.astype(np.int32), ya=ya.astype(np.int32), va=va,
+                            xb=xb.astype(np.int32), yb=yb.astype(np.int32), vb=vb, n=n, dpx=dpx, start=start,
+                            st=0.8, pt=pt, pt2=pt2, norm_fit=np.array(fits), **lists,
+                            **{"loc_" + k: v for k, v in locs.items()})
+    print(name, [len(o) for o in out], {k: v.shape for k, v in locs.items()})
 
 
 if __name__ == "__main__":
     if sys.argv[1:] == ["diff"]:
         make_diff()
+        sys.exit(0)
+    if sys.argv[1:] == ["diff2000"]:      # BASELINE config 5's block geometry (~1 min in the reference)
+        make_diff("diff_2000", n=2000, dpx=400, start=3200, res=5000, nloops=None, pt=0.3, pt2=0.3, compact=True)
         sys.exit(0)
     ref = load_reference("mustache")
     which = sys.argv[1:] or ["norm", "blocks", "big", "edges", "tiling", "regulator"]
@@ -345,6 +367,8 @@ if __name__ == "__main__":
         make_block(ref, "block_512", 512, 128, seed=2, start=0, st=0.7, pt=0.2, depth=200.0, nloops=40)
     if "big" in which:
         make_big_block(ref)
+    if "big4000" in which:          # BASELINE config 4's block geometry (not in the default list: ~2 min, ~3 GB)
+        make_big_block(ref, "block_4000", n=4000, dpx=2000, seed=4, start=8000, st=0.8, pt=0.1)
     if "edges" in which:
         make_edges(ref)
     if "tiling" in which:

@@ -158,14 +158,7 @@ def _big_block(g):
     return c, n, dpx
 
 
-def test_baseline_size_block_vs_reference_fixture(eng, golden_dir):
-    """BASELINE's 5 kb block geometry (2000 x 2000, distance limit 400 px) against outputs of the REFERENCE ITSELF
-    (tests/golden/block_2000.npz, made by make_golden.py): tested-pixel count, the whole found set through order-independent
-    checksums plus its first 4096 records, the 18 expon fits, and the final loop list of the drop-in mustache()."""
-    from mustache_amd.mustache import mustache
-    g = _load(golden_dir, "block_2000.npz")
-    c, n, dpx = _big_block(g)
-    dev, nz_d, nzc, found, fit = _run_block(eng, c.copy(), dpx, True)
+def _check_found_set(eng, g, nzc, found, fit):
     assert nzc == int(g["nz_count"])
     pix = found["pixel"].astype(np.int64)
     assert len(pix) == int(g["found_count"])
@@ -176,8 +169,33 @@ def test_baseline_size_block_vs_reference_fixture(eng, golden_dir):
     sig = np.asarray(eng.levels.tested_sigma)[found["level"].astype(int) - 1]
     np.testing.assert_allclose(float(np.sum(sig)), float(g["found_sigma_sum"]), rtol=1e-13)
     np.testing.assert_allclose(float(np.sum(found["value"])), float(g["found_value_sum"]), rtol=1e-12)
+    # (the reference overwrites pAll with the BH q-values before it returns, mustache.py:778-779: the fixture's "pvalue" sum is the q sum)
+    np.testing.assert_allclose(float(np.sum(found["q"])), float(g["found_pvalue_sum"]), rtol=1e-9)
     assert np.array_equal(fit[0], g["fit"][:, 0])
     np.testing.assert_allclose(fit[1], g["fit"][:, 1], rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["block_2000.npz", "block_4000.npz"])
+def test_baseline_size_block_vs_reference_fixture(eng, golden_dir, name):
+    """BASELINE's block geometries -- 5 kb: 2000 x 2000, distance limit 400 px; 1 kb (the headline workload): 4000 x 4000,
+    distance limit 2000 px -- against outputs of the REFERENCE ITSELF (tests/golden/block_*.npz, made by make_golden.py):
+    tested-pixel count, the whole found set through order-independent checksums plus its first 4096 records, the 18 expon
+    fits, and the final loop list of the drop-in mustache().  Every form of the fused kernel is held to it: dense-block
+    source and band-direct source, each with and without empty-tile skipping."""
+    import torch
+    from mustache_amd.mustache import mustache
+    from mustache_amd.normalize import band_from_coo
+    g = _load(golden_dir, name)
+    c, n, dpx = _big_block(g)
+    for skip_empty in (True, False):
+        dev, nz_d, nzc, found, fit = _run_block(eng, c.copy(), dpx, skip_empty)
+        _check_found_set(eng, g, nzc, found, fit)
+        del dev, nz_d
+    x, y = np.nonzero(c)
+    band = band_from_coo(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(c[x, y]).cuda(), n, dpx)
+    for skip_empty in (True, False):
+        found, fits, nzc = eng.sigma_loop_band(band, n, dpx, [0], n, skip_empty=skip_empty)
+        _check_found_set(eng, g, int(nzc.cpu().numpy().view(np.uint32)[0]), found[0], fits[0])
     start = int(g["start"])
     loops = mustache(c, "1", "1", 5000, [], start, start + n, 0, dpx, OCT, float(g["st"]), float(g["pt"]))
     exp = g["loops"]

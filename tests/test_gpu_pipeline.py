@@ -347,6 +347,7 @@ def test_normalisation_kernel_vs_oracle_at_real_window_sizes(n, dpx, res, depth)
     window sums depend on the BLAS build), and the blocked-sum fallback kernel gives the same."""
     import oracle
     from mustache_amd.mustache import normalize_sparse
+    from mustache_amd.normalize import normalize_sparse_device
     from mustache_amd.synth import synth_coo
     x, y, v = synth_coo(n, dpx, depth=depth, seed=9)
     exp = v.copy()
@@ -355,12 +356,8 @@ def test_normalisation_kernel_vs_oracle_at_real_window_sizes(n, dpx, res, depth)
     normalize_sparse(x, y, got, res, dpx)
     np.testing.assert_allclose(got, exp, rtol=1e-9, atol=1e-9)
     assert np.count_nonzero(got) > 0.9 * len(got)
-    os.environ["MST_NORMALIZE_BLOCKED"] = "1"
-    try:
-        alt = v.copy()
-        normalize_sparse(x, y, alt, res, dpx)
-    finally:
-        del os.environ["MST_NORMALIZE_BLOCKED"]
+    alt = v.copy()
+    normalize_sparse_device(x, y, alt, res, dpx, blocked=True)
     np.testing.assert_allclose(alt, exp, rtol=1e-9, atol=1e-9)
 
 

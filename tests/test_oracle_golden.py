@@ -171,11 +171,12 @@ def test_diff_block_vs_reference(golden_dir):
 
 
 @pytest.mark.slow
-def test_baseline_size_block_vs_reference(golden_dir):
-    """The oracle on BASELINE's 5 kb block geometry (2000 x 2000, dpx 400) against the reference's own outputs
-    (block_2000.npz): fits, found-set checksums, loops -- bit for bit."""
+@pytest.mark.parametrize("name", ["block_2000.npz", "block_4000.npz"])
+def test_baseline_size_block_vs_reference(golden_dir, name):
+    """The oracle on BASELINE's block geometries (5 kb: 2000 x 2000, dpx 400; 1 kb headline: 4000 x 4000, dpx 2000) against
+    the reference's own outputs (block_2000.npz / block_4000.npz): fits, found-set checksums, loops -- bit for bit."""
     from mustache_amd.synth import synth_coo
-    g = _load(golden_dir, "block_2000.npz")
+    g = _load(golden_dir, name)
     n, dpx = int(g["n"]), int(g["dpx"])
     x, y, v = synth_coo(n, dpx, depth=float(g["depth"]), seed=int(g["seed"]))
     assert len(v) == int(g["in_nnz"]) and v.sum() == float(g["in_checksum"])

@@ -13,9 +13,12 @@
  * hic-straw is a third-party dependency that is absent from the reference tree and from the build image, and no `.hic`
  * file is available offline: the file layout below is restated from the published format (Juicer / straw,
  * github.com/aidenlab/straw, `straw.cpp`: readHeader, readFooter, readMatrixZoomData, readBlock, readNormalizationVector)
- * and is exercised against files produced by tests/hic_writer.py, an independent writer of the same layout.  Parity
- * with hic-straw on a real file is UNPINNED here; mustache_amd.readers keeps a hic-straw backend for cross-checking
- * wherever that module is installed (MUSTACHE_HIC_BACKEND=hicstraw).
+ * and is exercised against files produced by tests/hic_writer.py, an independent writer of the same layout.  The HEADER
+ * parse (magic, version, master-index offset, genome, attributes, chromosome table, resolutions) is pinned on code the
+ * reference tree itself holds -- diff_mustache.py:182-249 readcstr()/read_header(), imported by tests/golden/make_golden.py
+ * for version-8 files (that function predates version 9's 64-bit lengths).  BLOCK decoding -- v8/v9 block indexing, the
+ * float32 norm-vector division, short-count sentinels -- stays UNPINNED against hic-straw; mustache_amd.readers therefore
+ * prefers hic-straw whenever that module is importable and uses this reader otherwise (MUSTACHE_HIC_BACKEND overrides).
  *
  * Conventions: int status (0 = ok, < 0 = MST_IO_E_*), mst_io_last_error() returns a thread-local message, no C++
  * exception crosses the ABI, arrays handed out are malloc'ed and released with mst_io_free().
@@ -48,6 +51,11 @@ int mst_hic_open(const char *path, mst_hic **out);
 void mst_hic_close(mst_hic *h);
 
 int32_t mst_hic_version(const mst_hic *h);
+/* Header fields as the reference's own (unused) header parser returns them, diff_mustache.py:201-249 read_header():
+ * file offset of the master index (footer) and the genome id.  tests/golden/hic_header_v8.npz pins the header parse
+ * on that function. */
+int64_t mst_hic_master_offset(const mst_hic *h);
+const char *mst_hic_genome(const mst_hic *h);
 /* Chromosomes in file order, index 0 is usually the pseudo-chromosome "All" (the reference skips it, mustache.py:311). */
 int32_t mst_hic_n_chromosomes(const mst_hic *h);
 int mst_hic_chromosome(const mst_hic *h, int32_t i, const char **name, int64_t *length);

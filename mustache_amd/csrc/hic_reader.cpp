@@ -451,6 +451,8 @@ extern "C" void mst_hic_close(mst_hic *h) {
 }
 
 extern "C" int32_t mst_hic_version(const mst_hic *h) { return h ? h->version : 0; }
+extern "C" int64_t mst_hic_master_offset(const mst_hic *h) { return h ? h->master : 0; }
+extern "C" const char *mst_hic_genome(const mst_hic *h) { return h ? h->genome.c_str() : ""; }
 extern "C" int32_t mst_hic_n_chromosomes(const mst_hic *h) { return h ? (int32_t)h->chroms.size() : 0; }
 extern "C" int mst_hic_chromosome(const mst_hic *h, int32_t i, const char **name, int64_t *length) {
     if (!h || i < 0 || (size_t)i >= h->chroms.size()) return fail(MST_IO_E_ARG, "mst_hic_chromosome: bad index");

@@ -48,6 +48,20 @@
 #define MST_VARIANT(bit_) 0
 #endif
 
+// PROFILE builds can record a phase timeline (s_memtime per wave at the phase boundaries of every level) for a sample of
+// workgroups: MST_TRACE=<file> (scripts/trace_timeline.py reads it).  ~+10 % run time while it is on.
+#ifdef MST_PROFILE
+#define MST_TRACE_WGS 64
+#define MST_TRACE_STAMPS 8
+#define MST_STAMP(tr_, slot_)                                                        \
+    if (tr_) {                                                                       \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                  \
+        if ((threadIdx.x & 63) == 0) (tr_)[slot_] = t_;                              \
+    }
+#else
+#define MST_STAMP(tr_, slot_)
+#endif
+
 #ifndef MST_KC8_BELOW
 #define MST_KC8_BELOW 11      // radii below this use one 8-output window per item, wider ones two 4-output windows
 #endif
@@ -97,7 +111,7 @@ struct Tile {
     static constexpr int CT_ELEMS = CTC * CTP;
     static constexpr int VB_ELEMS = RGR * VP;
     static constexpr int DE_ELEMS = NCG * 2 * RGR;           // edge strip: [cg][left/right][row]
-    static constexpr int ST_ELEMS = MST_MAX_TESTED * NW * 2;
+    static constexpr int ST_ELEMS = MST_MAX_TESTED * NW * 2;  // per (level, wave) partial {min, sum}
     static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)(CT_ELEMS + VB_ELEMS + DE_ELEMS + ST_ELEMS);
     static_assert(NT % 64 == 0 && RGR % K == 0 && RGC % K == 0, "whole waves, whole groups");
     static_assert(64 % RGR == 0 || RGR % 64 == 0, "a wave holds whole runs of consecutive rows");
@@ -319,19 +333,22 @@ __device__ __forceinline__ void hpass(const double *__restrict__ p, const double
 template <class T, int R>
 __device__ __forceinline__ void blur_level(const double *ct, double *vb, const double (&w)[T::RMAX + 1], int tid,
                                            const double *vsrc, double *vdst, const double *hsrc, double (&g)[T::K],
-                                           int variant) {
+                                           int variant, unsigned long long *tr) {
     vpass<T, R>(ct, vb, w, tid, vsrc, vdst, variant);
+    MST_STAMP(tr, 1)
     __syncthreads();
+    MST_STAMP(tr, 2)
     hpass<T, R>(hsrc, w, g);
+    MST_STAMP(tr, 3)
 }
 
 template <class T>
 __device__ __forceinline__ void blur_dispatch(int r, const double *ct, double *vb, const double (&wg)[T::RMAX + 1],
                                               int tid, const double *vsrc, double *vdst, const double *hsrc,
-                                              double (&g)[T::K], int variant) {
+                                              double (&g)[T::K], int variant, unsigned long long *tr) {
 #define MST_CASE(R_)                                                  \
     case R_:                                                          \
-        if constexpr (R_ <= T::RMAX) blur_level<T, R_>(ct, vb, wg, tid, vsrc, vdst, hsrc, g, variant); \
+        if constexpr (R_ <= T::RMAX) blur_level<T, R_>(ct, vb, wg, tid, vsrc, vdst, hsrc, g, variant, tr); \
         break;
     switch (r) {
         MST_CASE(1) MST_CASE(2) MST_CASE(3) MST_CASE(4) MST_CASE(5) MST_CASE(6) MST_CASE(7)
@@ -359,7 +376,8 @@ __global__ void __launch_bounds__(T::NT, T::MINW)
 scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz, BandSrc src, int CH,
                    const DevLevels *__restrict__ lv, mst_found *__restrict__ found, uint32_t found_cap,
                    uint32_t *__restrict__ found_count, double *__restrict__ partial, int tiles_x, int tiles_y,
-                   int n_tested, int skip_empty, const int32_t *__restrict__ tile_list, int n_slots, int variant) {
+                   int n_tested, int skip_empty, const int32_t *__restrict__ tile_list, int n_slots, int variant,
+                   unsigned long long *__restrict__ trace) {
     constexpr int K = T::K, RGR = T::RGR, RGC = T::RGC, RMAX = T::RMAX;
     extern __shared__ __align__(16) double lds[];
     double *ct = lds;
@@ -453,12 +471,25 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
         uint8_t *nzb = reinterpret_cast<uint8_t *>(vb);      // [RGR][RGC] tested flags of the region; vb is free until the V pass
         const int Y0 = y0 - RMAX, X0 = x0 - RMAX;
         const bool inner = Y0 >= 0 && X0 >= 0 && Y0 + T::CTR <= CH && X0 + T::CTC <= CH;   // no reflection in this tile
-        if (inner) {
+        // the tile incl. its halo lies entirely in one of the constant regions, col - row <= 3 or >= dpx + 2 (diagonals 4 and
+        // dpx + 1 are filled too, but their pixels can be TESTED, mustache.py:699 vs :703-706): every sample is the fill
+        // value and no pixel is tested -- the same LDS contents as the general walk below, written with wide stores
+        const bool constant = inner && (X0 + T::CTC - 1 - Y0 <= 3 || X0 - (Y0 + T::CTR - 1) >= dpx + 2);
+        if (constant) {
+            double2 *ct2 = reinterpret_cast<double2 *>(ct);
+            for (int i = tid; i < T::CT_ELEMS / 2; i += T::NT) ct2[i] = make_double2(2.0, 2.0);
+            uint4 *nz4 = reinterpret_cast<uint4 *>(nzb);
+            static_assert((RGR * RGC) % 16 == 0, "nzb is cleared in 16-byte pieces");
+            for (int i = tid; i < RGR * RGC / 16; i += T::NT) nz4[i] = make_uint4(0, 0, 0, 0);
+        } else if (inner) {
             // walk the tile by diagonals: pixels (Y0+i, X0+i+dd) of one diagonal are CONTIGUOUS in band row off = X0-Y0+dd,
-            // so a wave reads one 480-byte run per diagonal; the fill decision is wave-uniform
+            // so a wave reads one 480-byte run per diagonal; the fill decision is wave-uniform.  All loads of a wave's
+            // share (U diagonals per round, two rounds) are issued before the first LDS store: the staging is latency
+            // bound (each diagonal lives in a different band row), so memory-level parallelism is what shortens it.
             constexpr int ND = T::CTR + T::CTC - 1;
-            constexpr int U = 8;                         // diagonals in flight per wave: loads first, then the LDS stores
             constexpr int PER = (T::CTR + 63) / 64;      // elements of one diagonal per lane
+            constexpr int U2 = (ND + 2 * T::NW - 1) / (2 * T::NW);
+            constexpr int U = U2 * PER <= 20 ? U2 : 20 / PER;       // diagonals in flight per wave: loads first, then the stores
             for (int q0 = tid >> 6; q0 < ND; q0 += T::NW * U) {
                 double rawv[U][PER];
 #pragma unroll
@@ -564,6 +595,15 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
     const int n_oct = MST_VARIANT(4) ? 0 : lv->n_octaves, lpo = lv->levels_per_octave;   // [ablation 4: staging + epilogue only]
     const int prot = (int)(blockIdx.x >> 3) * 2 + (int)(blockIdx.x >> 11);
     int tested = 0;
+    unsigned long long *tr = nullptr;
+#ifdef MST_PROFILE
+    // timeline sample: MST_TRACE_WGS consecutive slots of block 0, starting at 3/8 of the grid (tiles inside the band)
+    if (trace && b == 0 && slot >= 3 * (n_slots >> 3) && slot < 3 * (n_slots >> 3) + MST_TRACE_WGS) {
+        tr = trace + ((size_t)(slot - 3 * (n_slots >> 3)) * T::NW + (tid >> 6)) * (MST_MAX_LEVELS + 1) * MST_TRACE_STAMPS;
+        MST_STAMP(tr, MST_MAX_LEVELS * MST_TRACE_STAMPS + 1)        // end of staging
+        if ((tid & 63) == 0) tr[MST_MAX_LEVELS * MST_TRACE_STAMPS + 2] = (unsigned long long)tile | ((unsigned long long)(nz_mask != 0) << 40);
+    }
+#endif
     for (int o = 0; o < n_oct; ++o) {
         // With octaves a factor 2 apart and s = 10, sigma_11 and sigma_12 of one octave are bit-identical to sigma_1 and
         // sigma_2 of the next (checked on the host), so G_1, G_2 and D_1 of the new octave are exactly the G_11, G_12
@@ -572,6 +612,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
         for (int kl = lv->first_level[o]; kl <= lpo; ++kl) {
             const int l = o * lpo + kl - 1;
             const int r = lv->radius[l];
+            MST_STAMP(tr, 0)
             // the level's taps, fetched ONCE (scalar loads, wave-uniform -> SGPRs) and shared by both passes
             double taps[RMAX + 1];
 #pragma unroll
@@ -580,7 +621,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
             // the leftover V-pass pieces occupy the first ceil(R/4) waves of a rotated wave order, so that over the
             // levels (and between the workgroups sharing a CU) every SIMD carries the same share of them
             const int ptid = (tid + 64 * ((l + prot) & 3)) & (T::NT - 1);
-            blur_dispatch<T>(r, ct, vb, taps, ptid, vsrc, vdst, hsrc, g, variant);
+            blur_dispatch<T>(r, ct, vb, taps, ptid, vsrc, vdst, hsrc, g, variant, tr);
             double d[K];
             if (kl >= 2) {
 #pragma unroll
@@ -595,7 +636,13 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) gprev[k] = g[k];
+            MST_STAMP(tr, 4)
             __syncthreads();   // edge strip visible; every H-pass read of vb is done before the next V pass writes it
+            MST_STAMP(tr, 5)
+#ifdef MST_PROFILE
+            unsigned long long *tr_lvl = tr;
+            if (tr) tr += MST_TRACE_STAMPS;
+#endif
             if (kl < 2) continue;
             if (MST_VARIANT(1)) continue;     // [ablation 1] blur + DoG only
 
@@ -655,6 +702,9 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
                 Mc[k] = m[k];
                 Dc[k] = d[k];
             }
+#ifdef MST_PROFILE
+            MST_STAMP(tr_lvl, 6)
+#endif
         }
     }
 
@@ -712,17 +762,23 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
     }
 }
 
-// partial[b][tile][t][2] -> level_stats[b][t][2], fixed summation order (tile-major, then a fixed tree)
+// partial[b][slot][t][2] -> level_stats[b][t][2].  The summation order is fixed by the TILE numbering (thread i takes tiles
+// i, i + 256, ... in ascending order, then a fixed tree), whether or not only a list of tiles was launched: a tile that
+// is not in the list (slot_of_tile < 0) would have contributed {inf, 0}, which changes neither the minimum nor the sum,
+// so a block's statistics do not depend on MST_FLAG_SKIP_EMPTY down to the last bit.
 __global__ void __launch_bounds__(256)
-stats_reduce_kernel(const double *__restrict__ partial, int ntiles, int n_tested, double *__restrict__ level_stats) {
+stats_reduce_kernel(const double *__restrict__ partial, int ntiles, int n_slots, const int32_t *__restrict__ slot_of_tile,
+                    int n_tested, double *__restrict__ level_stats) {
     __shared__ double smin[256], ssum[256];
     const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const double *p = partial + (size_t)b * ntiles * n_tested * 2;
+    const double *p = partial + (size_t)b * n_slots * n_tested * 2;
     double mn = INFINITY, sm = 0.0;
     for (int i = tid; i < ntiles; i += 256) {
-        const double a = p[((size_t)i * n_tested + t) * 2];
+        const int slot = slot_of_tile ? slot_of_tile[i] : i;
+        if (slot < 0) continue;
+        const double a = p[((size_t)slot * n_tested + t) * 2];
         mn = a < mn ? a : mn;
-        sm = sm + p[((size_t)i * n_tested + t) * 2 + 1];
+        sm = sm + p[((size_t)slot * n_tested + t) * 2 + 1];
     }
     smin[tid] = mn;
     ssum[tid] = sm;
@@ -803,7 +859,7 @@ extern "C" uint64_t mst_scale_space_workspace_bytes(int32_t B, int32_t CH, const
     if (B <= 0 || CH <= 0 || check_levels(lv, &mr, &nt) != MST_OK) return 0;
     const int nt_tiles = mr <= TileDefault::RMAX ? tiles_total<TileDefault>(CH) : tiles_total<TileWide>(CH);
     return align_up(sizeof(DevLevels), 256) + align_up(sizeof(int64_t) * (size_t)B, 256) +
-           align_up(sizeof(int32_t) * (size_t)nt_tiles_max(CH), 256) + sizeof(double) * 2 * (size_t)B * nt_tiles * nt;
+           align_up(sizeof(int32_t) * 2 * (size_t)nt_tiles_max(CH), 256) + sizeof(double) * 2 * (size_t)B * nt_tiles * nt;
 }
 
 template <class T, bool BAND>
@@ -816,14 +872,35 @@ static int launch_scale_space(const double *c, const uint8_t *nz, BandSrc src, i
     const int tx = tiles_x<T>(CH), ty = tiles_y<T>(CH);
     const int gx = (n_slots + 7) / 8 * 8;
     int variant = 0;
+    unsigned long long *trace = nullptr;
 #ifdef MST_PROFILE
     const char *venv = getenv("MST_ABLATE");          // timing ablations (results invalid), PROFILE builds only
     variant = venv ? atoi(venv) : 0;
+    const char *tpath = getenv("MST_TRACE");          // phase timeline of a sample of workgroups -> file
+    const size_t tbytes = sizeof(unsigned long long) * MST_TRACE_WGS * T::NW * (MST_MAX_LEVELS + 1) * MST_TRACE_STAMPS;
+    if (tpath) {
+        MST_HIP(hipMalloc((void **)&trace, tbytes));
+        MST_HIP(hipMemsetAsync(trace, 0, tbytes, s));
+    }
 #endif
     scale_space_kernel<T, BAND><<<dim3(gx, B), T::NT, T::LDS_BYTES, s>>>(c, nz, src, CH, d_lv, found, found_cap,
                                                                        found_count, partial, tx, ty, n_tested,
-                                                                       skip_empty, tile_list, n_slots, variant);
+                                                                       skip_empty, tile_list, n_slots, variant, trace);
     MST_LAUNCH_CHECK();
+#ifdef MST_PROFILE
+    if (trace) {
+        std::vector<unsigned long long> host(tbytes / sizeof(unsigned long long));
+        MST_HIP(hipStreamSynchronize(s));
+        MST_HIP(hipMemcpy(host.data(), trace, tbytes, hipMemcpyDeviceToHost));
+        MST_HIP(hipFree(trace));
+        if (FILE *f = fopen(tpath, "wb")) {
+            const unsigned long long hdr[4] = {MST_TRACE_WGS, (unsigned long long)T::NW, MST_MAX_LEVELS + 1, MST_TRACE_STAMPS};
+            fwrite(hdr, sizeof(hdr), 1, f);
+            fwrite(host.data(), 1, tbytes, f);
+            fclose(f);
+        }
+    }
+#endif
     return MST_OK;
 }
 
@@ -896,7 +973,7 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
     int64_t *d_starts = reinterpret_cast<int64_t *>(w);
     w += align_up(sizeof(int64_t) * (size_t)B, 256);
     int32_t *d_tiles = reinterpret_cast<int32_t *>(w);
-    w += align_up(sizeof(int32_t) * (size_t)nt_tiles_max(CH), 256);
+    w += align_up(sizeof(int32_t) * 2 * (size_t)nt_tiles_max(CH), 256);
     double *partial = reinterpret_cast<double *>(w);
     MST_HIP(hipMemcpyAsync(d_lv, &h, sizeof(h), hipMemcpyHostToDevice, s));
     MST_HIP(hipMemsetAsync(found_count, 0, sizeof(uint32_t) * B, s));
@@ -909,21 +986,25 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
     if (fma && mr > TileDefault::RMAX)
         return mst::fail(MST_E_ARG, "%s: MST_FLAG_FMA is only built for blur radii <= %d", who, TileDefault::RMAX);
     const bool wide = mr > TileDefault::RMAX;
-    int ntiles = wide ? tiles_total<TileWide>(CH) : tiles_total<TileDefault>(CH);
-    const int32_t *tile_list = nullptr;
+    const int ntiles_all = wide ? tiles_total<TileWide>(CH) : tiles_total<TileDefault>(CH);
+    int ntiles = ntiles_all;
+    const int32_t *tile_list = nullptr, *slot_of_tile = nullptr;
     if (BAND && skip_empty) {
         // only the tiles that can reach the tested band are launched (identical results: the others would return at once)
-        static thread_local std::vector<int32_t> host_list;
-        host_list.resize((size_t)ntiles);
+        static thread_local std::vector<int32_t> host_list;      // [0, ntiles): slot -> tile; [ntiles_all, 2 ntiles_all): tile -> slot
+        host_list.assign(2 * (size_t)ntiles_all, -1);
         ntiles = wide ? band_tile_list<TileWide>(CH, src.dpx, host_list.data())
                       : band_tile_list<TileDefault>(CH, src.dpx, host_list.data());
+        for (int sl = 0; sl < ntiles; ++sl) host_list[(size_t)ntiles_all + host_list[sl]] = sl;
         if (ntiles == 0) {          // no tile reaches the band: nothing is tested, nothing is found
             fill_stats_kernel<<<(B * MST_MAX_TESTED + 255) / 256, 256, 0, s>>>(level_stats, B * MST_MAX_TESTED);
             MST_LAUNCH_CHECK();
             return MST_OK;
         }
-        MST_HIP(hipMemcpyAsync(d_tiles, host_list.data(), sizeof(int32_t) * (size_t)ntiles, hipMemcpyHostToDevice, s));
+        MST_HIP(hipMemcpyAsync(d_tiles, host_list.data(), sizeof(int32_t) * 2 * (size_t)ntiles_all, hipMemcpyHostToDevice,
+                               s));
         tile_list = d_tiles;
+        slot_of_tile = d_tiles + ntiles_all;
     }
     if (fma)
         rc = launch_scale_space<TileDefaultFma, BAND>(c, nz, src, B, CH, d_lv, found, found_cap, found_count, partial,
@@ -935,7 +1016,7 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
         rc = launch_scale_space<TileWide, BAND>(c, nz, src, B, CH, d_lv, found, found_cap, found_count, partial, nt,
                                                 skip_empty, tile_list, ntiles, s);
     if (rc != MST_OK) return rc;
-    stats_reduce_kernel<<<dim3(nt, B), 256, 0, s>>>(partial, ntiles, nt, level_stats);
+    stats_reduce_kernel<<<dim3(nt, B), 256, 0, s>>>(partial, ntiles_all, ntiles, slot_of_tile, nt, level_stats);
     MST_LAUNCH_CHECK();
     return MST_OK;
 }

@@ -27,6 +27,8 @@ _SIGNATURES = {
     "mst_hic_open": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_P)]),
     "mst_hic_close": (None, [_P]),
     "mst_hic_version": (ctypes.c_int32, [_P]),
+    "mst_hic_master_offset": (ctypes.c_int64, [_P]),
+    "mst_hic_genome": (ctypes.c_char_p, [_P]),
     "mst_hic_n_chromosomes": (ctypes.c_int32, [_P]),
     "mst_hic_chromosome": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p),
                                           ctypes.POINTER(ctypes.c_int64)]),
@@ -84,6 +86,14 @@ class HicFile:
     @property
     def version(self):
         return int(self._lib.mst_hic_version(self._h))
+
+    @property
+    def master_offset(self):
+        return int(self._lib.mst_hic_master_offset(self._h))
+
+    @property
+    def genome(self):
+        return self._lib.mst_hic_genome(self._h).decode()
 
     def chromosomes(self):
         """[(name, length)] in file order; entry 0 is usually the pseudo-chromosome "All"."""

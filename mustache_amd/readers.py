@@ -67,11 +67,20 @@ def _dedup(xs, ys, vs):
 
 
 def hic_backend():
-    """"native" (default: libmustache_io.so, no third-party module) or "hicstraw" (MUSTACHE_HIC_BACKEND=hicstraw: the
-    reference's own dependency, kept for cross-checking the native reader wherever hic-straw is installed)."""
-    b = os.environ.get("MUSTACHE_HIC_BACKEND", "native").lower()
-    if b not in ("native", "hicstraw"):
-        raise ValueError("MUSTACHE_HIC_BACKEND must be 'native' or 'hicstraw'")
+    """Which reader serves `.hic` files: "hicstraw" (the reference's own dependency) or "native" (libmustache_io.so).
+    Default ("auto"): hic-straw when that module is importable, the native reader otherwise -- the native reader's block
+    decoding has no real `.hic` file or hic-straw dump to be pinned on in this build environment (only its header parse
+    is pinned on reference-held code, include/mustache_io.h), so wherever the reference's dependency exists it stays the
+    source of truth.  MUSTACHE_HIC_BACKEND=native|hicstraw forces one."""
+    b = os.environ.get("MUSTACHE_HIC_BACKEND", "auto").lower()
+    if b not in ("auto", "native", "hicstraw"):
+        raise ValueError("MUSTACHE_HIC_BACKEND must be 'auto', 'native' or 'hicstraw'")
+    if b == "auto":
+        import importlib.util
+        try:
+            b = "hicstraw" if importlib.util.find_spec("hicstraw") is not None else "native"
+        except (ImportError, ValueError):
+            b = "native"
     return b
 
 

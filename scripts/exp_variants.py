@@ -35,7 +35,10 @@ def one(reps=5, blocks=12):
     CH, start, end = block_tiling(n, dpx)
     eng = pipe.engine
     out = {"lib": os.environ.get("MUSTACHE_HIP_LIB", "default"), "blocks": len(start)}
+    modes = os.environ.get("EXP_MODES", "dense,skip").split(",")
     for mode, skip in (("dense", False), ("skip", True)):
+        if mode not in modes:
+            continue
         ms = []
         for it in range(reps + 1):
             tm = []
@@ -79,6 +82,7 @@ def main():
         lines = [l for l in p.stdout.splitlines() if l.startswith("EXP ")]
         if lines:
             print(lines[-1] + "  # %s %.0f s" % (extra, time.time() - t0), flush=True)
+            continue
         else:
             print("EXP-FAIL %s rc=%d\n%s" % (spec, p.returncode, (p.stdout + p.stderr)[-1500:]), flush=True)
 

@@ -351,7 +351,73 @@ def make_diff(name="diff_320", n=320, dpx=80, start=640, res=50000, nloops=30, p
     print(name, [len(o) for o in out], {k: v.shape for k, v in locs.items()})
 
 
+def make_krnorm(ref):
+    """The one real data file the reference bundles, data/chr21_5kb.KRnorm (3 columns: chr21, position, KR bias of HMEC chr21
+    at 5 kb; 9630 rows), through the reference's read_bias (mustache.py:218-251, the 3-column branch with `is_chr` and
+    position // res).  Fixture = the file's numeric content (positions, values) + what read_bias returned for it."""
+    path = "/root/reference/data/chr21_5kb.KRnorm"
+    pos, val, names = [], [], set()
+    for line in open(path):
+        a, b, c = line.strip().split("\t")
+        names.add(a)
+        pos.append(int(b))
+        val.append(float(c))
+    d = ref.read_bias(path, "21", 5000)
+    keys = np.array(sorted(d), dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "krnorm_chr21_5kb.npz"), chrom=np.array(sorted(names)),
+                        pos=np.array(pos, dtype=np.int64), value=np.array(val), res=5000,
+                        bias_keys=keys, bias_values=np.array([d[k] for k in keys]),
+                        other_chrom_entries=len(ref.read_bias(path, "20", 5000)))
+    v = np.array(val)
+    print("krnorm rows", len(v), "finite", int(np.isfinite(v).sum()), "nan", int(np.isnan(v).sum()),
+          "finite<0.2", int((v[np.isfinite(v)] < 0.2).sum()), "dict", len(keys))
+
+
+def hic_header_case(path):
+    """The version-8 `.hic` file the header fixture is made from (tests/hic_writer.py, deterministic); shared with the test."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from hic_writer import write_hic
+    rng = np.random.default_rng(77)
+    chroms = [("All", 5000), ("chr1", 1234567), ("2", 987654), ("chrX", 150000), ("MT", 16571)]
+    mats = {}
+    for ci in (1, 2, 3):
+        per = {}
+        for res in (5000, 25000):
+            nb = chroms[ci][1] // res + 1
+            x = rng.integers(0, nb, 300)
+            y = np.minimum(nb - 1, x + rng.integers(0, 40, 300))
+            per[res] = (x, y, rng.integers(1, 50, 300).astype(float))
+        mats[ci] = per
+    norms = {("KR", ci, res): rng.uniform(0.5, 1.5, chroms[ci][1] // res + 1) for ci in (1, 2, 3) for res in (5000, 25000)}
+    write_hic(path, chroms, mats, norms=norms, version=8)
+
+
+def make_hic_header():
+    """Pin the native `.hic` reader's HEADER parse on code the reference itself holds: diff_mustache.py:182-249
+    (readcstr / read_header, carried over from hic2cool, never called by the reference's own main).  It is imported here
+    and run on a version-8 file written by tests/hic_writer.py; what it returns is the fixture."""
+    import hashlib
+    dref = load_reference("diff_mustache")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "hdr.hic")
+        hic_header_case(path)
+        blob = open(path, "rb").read()
+        with open(path, "rb") as fh:
+            chrs, resolutions, masterindex, genome, metadata = dref.read_header(fh)
+    idx = sorted(chrs)
+    np.savez_compressed(os.path.join(HERE, "hic_header_v8.npz"), sha256=hashlib.sha256(blob).hexdigest(),
+                        file_bytes=len(blob), version=int(dref.version), masterindex=int(masterindex), genome=genome,
+                        chr_index=np.array(idx), chr_name=np.array([chrs[i][1] for i in idx]),
+                        chr_length=np.array([int(chrs[i][2]) for i in idx], dtype=np.int64),
+                        resolutions=np.array(resolutions, dtype=np.int64),
+                        meta_keys=np.array(sorted(metadata)), meta_values=np.array([metadata[k] for k in sorted(metadata)]))
+    print("hic header", dref.version, masterindex, genome, chrs, resolutions, metadata)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["hic"]:
+        make_hic_header()
+        sys.exit(0)
     if sys.argv[1:] == ["diff"]:
         make_diff()
         sys.exit(0)
@@ -359,7 +425,7 @@ if __name__ == "__main__":
         make_diff("diff_2000", n=2000, dpx=400, start=3200, res=5000, nloops=None, pt=0.3, pt2=0.3, compact=True)
         sys.exit(0)
     ref = load_reference("mustache")
-    which = sys.argv[1:] or ["norm", "blocks", "big", "edges", "tiling", "regulator"]
+    which = sys.argv[1:] or ["norm", "blocks", "big", "edges", "tiling", "regulator", "krnorm"]
     if "norm" in which:
         make_normalize(ref)
     if "blocks" in which:
@@ -375,3 +441,5 @@ if __name__ == "__main__":
         make_tiling(ref)
     if "regulator" in which:
         make_regulator(ref)
+    if "krnorm" in which:
+        make_krnorm(ref)

@@ -35,7 +35,7 @@ def test_io_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(ROOT, "mustache_amd", "libmustache_io.so"))
     header = open(os.path.join(ROOT, "include", "mustache_io.h")).read()
     names = set(re.findall(r"\b(mst_(?:io|hic|text)_\w+)\s*\(", header))
-    assert len(names) == 12
+    assert len(names) == 14
     for n in names:
         assert hasattr(lib, n), n
     assert lib.mst_io_abi_version() == 1
@@ -194,3 +194,32 @@ def test_corrupted_files_never_crash(tmp_path):
         except HicError:
             outcomes["err"] += 1
     assert outcomes["ok"] + outcomes["err"] == 120 and outcomes["err"] > 20
+
+
+def test_header_parse_equals_reference_held_parser(tmp_path, golden_dir):
+    """tests/golden/hic_header_v8.npz is what the reference's own header parser (diff_mustache.py:182-249 read_header, imported
+    by make_golden.py) returns for the version-8 file that `hic_header_case` writes: version, master-index offset, genome id,
+    the chromosome table and the resolutions.  mst_hic_open must agree field for field.  (Block decoding has no such pin:
+    the reference reads blocks through hic-straw only, include/mustache_io.h.)"""
+    import hashlib
+    sys.path.insert(0, golden_dir)
+    try:
+        from make_golden import hic_header_case
+    finally:
+        sys.path.remove(golden_dir)
+    from mustache_amd.hicfile import HicFile
+    g = np.load(os.path.join(golden_dir, "hic_header_v8.npz"))
+    path = str(tmp_path / "hdr.hic")
+    hic_header_case(path)
+    blob = open(path, "rb").read()
+    assert len(blob) == int(g["file_bytes"]) and hashlib.sha256(blob).hexdigest() == str(g["sha256"]), "writer drifted"
+    with HicFile(path) as h:
+        assert h.version == int(g["version"]) == 8
+        assert h.master_offset == int(g["masterindex"])
+        assert h.genome == str(g["genome"])
+        chroms = h.chromosomes()
+        # read_header keeps only entries with a name and a non-zero length; every entry of this file has both
+        assert [c[0] for c in chroms] == [str(s) for s in g["chr_name"]]
+        assert [c[1] for c in chroms] == [int(v) for v in g["chr_length"]]
+        assert list(range(len(chroms))) == [int(i) for i in g["chr_index"]]
+        assert h.resolutions() == [int(r) for r in g["resolutions"]]

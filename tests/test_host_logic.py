@@ -138,3 +138,24 @@ def test_components_match_scipy_label():
         ref, nref = label(m, structure=np.ones((3, 3)))
         assert n == nref
         assert np.array_equal(ref[px[order], py[order]] - 1, labels)
+
+
+def test_read_bias_on_the_reference_bundled_krnorm(tmp_path, golden_dir):
+    """data/chr21_5kb.KRnorm, the one real data file the reference ships (3 columns `chr21 <tab> position <tab> KR bias`,
+    9630 rows: 6813 finite, 2817 NaN, 185 finite below 0.2), through read_bias's 3-column branch (mustache.py:229-238):
+    the fixture holds the file's numbers and the dictionary the REFERENCE's read_bias returned for it."""
+    from mustache_amd.mustache import read_bias
+    g = np.load(os.path.join(golden_dir, "krnorm_chr21_5kb.npz"))
+    path = tmp_path / "chr21_5kb.KRnorm"
+    with open(path, "w") as fh:
+        for p, v in zip(g["pos"], g["value"]):
+            fh.write("chr21\t%d\t%s\n" % (int(p), "NaN" if np.isnan(v) else repr(float(v))))
+    res = int(g["res"])
+    d = read_bias(str(path), "21", res)                       # "21" matches "chr21" (is_chr)
+    keys = np.array(sorted(d), dtype=np.float64)
+    assert np.array_equal(keys, g["bias_keys"])
+    got = np.array([d[k] for k in keys])
+    assert np.array_equal(got, g["bias_values"])              # inf where the factor is NaN or < 0.2, the factor otherwise
+    assert int(np.isinf(got).sum()) == 2817 + 185
+    assert d[1e9] == 1.0                                      # bins the file does not list default to 1
+    assert len(read_bias(str(path), "20", res)) == int(g["other_chrom_entries"]) == 0

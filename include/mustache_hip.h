@@ -126,6 +126,15 @@ uint64_t mst_bh_workspace_bytes(int32_t B, uint32_t cap);
 int mst_bh_fdr(const double *pval, const uint32_t *count, int32_t B, uint32_t cap, double *q, void *workspace,
                uint64_t workspace_bytes, void *stream);
 
+/* BH + selection in one call, restricted to the records that can be selected (what the per-chromosome pipeline uses):
+ * the records with q < threshold and their q-values, bit-identical to mst_bh_fdr + mst_select_below, but only the records
+ * with p < threshold are sorted (q >= p, so no other record can be selected, and the suffix minimum over the rest is
+ * >= threshold; the global test count m = found_count[b] enters every division).  Outputs as mst_select_below; workspace
+ * from mst_bh_workspace_bytes(B, found_cap).  (mustache.py:778-797) */
+int mst_bh_select(const mst_found *found, const double *pval, const uint32_t *found_count, int32_t B, uint32_t found_cap,
+                  double threshold, uint32_t out_cap, uint32_t *out_pixel, uint32_t *out_level, double *out_q,
+                  uint32_t *out_count, void *workspace, uint64_t workspace_bytes, void *stream);
+
 /* mustache.py:789-797 (selection of the pixels with o < pt) on the device: the found records of each block whose q-value
  * is below `threshold`, compacted into out_pixel / out_level / out_q [B][out_cap] (order within a block unspecified).
  * out_count: dev [B], overwritten; a count > out_cap means records were dropped -> re-run with a larger capacity.

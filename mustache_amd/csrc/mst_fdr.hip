@@ -103,7 +103,136 @@ select_below_kernel(const mst_found *__restrict__ found, const double *__restric
     }
 }
 
+// ---- BH restricted to the records that can be selected (mst_bh_select) ------------------------------------------------
+// q_(i) = min_{j >= i} p_(j) m / (j + 1) >= p_(i), so q < pt needs p < pt: only the k records with p < pt can be selected.
+// They are the k smallest, so their ranks in the full sort are their ranks among themselves; and the part of the suffix
+// minimum that comes from the other m - k records, T = min_{j >= k} p_(j) m / (j + 1), is >= pt (p_(j) >= pt, m/(j+1) >= 1).
+// Hence for a record of the subset:  q = min(A, T) with A = the suffix minimum over the subset alone;  A < pt  =>  q = A
+// exactly, and A >= pt  =>  q >= pt (not selected).  Sorting 1 % of the records instead of all of them gives the same
+// selected set with bit-identical q-values (the global m is used in every division).
+__global__ void __launch_bounds__(256)
+compact_below_kernel(const double *__restrict__ pval, const uint32_t *__restrict__ count, uint32_t cap, double threshold,
+                     double *__restrict__ keys, uint32_t *__restrict__ idx, uint32_t *__restrict__ k_out) {
+    const int b = blockIdx.y;
+    const uint32_t n = count[b] < cap ? count[b] : cap;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {      // whole waves stay together
+        const uint32_t i = i0 + threadIdx.x;
+        const double p = i < n ? pval[(size_t)b * cap + i] : 2.0;
+        const bool take = i < n && p < threshold;
+        const unsigned long long bal = __ballot(take);
+        if (!bal) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(k_out + b, (uint32_t)__popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (take) {
+            const uint32_t slot = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));   // < n <= cap: cannot overflow
+            keys[(size_t)b * cap + slot] = p;
+            idx[(size_t)b * cap + slot] = i;
+        }
+    }
+}
+
+__global__ void seg_bounds_kernel(const uint32_t *__restrict__ k, uint32_t cap, int B, int *__restrict__ seg_begin,
+                                  int *__restrict__ seg_end) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        seg_begin[b] = (int)((size_t)b * cap);
+        seg_end[b] = (int)((size_t)b * cap + k[b]);
+    }
+}
+
+__global__ void __launch_bounds__(kBH)
+bh_select_kernel(const double *__restrict__ ps, const uint32_t *__restrict__ idx_sorted, const uint32_t *__restrict__ k_sub,
+                 const uint32_t *__restrict__ count, uint32_t cap, const mst_found *__restrict__ found, double threshold,
+                 uint32_t out_cap, uint32_t *__restrict__ out_pixel, uint32_t *__restrict__ out_level,
+                 double *__restrict__ out_q, uint32_t *__restrict__ out_count) {
+    __shared__ double chunk_min[kBH];
+    __shared__ uint32_t n_out;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const uint32_t m = count[b] < cap ? count[b] : cap;        // the GLOBAL number of tests
+    const uint32_t k = k_sub[b];                               // records with p < threshold, sorted ascending
+    if (t == 0) n_out = 0;
+    __syncthreads();
+    if (k == 0) {
+        if (t == 0) out_count[b] = 0;
+        return;
+    }
+    const double *p = ps + (size_t)b * cap;
+    const uint32_t *id = idx_sorted + (size_t)b * cap;
+    const uint32_t L = (k + kBH - 1) / kBH;
+    const uint32_t lo = t * L < k ? t * L : k, hi = (t + 1) * L < k ? (t + 1) * L : k;
+    const double dm = (double)m;
+    double mn = INFINITY;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const double adj = p[i] / ((double)(i + 1) / dm);
+        mn = adj < mn ? adj : mn;
+    }
+    chunk_min[t] = mn;
+    __syncthreads();
+    for (int off = 1; off < kBH; off <<= 1) {
+        const double other = (t + off < kBH) ? chunk_min[t + off] : INFINITY;
+        __syncthreads();
+        if (other < chunk_min[t]) chunk_min[t] = other;
+        __syncthreads();
+    }
+    double run = (t + 1 < kBH) ? chunk_min[t + 1] : INFINITY;
+    for (uint32_t i = hi; i > lo; --i) {
+        const double adj = p[i - 1] / ((double)i / dm);
+        run = adj < run ? adj : run;
+        const double q = run > 1.0 ? 1.0 : run;
+        if (q < threshold) {
+            const uint32_t slot = atomicAdd(&n_out, 1u);       // LDS atomic; the caller orders the records by pixel anyway
+            if (slot < out_cap) {
+                const mst_found r = found[(size_t)b * cap + id[i - 1]];
+                out_pixel[(size_t)b * out_cap + slot] = r.pixel;
+                out_level[(size_t)b * out_cap + slot] = r.level;
+                out_q[(size_t)b * out_cap + slot] = q;
+            }
+        }
+    }
+    __syncthreads();
+    if (t == 0) out_count[b] = n_out;
+}
+
 }  // namespace
+
+extern "C" int mst_bh_select(const mst_found *found, const double *pval, const uint32_t *count, int32_t B, uint32_t cap,
+                             double threshold, uint32_t out_cap, uint32_t *out_pixel, uint32_t *out_level, double *out_q,
+                             uint32_t *out_count, void *workspace, uint64_t workspace_bytes, void *stream) {
+    if (!found || !pval || !count || !out_pixel || !out_level || !out_q || !out_count || !workspace || B <= 0 ||
+        B > 65535 || cap == 0 || out_cap == 0 || (size_t)B * cap > 0x7FFFFFFFull)
+        return mst::fail(MST_E_ARG, "mst_bh_select: bad argument (B * cap must fit in int32)");
+    if (workspace_bytes < mst_bh_workspace_bytes(B, cap))
+        return mst::fail(MST_E_ARG, "mst_bh_select: workspace too small (mst_bh_workspace_bytes)");
+    hipStream_t s = mst::as_stream(stream);
+    const size_t n = (size_t)B * cap;
+    char *w = reinterpret_cast<char *>(workspace);
+    int *seg_begin = reinterpret_cast<int *>(w);
+    int *seg_end = seg_begin + B;
+    w += align_up(sizeof(int) * 2 * B, 256);
+    uint32_t *idx_in = reinterpret_cast<uint32_t *>(w);
+    w += align_up(sizeof(uint32_t) * n, 256);
+    uint32_t *idx_out = reinterpret_cast<uint32_t *>(w);
+    w += align_up(sizeof(uint32_t) * n, 256);
+    double *keys_out = reinterpret_cast<double *>(w);
+    w += align_up(sizeof(double) * n, 256);
+    size_t temp = sort_temp_bytes(B, cap);
+    double *keys_in = reinterpret_cast<double *>(w + align_up(temp, 256));
+    uint32_t *k_sub = reinterpret_cast<uint32_t *>(w + align_up(temp, 256) + align_up(sizeof(double) * n, 256));
+    MST_HIP(hipMemsetAsync(k_sub, 0, sizeof(uint32_t) * (size_t)B, s));
+    const int gx = (int)((cap + 255) / 256 < 256 ? (cap + 255) / 256 : 256);
+    compact_below_kernel<<<dim3(gx, B), 256, 0, s>>>(pval, count, cap, threshold, keys_in, idx_in, k_sub);
+    MST_LAUNCH_CHECK();
+    seg_bounds_kernel<<<(B + 255) / 256, 256, 0, s>>>(k_sub, cap, B, seg_begin, seg_end);
+    MST_LAUNCH_CHECK();
+    MST_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(w, temp, keys_in, keys_out, idx_in, idx_out, (int)n, B, seg_begin,
+                                                        seg_end, 0, 64, s));
+    bh_select_kernel<<<B, kBH, 0, s>>>(keys_out, idx_out, k_sub, count, cap, found, threshold, out_cap, out_pixel,
+                                       out_level, out_q, out_count);
+    MST_LAUNCH_CHECK();
+    return MST_OK;
+}
 
 extern "C" int mst_select_below(const mst_found *found, const double *q, const uint32_t *found_count, int32_t B,
                                 uint32_t found_cap, double threshold, uint32_t out_cap, uint32_t *out_pixel,
@@ -123,8 +252,9 @@ extern "C" int mst_select_below(const mst_found *found, const double *q, const u
 extern "C" uint64_t mst_bh_workspace_bytes(int32_t B, uint32_t cap) {
     if (B <= 0 || cap == 0 || (size_t)B * cap > 0x7FFFFFFFull) return 0;
     const size_t n = (size_t)B * cap;
-    return align_up(sizeof(int) * 2 * B, 256) + align_up(sizeof(uint32_t) * n, 256) * 2 + align_up(sizeof(double) * n, 256) +
-           align_up(sort_temp_bytes(B, cap), 256);
+    // segment bounds, index in/out, sorted keys, the sort's temporary storage, and (mst_bh_select) compacted keys + subset sizes
+    return align_up(sizeof(int) * 2 * B, 256) + align_up(sizeof(uint32_t) * n, 256) * 2 + align_up(sizeof(double) * n, 256) * 2 +
+           align_up(sort_temp_bytes(B, cap), 256) + align_up(sizeof(uint32_t) * (size_t)B, 256);
 }
 
 extern "C" int mst_bh_fdr(const double *pval, const uint32_t *count, int32_t B, uint32_t cap, double *q, void *workspace,

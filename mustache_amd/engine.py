@@ -305,8 +305,7 @@ class ScaleSpaceEngine:
         if not download:
             return found, pval, count, fit, found_cap
         if select_below is not None:
-            return self._download_selected(found, self.fdr(pval, count, found_cap), count, fit, nt, found_cap,
-                                           float(select_below))
+            return self._download_selected(found, pval, count, fit, nt, found_cap, float(select_below))
         extra = {"q": self.fdr(pval, count, found_cap)} if with_q else None
         return self._download(found, pval, count, fit, nt, sort=sort, with_value=with_value, extra=extra)
 
@@ -358,17 +357,30 @@ class ScaleSpaceEngine:
             _lib.check(self.lib.mst_bh_fdr(_ptr(pval), _ptr(count), B, found_cap, _ptr(q), _ptr(ws), ws_bytes, _stream()))
         return q
 
-    def _download_selected(self, found, q, count, fit, nt, found_cap, pt):
+    def _download_selected(self, found, pval, count, fit, nt, found_cap, pt, full_sort=False):
+        """BH-FDR and the selection q < pt on the device; only the selected records come back.  Default: mst_bh_select
+        (sorts only the records with p < pt -- same selected set, bit-identical q); full_sort=True runs mst_bh_fdr over all
+        records and then mst_select_below (kept as the cross-check)."""
         B = count.shape[0]
         cap = self._select_cap
+        ws_bytes = int(self.lib.mst_bh_workspace_bytes(B, found_cap))
+        if ws_bytes == 0:
+            raise ValueError("too many found records for one BH launch (B * capacity must fit in int32)")
         with torch.cuda.device(self.device):
+            q = self.fdr(pval, count, found_cap) if full_sort else None
+            ws = None if full_sort else torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
             while True:
                 pix = torch.empty((B, cap), dtype=torch.int32, device=self.device)
                 lvl = torch.empty((B, cap), dtype=torch.int32, device=self.device)
                 qs = torch.empty((B, cap), dtype=torch.float64, device=self.device)
                 n_sel = torch.empty(B, dtype=torch.int32, device=self.device)
-                _lib.check(self.lib.mst_select_below(_ptr(found), _ptr(q), _ptr(count), B, found_cap, pt, cap, _ptr(pix),
-                                                     _ptr(lvl), _ptr(qs), _ptr(n_sel), _stream()))
+                if full_sort:
+                    _lib.check(self.lib.mst_select_below(_ptr(found), _ptr(q), _ptr(count), B, found_cap, pt, cap,
+                                                         _ptr(pix), _ptr(lvl), _ptr(qs), _ptr(n_sel), _stream()))
+                else:
+                    _lib.check(self.lib.mst_bh_select(_ptr(found), _ptr(pval), _ptr(count), B, found_cap, pt, cap,
+                                                      _ptr(pix), _ptr(lvl), _ptr(qs), _ptr(n_sel), _ptr(ws), ws_bytes,
+                                                      _stream()))
                 n_h = n_sel.cpu().numpy().view(np.uint32).astype(np.int64)
                 if n_h.max(initial=0) <= cap:
                     break

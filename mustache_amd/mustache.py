@@ -52,6 +52,8 @@ def mustache(c, chromosome, chromosome2, res, pval_weights, start, end, mask_siz
         raise ValueError("mustache(): c must be a square float64 array")
     dev = torch.from_numpy(np.ascontiguousarray(c)).to(eng.device).unsqueeze(0)
     batch = eng.run_blocks(dev, distance_in_px, intra=(chromosome == chromosome2))
+    if int(batch.nz_count[0]) < 50:
+        return []                            # mustache.py:701-702 returns before the fills of :703-706: `c` stays untouched
     c[...] = batch.c[0].cpu().numpy()
     return block_tail(batch, 0, start, pt, st, intra=(chromosome == chromosome2))
 

@@ -109,10 +109,13 @@ def test_edge_blocks(golden_dir):
     few = g["few"]
     c1 = np.zeros((n, n))
     c1[g["x"][few], g["y"][few]] = g["v"][few]
+    before = c1.copy()
     assert mustache(c1, "1", "1", 5000, [], 0, n, 0, dpx, OCT, 0.8, 0.1) == []
+    assert np.array_equal(c1, before)      # < 50 tested pixels: the reference returns before it fills c (mustache.py:701-703)
     c2 = np.zeros((n, n))
     c2[g["x"], g["y"]] = g["v"]
     assert mustache(c2, "1", "1", 5000, [], 0, n, 0, dpx, OCT, 0.8, 0.1) == []
+    assert c2[0, 0] == 2.0 and c2[0, n - 1] == 2.0     # >= 50 tested pixels: filled in place (:703-706) before the :775 exit
     c3 = np.zeros((n, n))          # empty block
     assert mustache(c3, "1", "1", 5000, [], 0, n, 0, dpx, OCT, 0.8, 0.1) == []
 

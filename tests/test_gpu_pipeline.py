@@ -284,8 +284,10 @@ def test_cli_from_hic_file_equals_cli_from_text(golden_dir, tmp_path, version):
 
 
 def test_device_selection_equals_host_selection():
-    """mst_select_below (q < pt on the device, only those records downloaded) == the same selection applied on the host
-    to the full found set: pixels, levels and q-values identical, sorted by pixel; capacity overflow re-runs."""
+    """mst_bh_select (BH over the records with p < pt only + the selection q < pt, on the device; only those records are
+    downloaded) == the same selection applied on the host to the full found set with the q-values of the FULL sort
+    (mst_bh_fdr): pixels, levels and q-values identical bit for bit, sorted by pixel; capacity overflow re-runs; pt = 1
+    keeps every record with q < 1 (the subset is then the whole found set)."""
     import torch
     from mustache_amd.normalize import band_from_coo, normalize_band
     from mustache_amd.pipeline import ChromosomePipeline, block_tiling
@@ -297,7 +299,7 @@ def test_device_selection_equals_host_selection():
     band, _, _ = normalize_band(band, n, dpx, res)
     CH, start, end = block_tiling(n, dpx)
     full, fits, _ = pipe.engine.sigma_loop_band(band, n, dpx, start, CH)
-    for pt, cap in ((0.1, 4096), (0.9, 64)):                    # the second capacity is far too small on purpose
+    for pt, cap in ((0.1, 4096), (0.9, 64), (1.0, 4096)):       # the second capacity is far too small on purpose
         pipe.engine._select_cap = cap
         sel, fits2, _ = pipe.engine.sigma_loop_band(band, n, dpx, start, CH, select_below=pt)
         total = 0

@@ -14,9 +14,11 @@ With N ranks the 124 blocks are dealt round-robin (strong scaling, no data-path 
 MAX over ranks between two barriers.  `value` = 1,984 Mpix / step time, whole job.
 
 Also reported on the same JSON line:
-  roofline      the fused kernel against the level-streaming HBM model of BASELINE.md (592 B per pixel), timed with
-                HIP events on the launch stream; plus the FP64-VALU view, because the fused kernel keeps all 24
-                levels on chip and is compute-bound
+  roofline      the fused kernel, timed with HIP events on the launch stream, against the roofline that binds it: the
+                FP64 vector pipe WITHOUT fused multiply-add (bit-exactness with SciPy forbids contraction): 1152
+                algorithmic flops per pixel over 39.3 TFLOP/s.  `hbm_model` keeps the
+                level-streaming traffic model of BASELINE.md (592 B per pixel) next to the HBM traffic the kernel
+                really causes (PMC), because the kernel holds all levels on chip and does not follow that model
   cpu_baseline  the CPU oracle (SciPy calls, the reference's own arithmetic) on ONE block of the same workload
   band_skip     the same step with empty tiles skipped (identical results; reported separately, not as `value`)
   chr21_5kb     the 5 kb shape (6 blocks of 2000 x 2000) for the second half of the metric's name
@@ -34,6 +36,20 @@ if ROOT not in sys.path:
 BYTES_PER_PIXEL = 592.0          # BASELINE.md section 3 / SURVEY.md 8d: level-streaming algorithmic traffic, fp64
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6          # FMA-counted vector FP64 peak (256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
+FLOPS_PER_PIXEL = 1152.0         # 24 blurs x 2 axes x (1 + 3 r) non-fusable flops, sum of r = 184
+
+
+def executed_flops_per_pixel():
+    """FP64 blur operations the kernel really issues per block pixel: 22 distinct blurs (the two levels that repeat between
+    the octaves are computed once), the V pass over the 2r halo columns of its 64-column region, and the 1-pixel ring of
+    the 32 x 64 region around the 30 x 62 pixels a workgroup owns (mst_scale_space.hip, Tile<32, 64, 14>)."""
+    from mustache_amd.levels import LevelTable
+    lt = LevelTable((1.6, 3.2), 10)
+    radii = [int(r) for r in lt.radius]
+    lpo = lt.levels_per_octave
+    distinct = radii[:lpo] + radii[lpo + 2:]                       # octave 2 starts from the state octave 1 left behind
+    per_region_px = sum((1 + 3 * r) * ((64 + 2 * r) / 64.0 + 1.0) for r in distinct)      # V pass + H pass
+    return per_region_px * (32 * 64) / (30.0 * 62.0)
 
 
 def parse():
@@ -193,50 +209,71 @@ def main():
         t0 = time.time()
         for _ in range(steps):
             last = w.step(skip_empty, fma=fma)
+        torch.cuda.synchronize()
+        own = [time.time() - t0]
         barrier()
         dt = time.time() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        # per-rank view next to the job time: each rank's own work time (stream-synchronised end of its last step, before
+        # the closing barrier) -- max/min over ranks shows the imbalance of the block split
+        torch.cuda.synchronize()
+        t = torch.tensor([dt, own[0]], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            dt = max(float(a[0]) for a in allt)
+            owns = [float(a[1]) for a in allt]
+        else:
+            owns = [own[0]]
         kms = [a.elapsed_time(b) for a, b in w.kernel_ms]
-        return float(t.item()), kms, last
+        return dt, kms, last, owns
 
-    dt, kms, last = timed(False, args.steps, args.warmup)
+    dt, kms, last, owns = timed(False, args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
     value = w.total_mpix / (dt / args.steps)
 
-    # roofline of the dominant kernel (rank 0's launches): algorithmic bytes per launch / event-timed duration
+    # roofline of the dominant kernel (rank 0's launches): algorithmic flops per launch / event-timed duration
     launches_per_step = max(1, len(kms) // args.steps)
     k_ms = sum(kms) / len(kms)
     px_per_launch = len(w.mine) * w.CH * w.CH / launches_per_step
+    achieved_tf = px_per_launch * FLOPS_PER_PIXEL / (k_ms * 1e-3) / 1e12
     achieved_gbs = px_per_launch * BYTES_PER_PIXEL / (k_ms * 1e-3) / 1e9
-    flops_px = 1152.0                       # non-fusable fp64 flops per pixel of the 24 blurs
-    roof = {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "scale_space_kernel<Tile<32,64,14>>", "kernel_ms": round(k_ms, 3),
+    peak_tf = FP64_PEAK_TFLOPS / 2
+    exec_fpp = executed_flops_per_pixel()
+    roof = {"bound": "fp64_valu", "achieved": round(achieved_tf, 3), "peak": peak_tf, "unit": "TFLOP/s",
+            "frac": round(achieved_tf / peak_tf, 4), "traffic": None,
+            "kernel": "scale_space_kernel<Tile<32,64,14>, band>", "kernel_ms": round(k_ms, 3),
             "launches_per_step": launches_per_step, "kernel_ms_per_step": round(k_ms * launches_per_step, 3),
-            "pixels_per_launch": int(px_per_launch), "bytes_per_pixel_model": BYTES_PER_PIXEL,
-            "fp64_view": {"blur_flops_per_pixel": flops_px,
-                          "achieved_tflops": round(px_per_launch * flops_px / (k_ms * 1e-3) / 1e12, 2),
-                          "peak_tflops_no_fma": FP64_PEAK_TFLOPS / 2,
-                          "note": "taps cannot be fused into FMAs (bit-exactness with SciPy), so the usable peak is "
-                                  "half the FMA-counted 78.6 TFLOP/s; halo/redundant work is not counted"}}
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            "pixels_per_launch": int(px_per_launch), "flops_per_pixel": FLOPS_PER_PIXEL,
+            "executed_flops_per_pixel": round(exec_fpp, 1),
+            "executed_frac": round(px_per_launch * exec_fpp / (k_ms * 1e-3) / 1e12 / peak_tf, 4),
+            "note": "peak = FP64 vector add/mul rate without FMA (78.6 TFLOP/s FMA-counted / 2 at the 2.4 GHz spec clock): "
+                    "the taps cannot be contracted into FMAs if the DoG values are to stay bit-identical to SciPy's; "
+                    "`achieved` counts the 1152 algorithmic blur flops per pixel, `executed_*` adds the halo columns, "
+                    "the ring and subtracts the two repeated levels; max / sieve / statistics instructions are not counted",
+            "hbm_model": {"bound": "hbm", "bytes_per_pixel_model": BYTES_PER_PIXEL, "achieved_equivalent": round(achieved_gbs, 1),
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac_of_model_roofline": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                          "note": "level-streaming model of BASELINE.md (every level written and re-read): the rate the "
+                                  "kernel WOULD need if it followed that model -- it does not, see traffic"}}
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            roof["traffic"] = round(json.load(open(pmc))["bytes_per_pixel"] * px_per_launch)   # PMC bytes/pixel x pixels/launch
+            pj = json.load(open(pmc))
+            roof["traffic"] = round(pj["bytes_per_pixel"] * px_per_launch)        # PMC bytes/pixel x pixels/launch
+            roof["traffic_source"] = "profiles/r02_pmc_traffic.json: FETCH_SIZE (x2, gfx950) + WRITE_SIZE of the fused kernel " \
+                                     "in this round's rocprofv3 --pmc pass (%s), %.2f B/pixel" % (pj.get("command", "?"),
+                                                                                                pj["bytes_per_pixel"])
         except Exception:
             pass
 
     # the same step with empty tiles skipped (separate speed-up, never folded into `value`)
-    dt_s, kms_s, _ = timed(True, max(1, args.steps // 2), 1)
+    dt_s, kms_s, _, _ = timed(True, max(1, args.steps // 2), 1)
     band_skip = {"value": round(w.total_mpix / (dt_s / max(1, args.steps // 2)), 1), "unit": "Mpix/s",
                  "speedup": round((dt / args.steps) / (dt_s / max(1, args.steps // 2)), 3),
                  "kernel_ms_per_step": round(sum(kms_s) / max(1, args.steps // 2), 3)}
 
     # opt-in relaxed arithmetic (fused multiply-add per tap pair): DoG no longer bit-identical (~1e-16 relative, north_star
     # allows 1e-5), found set unchanged on every case tested.  Reported separately; `value` is always the exact mode.
-    dt_f, kms_f, _ = timed(False, max(1, args.steps // 2), 1, fma=True)
+    dt_f, kms_f, _, _ = timed(False, max(1, args.steps // 2), 1, fma=True)
     fma_mode = {"value": round(w.total_mpix / (dt_f / max(1, args.steps // 2)), 1), "unit": "Mpix/s",
                 "kernel_ms_per_step": round(sum(kms_f) / max(1, args.steps // 2), 3),
                 "note": "MST_FLAG_FMA, dense; not bit-exact DoG, therefore never the headline value"}
@@ -249,6 +286,12 @@ def main():
                       "timed_region": "normalised band in HBM -> fused kernel (blocks cut, filled and masked in-kernel; "
                                       "sigma loop, sieve, level statistics) -> p-values -> found records on host; "
                                       "%d launches per step, the download of one under the kernel of the next" % OVERLAP},
+           "ranks": {"ms_per_step_max": round(max(owns) / args.steps * 1e3, 3),
+                     "ms_per_step_min": round(min(owns) / args.steps * 1e3, 3),
+                     "blocks_per_rank_max": -(-len(w.start) // world), "blocks_per_rank_min": len(w.start) // world,
+                     "imbalance_bound": round(-(-len(w.start) // world) * world / len(w.start), 4),
+                     "note": "round-robin split of the blocks: the slowest rank carries ceil(blocks / ranks) blocks, so "
+                             "the strong-scaling efficiency cannot exceed blocks / (ranks * ceil(blocks / ranks))"},
            "roofline": roof, "band_skip": band_skip, "fma_mode": fma_mode,
            "normalize_ms_untimed": round(w.normalize_s * 1e3, 1),
            # row 1 of SURVEY 8a next to it: 16 B per band sample (8 read + 8 written) over the wall time of mst_normalize_band

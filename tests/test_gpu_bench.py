@@ -1,0 +1,58 @@
+"""bench.py's contract on the GPU box: the JSON line of a 1-rank run and of a 2-rank run launched exactly as the driver
+launches it (torch.distributed.run, one process per rank; both ranks share this box's one GPU and talk over gloo -- the
+test hooks MST_BENCH_BACKEND / MST_BENCH_ONE_DEVICE -- so the N > 1 control flow is exercised before an 8-GPU node is)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(out):
+    lines = [l for l in out.strip().split("\n") if l.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def _check_line(j, n_gpus, steps, warmup):
+    assert j["metric"].startswith("scale-space Mpix/s") and j["unit"] == "Mpix/s" and j["higher_is_better"] is True
+    assert j["n_gpus"] == n_gpus and j["steps"] == steps and j["warmup"] == warmup
+    assert j["dtype"] == "f64" and j["data"] == "synthetic" and j["scaling"] == "strong" and j["vs_baseline"] is None
+    assert abs(j["value"] - j["config"]["megapixels_per_step"] / (j["ms_per_step"] * 1e-3)) < 1e-3 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] == "fp64_valu" and r["unit"] == "TFLOP/s" and r["peak"] == 39.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["pixels_per_launch"] * r["flops_per_pixel"] / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-2
+    assert r["executed_flops_per_pixel"] > r["flops_per_pixel"] * 0.9
+    assert r["hbm_model"]["bytes_per_pixel_model"] == 592.0
+    assert r["kernel_ms_per_step"] <= j["ms_per_step"] * 1.02          # the kernel fits inside the step it dominates
+    rk = j["ranks"]
+    assert rk["ms_per_step_max"] <= j["ms_per_step"] * 1.001 and rk["ms_per_step_min"] <= rk["ms_per_step_max"]
+    assert rk["blocks_per_rank_max"] >= rk["blocks_per_rank_min"] and rk["imbalance_bound"] >= 1.0
+
+
+def test_bench_one_rank_small():
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--small", "--no-cpu"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    _check_line(j, 1, 2, 1)
+    assert j["band_skip"]["value"] > j["value"] and j["chr21_5kb"]["value"] > 0 and j["end_to_end"]["loops"] > 0
+
+
+def test_bench_two_ranks_gloo_one_device():
+    env = dict(os.environ, MST_BENCH_BACKEND="gloo", MST_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--small",
+           "--no-cpu"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    _check_line(j, 2, 2, 1)
+    assert j["ranks"]["blocks_per_rank_max"] == 6 and "2 rank" in j["config"]["sharding"]
+    assert "cpu_baseline" not in j and "chr21_5kb" not in j        # rank-0-at-N=1-only legs stay out of the N > 1 line

@@ -397,3 +397,63 @@ def test_two_rank_cli_equals_one_process(golden_dir, tmp_path):
         assert sorted(a[1:]) == sorted(b[1:])
         if tag == "genome":
             assert [l.split("\t")[0] for l in a[1:]] == [l.split("\t")[0] for l in b[1:]], "chromosomes in file order"
+
+
+def test_whole_genome_cool_path_two_ranks_equals_oracle(tmp_path):
+    """BASELINE config 3's code path on the GPU: `mustache -f <.cool> -r 5kb` with NO -ch -- chromosomes enumerated from the
+    file (> 1 Mb only, mustache.py:1027-1029), each read through read_cooler's overlapping windows (balanced matrix, upper
+    triangle, NaN -> 0, distance and > 0 filters, :399-493) -- over three chromosomes at 5 kb, single process and as a
+    2-rank torchrun job sharded by chromosome.  `cooler` itself (HDF5) is absent offline: tests/standins/cooler.py provides
+    the calls the reference makes on a file-backed container.  Loops are compared per chromosome with the oracle's
+    regulator restatement on the same records."""
+    import subprocess
+    import sys
+    import oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    standins = os.path.join(root, "tests", "standins")
+    sys.path.insert(0, standins)
+    try:
+        import cooler
+        from mustache_amd.mustache import main
+        from mustache_amd.synth import synth_coo
+        res, dpx = 5000, 400
+        chroms, truth = [], {}
+        for name, n, seed in (("chr1", 5200, 61), ("chr2", 4300, 62), ("chrX", 2900, 63)):
+            x, y, v = synth_coo(n, dpx, depth=150.0, seed=seed)
+            v = v.copy()
+            v[::53] = np.nan                                   # unbalanceable bins: NaN -> 0 -> dropped (mustache.py:463, :487)
+            chroms.append((name, n * res, x, y, v))
+            ok = ~np.isnan(v) & ((y - x) <= dpx) & (v > 0)
+            truth[name] = (x[ok], y[ok], v[ok])
+        chroms.append(("chrM", 16571, np.array([0, 1]), np.array([1, 2]), np.array([3.0, 4.0])))   # < 1 Mb: not enumerated
+        cool = str(tmp_path / "g.cool")
+        cooler.write_cool(cool, res, chroms)
+        common = ["-f", cool, "-r", "5kb", "-pt", "0.1", "-st", "0.8"]
+        single, multi = str(tmp_path / "one.tsv"), str(tmp_path / "two.tsv")
+        main(common + ["-o", single])
+        env = dict(os.environ, MUSTACHE_DIST_BACKEND="gloo", MUSTACHE_ONE_DEVICE="1",
+                   PYTHONPATH=os.pathsep.join([root, standins]))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", "29541", "-m", "mustache_amd"] + common + ["-o", multi]
+        r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+    finally:
+        sys.path.remove(standins)
+        sys.modules.pop("cooler", None)
+    a, b = open(single).read().strip().split("\n"), open(multi).read().strip().split("\n")
+    assert a[0] == b[0] and sorted(a[1:]) == sorted(b[1:])
+    assert [l.split("\t")[0] for l in a[1:]] == [l.split("\t")[0] for l in b[1:]], "chromosomes in file order"
+    got = {}
+    for line in a[1:]:
+        f = line.split("\t")
+        got.setdefault(f[0], []).append((int(f[1]) // res, int(f[4]) // res, float(f[6]), float(f[7])))
+    assert set(got) == {"chr1", "chr2", "chrX"}
+    total = 0
+    for name, (x, y, v) in truth.items():
+        exp = oracle.regulator_coo(x.copy(), y.copy(), v.copy(), res, dpx, OCT, 0.8, 0.1)
+        g = sorted(got[name])
+        assert [(int(p), int(q)) for p, q, _, _ in exp] == [(p, q) for p, q, _, _ in g], name
+        assert [s for _, _, _, s in exp] == [s for _, _, _, s in g]
+        np.testing.assert_allclose([q for _, _, q, _ in g], [q for _, _, q, _ in exp], rtol=1e-9)
+        total += len(exp)
+    assert total > 30

@@ -178,9 +178,10 @@ int mst_band_to_coo(const double *band, const int64_t *x, const int64_t *y, int6
 
 /* normalize_sparse (mustache.py:622-686) on the band, out of place (band_in != band_out).
  *   local != 0 : branch A (:628-669), taken by the caller when (n - dpx) * res > 2e6; `window` = int(2e6 / res).
- *                (local == 1: the library picks the kernel -- prefix sums per 1024-sample segment for windows up to
- *                ~3000, blocked sums above; local == 2: the blocked-sum kernel whatever the window, a second
- *                implementation of the same sums kept selectable so the two can be cross-checked.)
+ *                (local == 1: the library picks the kernel -- the walking kernel (blocks of `window` samples along each
+ *                diagonal, one scan per sample) for windows up to 4096, blocked sums above; local == 2: the blocked-sum
+ *                kernel whatever the window; local == 3: the segment kernel with prefix arrays in LDS (windows up to
+ *                ~3000, blocked sums above).  Three formulations of the same sums, selectable so they can be cross-checked.)
  *                Per diagonal d <= dpx+1: vals = v + 0.001; counts / sum / sum of squares over the zero-padded
  *                window [i - window/2, i - window/2 + window - 1] (np.convolve 'same'); local variance and mean
  *                with the global fallback below 30 samples or when non-finite; z = (vals - mean)/sqrt(var),
@@ -240,6 +241,23 @@ int mst_masked_normfit(const double *a, const double *b, const uint8_t *mask, co
 int mst_pair_pvalues(const mst_found *found, uint32_t found_cap, const uint32_t *found_count, const double *g2,
                      const double *g3, const double *fit, int32_t B, int32_t CH, int32_t n_octaves,
                      int32_t tested_per_octave, int32_t sample_offset, double *ppair, void *stream);
+
+/* ---- two-sample path, band-direct (what the per-chromosome driver uses; diff_mustache.py:262-276, :315-336, :371) -----------
+ * For B block pairs cut out of the two samples' normalised bands (same n, dpx, starts): the difference image
+ *     cd = filled_1 - filled_2 where both samples test the pixel (raw != 0, col - row >= 4), else 0
+ * is formed tile by tile in LDS, blurred at sigma_2 and sigma_3 of every octave with the fused kernel's own separable passes
+ * (SciPy tap order, no FMA) and only  dog[oct][b] = G_2 - G_3  (dev [n_octaves][B][CH][CH]) is written, together with
+ * fit[oct][b] = {loc, scale} of norm.fit over the doubly tested pixels (dev [n_octaves][B][2]; scale from one pass,
+ * sqrt(mean(x^2) - loc^2)) and mask_count[b] = their number.  No dense block, difference image or blurred level reaches HBM.
+ * lv: the SAME level table as the sigma loop (levels 2 and 3 of each octave are used).  starts: host [B]. */
+uint64_t mst_diff_dog_workspace_bytes(int32_t B, int32_t CH, const mst_levels *lv);
+int mst_diff_dog_band(const double *band1, const double *band2, int64_t n, int32_t dpx, const int64_t *starts, int32_t B,
+                      int32_t CH, const mst_levels *lv, double *dog, double *fit, uint32_t *mask_count, void *workspace,
+                      uint64_t workspace_bytes, void *stream);
+/* mst_pair_pvalues with x read from dog[octave][b][pixel] (the output of mst_diff_dog_band). */
+int mst_pair_pvalues_dog(const mst_found *found, uint32_t found_cap, const uint32_t *found_count, const double *dog,
+                         const double *fit, int32_t B, int32_t CH, int32_t n_octaves, int32_t tested_per_octave,
+                         int32_t sample_offset, double *ppair, void *stream);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,10 @@ _SIGNATURES = {
     "mst_diag_means_band_multi": (ctypes.c_int, [_p, _i64, _i32, _p, _i32, _p, _i32, _p, _p]),
     "mst_diff_image": (ctypes.c_int, [_p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p]),
     "mst_masked_normfit": (ctypes.c_int, [_p, _p, _p, _p, _i32, _i64, _p, _p, _u64, _p]),
+    "mst_diff_dog_workspace_bytes": (_u64, [_i32, _i32, ctypes.POINTER(MstLevels)]),
+    "mst_diff_dog_band": (ctypes.c_int, [_p, _p, _i64, _i32, ctypes.POINTER(_i64), _i32, _i32, ctypes.POINTER(MstLevels),
+                                         _p, _p, _p, _p, _u64, _p]),
+    "mst_pair_pvalues_dog": (ctypes.c_int, [_p, _u32, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     "mst_pair_pvalues": (ctypes.c_int, [_p, _u32, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
 }
 

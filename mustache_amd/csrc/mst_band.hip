@@ -66,32 +66,43 @@ __device__ __forceinline__ void block_reduce2(double &a, double &b, double *sa, 
 // One workgroup per diagonal: count, mean and population std of the raw entries (np.mean / np.std at
 // mustache.py:638-643, :677-682; NaN -> mean 0, std 1), and the weight 1 + log30(1 + mean) (:667).
 // diag_stats[d] = {mean, std, weight, count}
+// The row is read ONCE: np.std's two passes (mean, then squared deviations) become shifted sums around a pivot K taken
+// from the row's head (the mean of the non-zero entries among its first 256 samples):
+//     mean = K + sum(v - K) / n,      var = (sum((v - K)^2) - sum(v - K)^2 / n) / n.
+// With K within a few standard deviations of the mean the cancellation in `var` costs a few ulp (relative error
+// ~ eps * (1 + (mean - K)^2 / var)); the band is 4 GB for chr1 at 1 kb, so the second pass was as expensive as the first.
 __global__ void __launch_bounds__(kThreads)
 diag_stats_kernel(const double *__restrict__ band, int64_t n, double *__restrict__ diag_stats) {
     __shared__ double sa[kThreads], sb[kThreads];
     const int d = blockIdx.x;
     const int64_t L = n - d;
     const double *row = band + (int64_t)d * n;
-    double cnt = 0.0, sum = 0.0;
+    double hc = 0.0, hs = 0.0;
+    if ((int64_t)threadIdx.x < L) {
+        const double v = row[threadIdx.x];
+        if (v != 0.0 && isfinite(v)) {
+            hc = 1.0;
+            hs = v;
+        }
+    }
+    block_reduce2(hc, hs, sa, sb);
+    const double K = hc > 0.0 ? hs / hc : 0.0;
+    double cnt = 0.0, s1 = 0.0, s2 = 0.0, dummy = 0.0;
     for (int64_t i = threadIdx.x; i < L; i += kThreads) {
         const double v = row[i];
         if (v != 0.0) {
+            const double t = v - K;
             cnt = cnt + 1.0;
-            sum = sum + v;
+            s1 = s1 + t;
+            s2 = s2 + t * t;
         }
     }
-    block_reduce2(cnt, sum, sa, sb);
-    double mean = sum / cnt;            // 0/0 -> NaN like np.mean of an empty selection
-    double ssq = 0.0, dummy = 0.0;
-    for (int64_t i = threadIdx.x; i < L; i += kThreads) {
-        const double v = row[i];
-        if (v != 0.0) {
-            const double t = v - mean;
-            ssq = ssq + t * t;
-        }
-    }
-    block_reduce2(ssq, dummy, sa, sb);
-    double sd = sqrt(ssq / cnt);
+    block_reduce2(cnt, s1, sa, sb);
+    block_reduce2(s2, dummy, sa, sb);
+    double mean = K + s1 / cnt;         // 0/0 -> NaN like np.mean of an empty selection
+    double var = (s2 - s1 * s1 / cnt) / cnt;
+    if (var < 0.0) var = 0.0;           // rounding of an (almost) constant diagonal; NaN (empty diagonal) passes through
+    double sd = sqrt(var);
     if (mean != mean) mean = 0.0;       // math.isnan(mean) -> 0   (:640-641)
     if (sd != sd) sd = 1.0;             // math.isnan(std)  -> 1   (:642-643)
     if (threadIdx.x == 0) {
@@ -415,6 +426,188 @@ normalize_prefix_kernel(const double *__restrict__ band_in, double *__restrict__
     }
 }
 
+// ---- Branch A, walking form (the default) ------------------------------------------------------------------------------
+// A workgroup walks along ONE diagonal in blocks of W samples, W = the window length.  With sample blocks
+//     B_m = [m W - left, (m + 1) W - left),   left = W / 2   (np.convolve(..., 'same'): window of output i = [i - left, i - left + W)),
+// the window of output i = m W + k is the tail of B_m from offset k plus the head of B_{m+1} up to offset k, so
+//     window sum(i) = (T_m - P_m[k]) + P_{m+1}[k]          P = exclusive prefix inside a block, T = block total,
+// and the thread that holds offset k of the scans needs nothing from any other thread: ONE 3-quantity scan (count, sum, sum of
+// squares) per sample, no prefix arrays in LDS, no re-scan of the W - 1 samples neighbouring segments share (the segment
+// form above scans every sample ~3 times at W = 2000 and parks 20 B per sample in LDS).  A thread owns C consecutive
+// offsets: it loads them straight from the band (the C loads of a wave cover the same cache lines), scans serially, and
+// joins the other threads through one DPP wave scan + one LDS exchange of the wave totals -- ONE barrier per block.  The
+// centre sample x_i of an output sits W / 2 further along, in another thread's chunk: it is simply read again (cache hit).
+// Numerics: every window sum is the sum of two partial sums of at most W terms each, accumulated in a fixed order
+// (deterministic; relative error of a few 1e-16 on the sums, measured against extended-precision windows by
+// scripts/norm_accuracy.py).  Counts are exact integers.
+template <int NT>
+__device__ __forceinline__ void block_totals3(double &s1, double &s2, int &sc, double *w1, double *w2, int *wc,
+                                               double &o1, double &o2, int &oc, double &t1, double &t2, int &tc) {
+    // in: this thread's chunk totals.  out: (s*) inclusive scan across the wave, (o*) sum over the waves before this one,
+    // (t*) block totals.  Fixed order: DPP scan inside the wave, waves added in index order.
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    wave_scan3(s1, s2, sc);
+    if (lane == 63) {
+        w1[wave] = s1;
+        w2[wave] = s2;
+        wc[wave] = sc;
+    }
+    __syncthreads();
+    o1 = o2 = t1 = t2 = 0.0;
+    oc = tc = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const double a = w1[w], b = w2[w];
+        const int c = wc[w];
+        if (w < wave) {
+            o1 = o1 + a;
+            o2 = o2 + b;
+            oc += c;
+        }
+        t1 = t1 + a;
+        t2 = t2 + b;
+        tc += c;
+    }
+}
+
+template <int NT, int C>
+#ifndef MST_WALK_MINW
+#define MST_WALK_MINW 4
+#endif
+__global__ void __launch_bounds__(NT, (C <= 4 ? MST_WALK_MINW : 2))
+normalize_walk_kernel(const double *__restrict__ band_in, double *__restrict__ band_out, int64_t n, int W,
+                      const double *__restrict__ diag_stats, int nb, int run, int runs_per_diag) {
+    constexpr int NW = NT / 64;
+    __shared__ double w1[2][NW], w2[2][NW];            // wave totals of the block being scanned, double-buffered: ONE barrier per block
+    __shared__ int wc[2][NW];
+    const int tid = threadIdx.x;
+    const int d = blockIdx.x / runs_per_diag;
+    const int m_lo = (blockIdx.x - d * runs_per_diag) * run;
+    const int m_hi = m_lo + run < nb ? m_lo + run : nb;
+    const int64_t L = n - d;
+    const int left = W / 2;
+    const double *row = band_in + (int64_t)d * n;
+    double *orow = band_out + (int64_t)d * n;
+    const double mean = diag_stats[4 * d + 0], sd = diag_stats[4 * d + 1], wgt = diag_stats[4 * d + 2];
+    const double std2 = sd * sd;
+    const int k0 = tid * C;                             // this thread's offsets inside a block: k0 .. k0 + C - 1
+
+    // shifted samples (vals[x] = v + 0.001, :635) of this thread's offsets in sample block m; 0 outside the diagonal.  Each
+    // lane reads C consecutive doubles (the scan is serial inside a thread); the C loads of a wave cover the same cache lines.
+    auto fetch = [&](int m, double (&r)[C]) {
+        const int64_t base = (int64_t)m * W - left + k0;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const int64_t q = base + j;
+            const double v = (k0 + j < W && q >= 0 && q < L) ? row[q] : 0.0;
+            r[j] = v != 0.0 ? v + 0.001 : 0.0;
+        }
+    };
+    // the outputs' own samples: output i = m W + k is sample offset k + left of block m -- another thread's chunk, so it is
+    // re-read from memory (the same workgroup loaded it one or two blocks ago: cache hits)
+    auto fetch_x = [&](int m, double (&x)[C]) {
+        const int64_t base = (int64_t)m * W + k0;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const int64_t q = base + j;
+            const double v = (k0 + j < W && q < L) ? row[q] : 0.0;
+            x[j] = v != 0.0 ? v + 0.001 : 0.0;
+        }
+    };
+    // exclusive prefix of this thread's first offset (p*) and the block totals (t*) from the chunk totals (a*)
+    auto scan = [&](int buf, double a1, double a2, int ac, double &p1, double &p2, int &pc, double &t1, double &t2, int &tc) {
+        double s1 = a1, s2 = a2, o1, o2;
+        int sc = ac, oc;
+        block_totals3<NT>(s1, s2, sc, w1[buf], w2[buf], wc[buf], o1, o2, oc, t1, t2, tc);
+        p1 = o1 + lane_before(s1);
+        p2 = o2 + lane_before(s2);
+        pc = oc + lane_before_i(sc);
+    };
+
+    double vv[C], nx[C], xv[C];
+    double S1[C], S2[C];                                // tail sums of the previous block from each of my offsets: T - P[k]
+    int Sc[C];
+    // prime: sample block m_lo -> its tail sums
+    fetch(m_lo, vv);
+    fetch(m_lo + 1, nx);                                // in flight while block m_lo is scanned
+    fetch_x(m_lo, xv);
+    {
+        double a1 = 0.0, a2 = 0.0, p1, p2, t1, t2;
+        int ac = 0, pc, tc;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            ac += (vv[j] != 0.0) ? 1 : 0;
+            a1 = a1 + vv[j];
+            a2 = a2 + vv[j] * vv[j];                    // vals ** 2  (:649)
+        }
+        scan(0, a1, a2, ac, p1, p2, pc, t1, t2, tc);
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            S1[j] = t1 - p1;
+            S2[j] = t2 - p2;
+            Sc[j] = tc - pc;
+            pc += (vv[j] != 0.0) ? 1 : 0;
+            p1 = p1 + vv[j];
+            p2 = p2 + vv[j] * vv[j];
+        }
+    }
+    int buf = 1;
+    for (int m = m_lo; m < m_hi; ++m, buf ^= 1) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) vv[j] = nx[j];      // sample block m + 1
+        double x[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) x[j] = xv[j];
+        if (m + 1 < m_hi) {                             // next block's loads hide under this block's arithmetic
+            fetch(m + 2, nx);
+            fetch_x(m + 1, xv);
+        }
+        double a1 = 0.0, a2 = 0.0, p1, p2, t1, t2;
+        int ac = 0, pc, tc;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            ac += (vv[j] != 0.0) ? 1 : 0;
+            a1 = a1 + vv[j];
+            a2 = a2 + vv[j] * vv[j];
+        }
+        scan(buf, a1, a2, ac, p1, p2, pc, t1, t2, tc);
+        const int64_t i0 = (int64_t)m * W + k0;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const int c = Sc[j] + pc;
+            const double s1w = S1[j] + p1, s2w = S2[j] + p2;
+            double zz = 0.0;
+            if (x[j] != 0.0) {
+                // 1/cnt and 1/(cnt-1) from ONE division; a window with c < 30 -- including c = 1, where the product form
+                // gives NaN -- takes the fallback below
+                const double cnt = (double)c;
+                const double rcc = 1.0 / (cnt * (cnt - 1.0));
+                const double inv_c = rcc * (cnt - 1.0), inv_cm1 = rcc * cnt;
+                double var = (s2w - s1w * s1w * inv_c) * inv_cm1;        // (:650)
+                if (!isfinite(var)) var = std2;                          // (:653-654)
+                double mu = s1w * inv_c;                                 // (:656)
+                if (c < 30) {                                            // (:657-658)
+                    mu = mean;
+                    var = std2;
+                }
+                if (!isfinite(mu)) mu = mean;                            // (:660-661)
+                zz = (x[j] - mu) * rsqrt(var);                           // (:663-665)  (rsqrt: same accuracy as / sqrt, measured)
+                if (!isfinite(zz)) zz = 0.0;                             // (:666)
+                zz = zz * wgt;                                           // (:667)
+            }
+            if (k0 + j < W && i0 + j < n) orow[i0 + j] = zz;             // positions past the diagonal's end receive 0
+            // this block's tail sums for the next output block
+            S1[j] = t1 - p1;
+            S2[j] = t2 - p2;
+            Sc[j] = tc - pc;
+            pc += (vv[j] != 0.0) ? 1 : 0;
+            p1 = p1 + vv[j];
+            p2 = p2 + vv[j] * vv[j];
+        }
+    }
+}
+
 // Branch B (mustache.py:671-685): plain per-diagonal z-score for d < min(dpx, n); other diagonals pass through
 // (after the nan_to_num at :673).
 __global__ void __launch_bounds__(kThreads)
@@ -547,12 +740,33 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
     const int nd = dpx + 2;
     diag_stats_kernel<<<nd, kThreads, 0, s>>>(band_in, n, diag_stats);
     MST_LAUNCH_CHECK();
+    if (local == 1 && window >= 2 && window <= 512 * 8) {
+        // default: the walking kernel -- one scan per sample, blocks of `window` samples along each diagonal
+        const int nb = (int)((n + window - 1) / window);                  // output blocks per diagonal (covers [0, n))
+        int run = (int)(((int64_t)nb * nd + 8191) / 8192);                // >= ~8 k workgroups when the band is large enough
+        run = run < 4 ? (nb < 4 ? nb : 4) : (run > 32 ? 32 : run);        // priming costs one extra block scan per run
+        const int rpd = (nb + run - 1) / run;
+#define MST_WALK_CASE(NT_, C_)                                                                                          \
+    {                                                                                                                  \
+        normalize_walk_kernel<NT_, C_><<<(unsigned)(rpd * nd), NT_, 0, s>>>(band_in, band_out, n, window, diag_stats,   \
+                                                                           nb, run, rpd);                            \
+    }
+        // 4 samples per thread keep the kernel at ~120 VGPRs (4 waves per SIMD); wider windows take more threads, not more
+        // samples per thread (8 per thread need ~200 VGPRs)
+        if (window <= 256 * 2) MST_WALK_CASE(256, 2)
+        else if (window <= 256 * 4) MST_WALK_CASE(256, 4)
+        else if (window <= 512 * 4) MST_WALK_CASE(512, 4)
+        else MST_WALK_CASE(512, 8)
+#undef MST_WALK_CASE
+        MST_LAUNCH_CHECK();
+        return MST_OK;
+    }
     if (local && window >= 2) {
-        // default: prefix-sum kernel, as long as its tile (2 doubles + 1 int per sample, + the segment) fits the LDS
+        // local == 3: the segment / prefix-array kernel (2 doubles + 1 int per sample in LDS), kept selectable for cross-checks
         const int tile = kPSeg + window - 1;
         const int chunk = ((tile + 1 + kPThreads - 1) / kPThreads) | 1;  // samples per thread, odd
         const size_t plds = (sizeof(double) * 2 + sizeof(int)) * (size_t)kPThreads * chunk + sizeof(double) * kPSeg + 16;
-        if (plds <= 80 * 1024 && chunk <= kPMaxChunk && local != 2) {
+        if (plds <= 80 * 1024 && chunk <= kPMaxChunk && local == 3) {
             const int nseg = (int)((n + kPSeg - 1) / kPSeg);            // covers [0, n): the kernel also writes the zero tails
             const int64_t total = (int64_t)nseg * nd;
             const int64_t want_wgs = 256 * 2 * 8;                        // 8 waves of workgroups over 256 CUs x 2 resident

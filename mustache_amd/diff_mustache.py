@@ -7,8 +7,10 @@
     regulator(f1, f2, ...)                               <- diff_mustache.py:572-690
     main()                                               <- diff_mustache.py:720-906   (.loop1/.diffloop1/.loop2/.diffloop2)
 
-Both samples' sigma loops run as one 2-block launch of the fused HIP kernel; the difference image is scored on the
-device (mst_diff_image / mst_gauss_blur / mst_masked_normfit / mst_pair_pvalues).  Behaviour that looks odd but is the
+Per chromosome both samples' sigma loops run band-direct (mst_scale_space_band on each sample's band) and the difference
+image is formed, blurred and scored inside mst_diff_dog_band -- no dense block of either sample, no difference image and no
+blurred level of it reaches HBM.  diff_mustache() itself receives dense blocks (the reference's seam) and runs them through
+mst_scale_space / mst_diff_image / mst_gauss_blur / mst_masked_normfit / mst_pair_pvalues; the tests hold the two routes equal.  Behaviour that looks odd but is the
 reference's is kept and marked: the difference DoG is the octave's D_2 for every tested level (:336 vs :363), the
 bias of sample 1 is never applied by main() (:824-827), and -d is clamped to 2000 * res (:770-778).
 """
@@ -129,7 +131,8 @@ def call_diff_loops_coo(coo1, coo2, res, distance_in_px, octave_values, st, pt, 
     CH, start, end = block_tiling(n, distance_in_px)                       # (:637-651)
     if verbose:
         print("Loop calling...")
-    per_pair = 2 * (CH * CH * 9) + 5 * CH * CH * 8 + 2 * max(4096, CH * CH // 32) * 32
+    # per block pair in HBM: D_2 of the difference image for every octave + the two samples' record buffers
+    per_pair = len(octave_values) * CH * CH * 8 + 2 * max(4096, CH * CH // 32) * 48
     bs = max(1, int(pipe.max_batch_bytes // per_pair))
     o = []
     idx = list(range(len(start)))
@@ -145,8 +148,13 @@ def call_diff_loops_coo(coo1, coo2, res, distance_in_px, octave_values, st, pt, 
     return o
 
 
-def _pairs_from_filled(eng, pipe, dbands, n, dpx, starts, CH):
-    """Blocks + masks of both samples straight from their bands (filled, with nz), then sigma loop + pair p-values."""
+def _pairs_from_filled(eng, pipe, dbands, n, dpx, starts, CH, dense=False):
+    """Sigma loops of both samples + pair p-values for the block pairs that start at `starts`.  Default: band-direct -- both
+    samples' tiles are cut out of their bands inside the kernels (engine.run_band_pairs), no dense block, difference image or
+    blurred level of it is ever materialised.  dense=True: the reference's own data flow (filled dense blocks of both
+    samples, difference image, its two blurs per octave) -- kept as the cross-check path."""
+    if not dense:
+        return eng.run_band_pairs(dbands, n, dpx, starts, CH)
     import torch
     from .engine import BlockBatch
     c1, nz1, cnt1 = pipe.blocks_from_band(dbands[0], n, dpx, starts, CH)
@@ -159,7 +167,9 @@ def _pairs_from_filled(eng, pipe, dbands, n, dpx, starts, CH):
     ppair, nfit = eng.pair_pvalues(c, nz, found, cap, count)
     recs, fits = eng._download(found, pval, count, fit, eng.levels.n_tested, sort=True,
                                extra={"pair": ppair, "q": eng.fdr(pval, count, cap)})
-    return BlockBatch(eng, c, nz, CH, c.shape[0], nzc.cpu().numpy().view(np.uint32).astype(np.int64), recs, fits)
+    batch = BlockBatch(eng, c, nz, CH, c.shape[0], nzc.cpu().numpy().view(np.uint32).astype(np.int64), recs, fits)
+    batch.norm_fit = nfit.cpu().numpy()
+    return batch
 
 
 def regulator(f1, f2, norm_method, CHRM_SIZE, outdir, bed1="", bed2="", res=5000, sigma0=1.6, s=10, pt=0.1, pt2=0.1,

@@ -178,6 +178,36 @@ class BandBatch(_MultiGather):
                                                        ks, m, out, _stream()))
 
 
+class PairBandBatch(_MultiGather):
+    """The two-sample caller's batch: blocks [0, P) are windows of sample 1's band, blocks [P, 2P) the same windows of
+    sample 2's band (reference diff_mustache.py:671-674 builds the two dense blocks; here neither exists)."""
+
+    def __init__(self, engine, bands, n, dpx, starts, CH, nz_count, found, fit):
+        self.engine, self.bands, self.n, self.dpx, self.CH = engine, bands, int(n), int(dpx), CH
+        self.starts = list(starts) + list(starts)
+        self.P = len(starts)
+        self.B = 2 * self.P
+        self.nz_count, self.found, self.fit = nz_count, found, fit
+
+    def _device(self):
+        return self.bands[0].device
+
+    def _band(self, b):
+        return self.bands[0] if b < self.P else self.bands[1]
+
+    def _features_launch(self, b, pix, half, m, cnt1, cnt2, cval):
+        _lib.check(self.engine.lib.mst_candidate_features_band(_ptr(self._band(b)), self.n, self.dpx, int(self.starts[b]),
+                                                               self.CH, pix, half, m, cnt1, cnt2, cval, _stream()))
+
+    def _diagonals_launch(self, b, ks, m, out):
+        _lib.check(self.engine.lib.mst_gather_diagonals_band(_ptr(self._band(b)), self.n, self.dpx, int(self.starts[b]),
+                                                             self.CH, ks, m, out, _stream()))
+
+    def _diag_means_launch(self, b, ks, m, out):
+        _lib.check(self.engine.lib.mst_diag_means_band(_ptr(self._band(b)), self.n, self.dpx, int(self.starts[b]), self.CH,
+                                                       ks, m, out, _stream()))
+
+
 class ScaleSpaceEngine:
     """Owns the level table and runs rows 2-7 of SURVEY.md section 8a on the GPU."""
 
@@ -497,6 +527,54 @@ class ScaleSpaceEngine:
                 _lib.check(self.lib.mst_pair_pvalues(_ptr(found), found_cap, _ptr(count), _ptr(g2), _ptr(g3), _ptr(fit),
                                                      P, CH, n_oct, tpo, off, _ptr(ppair), _stream()))
         return ppair, fit
+
+    def pair_pvalues_band(self, band1, band2, n, dpx, starts, CH, found, found_cap, count):
+        """Band-direct form of pair_pvalues: the difference image and its G_2 / G_3 never reach HBM -- mst_diff_dog_band
+        writes D_2 = G_2 - G_3 of the difference image per octave and the norm.fit sums; found / count are the device records
+        of the two samples' sigma loops, sample 1 in [0, P), sample 2 in [P, 2P).  Returns (ppair [2P, found_cap], fit)."""
+        P = len(starts)
+        lt = self.levels
+        n_oct, tpo = len(lt.octave_values), lt.s - 1
+        dev = self.device
+        lv = ctypes.byref(self._lv_struct)
+        st_arr = (ctypes.c_int64 * P)(*[int(s) for s in starts])
+        with torch.cuda.device(dev):
+            dog = torch.empty((n_oct, P, CH, CH), dtype=torch.float64, device=dev)
+            fit = torch.empty((n_oct, P, 2), dtype=torch.float64, device=dev)
+            mcount = torch.empty(P, dtype=torch.int32, device=dev)
+            ws_bytes = int(self.lib.mst_diff_dog_workspace_bytes(P, CH, lv))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(self.lib.mst_diff_dog_band(_ptr(band1), _ptr(band2), int(n), int(dpx), st_arr, P, CH, lv, _ptr(dog),
+                                                  _ptr(fit), _ptr(mcount), _ptr(ws), ws_bytes, _stream()))
+            ppair = torch.empty((2 * P, found_cap), dtype=torch.float64, device=dev)
+            for off in (0, P):
+                _lib.check(self.lib.mst_pair_pvalues_dog(_ptr(found), found_cap, _ptr(count), _ptr(dog), _ptr(fit), P, CH,
+                                                         n_oct, tpo, off, _ptr(ppair), _stream()))
+        return ppair, fit
+
+    def run_band_pairs(self, bands, n, dpx, starts, CH, skip_empty=True):
+        """Both samples' sigma loops straight from their bands + the pair p-values: PairBandBatch over 2P blocks whose
+        records carry `pair` and `q`."""
+        cap = self._found_cap.get(CH, max(4096, (CH * CH) // 32))
+        while True:
+            parts = [self.sigma_loop_band(bd, n, dpx, starts, CH, skip_empty=skip_empty, download=False, found_cap=cap)
+                     for bd in bands]
+            caps = {p[4] for p in parts}
+            if caps == {cap}:
+                break
+            cap = max(caps)                      # a record-capacity overflow re-ran one sample with more room: redo both alike
+        found = torch.cat([p[0] for p in parts])
+        pval = torch.cat([p[1] for p in parts])
+        count = torch.cat([p[2] for p in parts])
+        fit = torch.cat([p[3] for p in parts])
+        nzc = torch.cat([p[5] for p in parts])
+        ppair, nfit = self.pair_pvalues_band(bands[0], bands[1], n, dpx, starts, CH, found, cap, count)
+        recs, fits = self._download(found, pval, count, fit, self.levels.n_tested, sort=True,
+                                    extra={"pair": ppair, "q": self.fdr(pval, count, cap)})
+        batch = PairBandBatch(self, bands, n, dpx, starts, CH, nzc.cpu().numpy().view(np.uint32).astype(np.int64), recs,
+                              fits)
+        batch.norm_fit = nfit.cpu().numpy()
+        return batch
 
     def run_block_pairs(self, c, dpx, intra=True, skip_empty=True):
         """c: [2P, CH, CH] raw blocks (sample 1 first, then sample 2), mutated in place.  BlockBatch over all 2P blocks

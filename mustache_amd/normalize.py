@@ -27,22 +27,26 @@ def band_to_coo(band, x, y, v_out, n, dpx):
     return v_out
 
 
-def normalize_band(band, n, dpx, resolution, blocked=False):
+_KERNELS = {"auto": 1, "blocked": 2, "segment": 3}
+
+
+def normalize_band(band, n, dpx, resolution, blocked=False, kernel=None):
     """Returns (normalised band, diag_stats [dpx+2, 4] = mean, std, weight, count).  Branch selection and window
-    size follow mustache.py:628, :631.  `blocked=True` asks for the blocked-sum kernel of branch A whatever the window
-    (mst_normalize_band's local == 2; the tests cross-check the two kernels)."""
+    size follow mustache.py:628, :631.  `kernel` picks the implementation of branch A (mst_normalize_band's `local`):
+    "auto" (default: the walking kernel, blocked sums for windows beyond 4096), "blocked", "segment" -- three independent
+    formulations of the same window sums that the tests cross-check.  `blocked=True` is short for kernel="blocked"."""
     lib = require_gpu()
     local = (n - dpx) * resolution > 2000000
     window = int(2000000 / resolution)
     out = torch.empty_like(band)
     stats = torch.empty((dpx + 2, 4), dtype=torch.float64, device=band.device)
     with torch.cuda.device(band.device):
-        _lib.check(lib.mst_normalize_band(_ptr(band), _ptr(out), int(n), int(dpx), window, (2 if blocked else 1) if local else 0,
+        _lib.check(lib.mst_normalize_band(_ptr(band), _ptr(out), int(n), int(dpx), window, _KERNELS[kernel or ("blocked" if blocked else "auto")] if local else 0,
                                           _ptr(stats), _stream()))
     return out, stats, local
 
 
-def normalize_sparse_device(x, y, v, resolution, distance_in_px, blocked=False):
+def normalize_sparse_device(x, y, v, resolution, distance_in_px, blocked=False, kernel=None):
     """Host COO in, `v` overwritten in place, weights returned -- the reference's call shape."""
     require_gpu()
     xh = np.ascontiguousarray(np.asarray(x), dtype=np.int64)
@@ -52,7 +56,7 @@ def normalize_sparse_device(x, y, v, resolution, distance_in_px, blocked=False):
     xd, yd = torch.from_numpy(xh).to(dev), torch.from_numpy(yh).to(dev)
     vd = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(dev)
     band = band_from_coo(xd, yd, vd, n, distance_in_px)
-    out, stats, local = normalize_band(band, n, distance_in_px, resolution, blocked=blocked)
+    out, stats, local = normalize_band(band, n, distance_in_px, resolution, blocked=blocked, kernel=kernel)
     band_to_coo(out, xd, yd, vd, n, distance_in_px)
     v[...] = vd.cpu().numpy()
     st = stats.cpu().numpy()

@@ -72,8 +72,8 @@ def main():
         sd = np.array([np.std(ex[d][ex[d] != 0]) if (ex[d] != 0).any() else 1.0 for d in range(dpx + 2)])[:, None]
         den = np.maximum(np.abs(ex), 1e-3 * sd)
         line = "%-16s n=%d dpx=%d window=%d nnz=%d:" % (name, n, dpx, int(2000000 / res), int((rh != 0).sum()))
-        for label, blocked in (("prefix kernel", False), ("blocked kernel", True)):
-            got = normalize_band(raw, n, dpx, res, blocked=blocked)[0].cpu().numpy()
+        for label, kern in (("walk", "auto"), ("segment", "segment"), ("blocked", "blocked")):
+            got = normalize_band(raw, n, dpx, res, kernel=kern)[0].cpu().numpy()
             err = np.abs(got - ex)
             line += "  %s rel %.2e abs %.2e" % (label, float((err / den).max()), float(err.max()))
         # the float64 oracle (np.convolve) against the same yardstick

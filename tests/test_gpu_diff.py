@@ -40,6 +40,84 @@ def test_pair_records_vs_reference(golden_dir):
         np.testing.assert_allclose(rec["pair"], ppair[f], rtol=1e-5, atol=1e-300)
 
 
+def _band_of(c, n, dpx):
+    """raw dense block -> band tensor [dpx+2, n] on the GPU (what the per-chromosome driver holds)."""
+    import torch
+    from mustache_amd.normalize import band_from_coo
+    x, y = np.nonzero(np.triu(c))
+    return band_from_coo(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(c[x, y]).cuda(), n, dpx)
+
+
+def test_band_direct_pairs_equal_dense_pairs_and_reference(golden_dir):
+    """engine.run_band_pairs (both samples band-direct, difference image / G_2 / G_3 only ever in LDS: mst_diff_dog_band)
+    against engine.run_block_pairs (the reference's dense data flow) and the reference's locals: found sets and winning DoG
+    values identical, p-values and q identical, pair p-values within 1e-9 of the dense route (the norm.fit scale comes from
+    one pass instead of two) and within 1e-5 of the reference."""
+    import torch
+    from mustache_amd.engine import ScaleSpaceEngine
+    g = _load(golden_dir)
+    c1, c2 = _blocks(g)
+    n, dpx = int(g["n"]), int(g["dpx"])
+    eng = ScaleSpaceEngine(OCT)
+    dense = eng.run_block_pairs(torch.from_numpy(np.stack([c1, c2])).cuda(), dpx)
+    band = eng.run_band_pairs([_band_of(c1, n, dpx), _band_of(c2, n, dpx)], n, dpx, [0], n)
+    np.testing.assert_allclose(band.norm_fit, dense.norm_fit, rtol=1e-10)
+    assert list(band.nz_count) == list(dense.nz_count)
+    for b, nm in ((0, "1"), (1, "2")):
+        ra, rb = dense.found[b], band.found[b]
+        for k in ("pixel", "level", "value", "pval", "q"):
+            assert np.array_equal(ra[k], rb[k]), k
+        np.testing.assert_allclose(rb["pair"], ra["pair"], rtol=1e-9, atol=1e-300)
+        f = g["loc_pPair" + nm] != 2
+        np.testing.assert_allclose(rb["pair"], g["loc_pPair" + nm][f], rtol=1e-5, atol=1e-300)
+        # the gathers of the tail read the band: same window counts and values as the dense blocks give
+        pix = ra["pixel"][:200]
+        half = np.full(len(pix), 2, np.int64)
+        fa, fb = dense.candidate_features(b, pix, half), band.candidate_features(b, pix, half)
+        for u, v in zip(fa, fb):
+            assert np.array_equal(u, v)
+
+
+def test_baseline_geometry_pairs_vs_reference_fixture(golden_dir):
+    """BASELINE config 5's block geometry (2000 x 2000, distance limit 400 px) against the reference's own diff_mustache()
+    (tests/golden/diff_2000.npz): both samples' found sets through checksums, the norm.fit pairs, and the four loop lists
+    -- through the band-direct route the driver uses."""
+    from mustache_amd.diff_mustache import _pair_tail
+    from mustache_amd.engine import ScaleSpaceEngine
+    from mustache_amd.synth import synth_coo
+    g = np.load(os.path.join(golden_dir, "diff_2000.npz"), allow_pickle=True)
+    n, dpx, start = int(g["n"]), int(g["dpx"]), int(g["start"])
+    eng = ScaleSpaceEngine(OCT)
+    bands = []
+    for depth, seed, chk in ((300.0, 51, 0), (260.0, 52, 1)):        # the raw synthetic maps, as the fixture was made
+        x, y, v = synth_coo(n, dpx, depth=depth, seed=seed)
+        assert float(v.sum()) == float(g["in_sums"][chk]) and len(v) == int(g["in_sums"][2 + chk]), "generator drifted"
+        c = np.zeros((n, n))
+        c[x, y] = v
+        bands.append(_band_of(c, n, dpx))
+    batch = eng.run_band_pairs(bands, n, dpx, [0], n)
+    sig = np.asarray(eng.levels.tested_sigma)
+    for b, nm in ((0, "1"), (1, "2")):
+        rec = batch.found[b]
+        pix = rec["pixel"].astype(np.int64)
+        assert int(batch.nz_count[b]) == int(g["nz_count" + nm])
+        assert len(pix) == int(g["found_count" + nm]) and int(pix.sum()) == int(g["found_pixel_sum" + nm])
+        assert int(np.bitwise_xor.reduce(pix)) == int(g["found_pixel_xor" + nm])
+        np.testing.assert_allclose(float(rec["value"].sum()), float(g["found_value_sum" + nm]), rtol=1e-9)
+        np.testing.assert_allclose(float(sig[rec["level"].astype(int) - 1].sum()), float(g["found_sigma_sum" + nm]), rtol=1e-12)
+        np.testing.assert_allclose(float(rec["q"].sum()), float(g["found_pvalue_sum" + nm]), rtol=1e-7)
+        np.testing.assert_allclose(float(rec["pair"].sum()), float(g["found_pair_sum" + nm]), rtol=1e-6)
+    np.testing.assert_allclose(batch.norm_fit[0, 0], g["norm_fit"][0], rtol=1e-7)
+    np.testing.assert_allclose(batch.norm_fit[1, 0], g["norm_fit"][9], rtol=1e-7)
+    out = _pair_tail(batch, 0, 1, start, float(g["pt"]), float(g["pt2"]), float(g["st"]), True)
+    for got, key in zip(out, ("loops1", "diff1", "loops2", "diff2")):
+        exp = g[key]
+        arr = np.array([[float(a), float(b), q, s] for a, b, q, s in got]).reshape(-1, 4)
+        assert arr.shape == exp.shape and len(exp) > 30, key
+        assert np.array_equal(arr[:, :2], exp[:, :2]) and np.array_equal(arr[:, 3], exp[:, 3]), key
+        np.testing.assert_allclose(arr[:, 2], exp[:, 2], rtol=1e-7)
+
+
 def test_diff_mustache_dropin_vs_reference(golden_dir):
     from mustache_amd.diff_mustache import diff_mustache
     g = _load(golden_dir)

@@ -358,9 +358,11 @@ def test_normalisation_kernel_vs_oracle_at_real_window_sizes(n, dpx, res, depth)
     normalize_sparse(x, y, got, res, dpx)
     np.testing.assert_allclose(got, exp, rtol=1e-9, atol=1e-9)
     assert np.count_nonzero(got) > 0.9 * len(got)
-    alt = v.copy()
-    normalize_sparse_device(x, y, alt, res, dpx, blocked=True)
-    np.testing.assert_allclose(alt, exp, rtol=1e-9, atol=1e-9)
+    for kernel in ("blocked", "segment"):                  # the other two formulations of the same window sums
+        alt = v.copy()
+        normalize_sparse_device(x, y, alt, res, dpx, kernel=kernel)
+        np.testing.assert_allclose(alt, exp, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(alt, got, rtol=1e-11, atol=1e-11)
 
 
 def test_two_rank_cli_equals_one_process(golden_dir, tmp_path):

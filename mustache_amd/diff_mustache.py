@@ -106,7 +106,7 @@ def call_diff_loops_coo(coo1, coo2, res, distance_in_px, octave_values, st, pt, 
     """regulator's body after the readers (diff_mustache.py:628-685): normalise both samples on the GPU, cut the same
     tiling out of both bands, run all block pairs."""
     import torch
-    from .normalize import band_from_coo, normalize_band
+    from .normalize import band_from_host_coo, normalize_band
     from .pipeline import ChromosomePipeline
     pipe = ChromosomePipeline(octave_values)
     eng, dev = pipe.engine, pipe.device
@@ -120,8 +120,7 @@ def call_diff_loops_coo(coo1, coo2, res, distance_in_px, octave_values, st, pt, 
     n = max(ns)                                                            # (:632)
     dbands = []
     for (x, y, v), n_s in zip(bands, ns):
-        xd, yd, vd = (torch.from_numpy(a).to(dev) for a in (x, y, v))
-        band = band_from_coo(xd, yd, vd, n_s, distance_in_px)              # each sample is normalised with ITS OWN n
+        band = band_from_host_coo(x, y, v, n_s, distance_in_px, dev)       # each sample is normalised with ITS OWN n
         band, _, _ = normalize_band(band, n_s, distance_in_px, res)       # (:634-635 -> mustache.py:623)
         if n_s < n:                                                        # blocks are cut with the common n
             pad = torch.zeros((distance_in_px + 2, n), dtype=torch.float64, device=dev)

@@ -19,6 +19,33 @@ def band_from_coo(x, y, v, n, dpx):
     return band
 
 
+def band_from_host_coo(x, y, v, n, dpx, device):
+    """Host COO (the readers' output) -> band on `device`, with the reference's rule for repeated pixels.  The reference
+    writes the entries of a diagonal in input order (`vals[x[indices]] = v[indices]`, mustache.py:633-635; `cc[xc, yc] = vc`,
+    :921-924): the LAST entry of a repeated (x, y) wins.  The device scatter is a plain racing store, so repeated pixels are
+    looked for first (one count on the device) and, only if there are any, removed on the host keeping the last one.
+    (The reference's per-diagonal mean / std run over ALL entries, repeats included, :636-639; after the de-duplication a
+    repeated pixel counts once here -- stated in DESIGN.md; a contact list with repeats is malformed input for both.)"""
+    import warnings
+    xd, yd, vd = (torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in (x, y, v))
+    band = band_from_coo(xd, yd, vd, n, dpx)
+    lo, hi = torch.minimum(xd, yd), torch.maximum(xd, yd)
+    in_band = ((hi - lo) <= dpx + 1) & (lo >= 0) & (hi < n) & (vd != 0)
+    if int((band != 0).sum().item()) != int(in_band.sum().item()):
+        xs, ys, vs = np.asarray(x, dtype=np.int64), np.asarray(y, dtype=np.int64), np.asarray(v, dtype=np.float64)
+        key = np.minimum(xs, ys) * np.int64(n) + np.maximum(xs, ys)
+        order = np.argsort(key, kind="stable")
+        last = np.ones(len(key), bool)
+        last[:-1] = key[order][1:] != key[order][:-1]          # last entry of every run of equal keys, in input order
+        keep = np.sort(order[last])
+        warnings.warn("contact list holds %d repeated pixel(s): the last entry of each is used (as the reference's scatter does)"
+                      % (len(key) - len(keep)))
+        del band, xd, yd, vd
+        xd, yd, vd = (torch.from_numpy(np.ascontiguousarray(a[keep])).to(device) for a in (xs, ys, vs))
+        band = band_from_coo(xd, yd, vd, n, dpx)
+    return band
+
+
 def band_to_coo(band, x, y, v_out, n, dpx):
     lib = require_gpu()
     with torch.cuda.device(band.device):

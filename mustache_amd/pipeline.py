@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from .engine import ScaleSpaceEngine, BlockBatch, BandBatch, _ptr, _stream
-from .normalize import band_from_coo, normalize_band
+from .normalize import band_from_coo, band_from_host_coo, normalize_band
 from .sharding import shard_blocks, gather_loops, world
 from .tail import batch_tail
 
@@ -114,9 +114,7 @@ class ChromosomePipeline:
         v = np.ascontiguousarray(np.asarray(v), dtype=np.float64)
         n = int(max(x.max(), y.max())) + 1                                       # mustache.py:894
         t0 = time.time()
-        xd, yd, vd = (torch.from_numpy(a).to(self.device) for a in (x, y, v))
-        band = band_from_coo(xd, yd, vd, n, dpx)
-        del xd, yd, vd
+        band = band_from_host_coo(x, y, v, n, dpx, self.device)
         if not normalized:
             if verbose:
                 print("Normalizing contact map...")

@@ -59,10 +59,18 @@ def kernels(path):
 
 
 def demangle(name):
-    try:
-        return subprocess.run([LLVM + "/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip() or name
-    except Exception:
-        return name
+    for tool in (LLVM + "/llvm-cxxfilt", "llvm-cxxfilt", "c++filt"):
+        try:
+            out = subprocess.run([tool, name], capture_output=True, text=True).stdout.strip()
+            if out and out != name:
+                return out
+        except Exception:
+            pass
+    # no demangler on this box: keep the readable middle of the Itanium name
+    import re
+    m = re.search(r"N_1\d+(\w+?)I", name) or re.search(r"N_1\d+(\w+?)E", name)
+    tail = re.sub(r"^.*?(INS_4Tile|ILi)", r"\1", name) if "Tile" in name or "ILi" in name else ""
+    return (m.group(1) if m else name) + ("<" + tail[:60] + ">" if tail else "")
 
 
 if __name__ == "__main__":

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Condense a gpurun_out/prof_<tag>/ directory (scripts/profile_bench.sh) into profiles/<tag>_summary.md and
-profiles/pmc_traffic.json (HBM bytes per launch of the fused kernel, corrected as MI355X_MICROARCH.md prescribes)."""
+"""Condense a gpurun_out/prof_<tag>/ directory (scripts/profile_bench.sh) into <tag>_summary.md, <tag>_pmc_traffic.json (HBM
+bytes per pixel of the fused kernel, corrected as MI355X_MICROARCH.md prescribes) and <tag>_kernel_stats.csv, written next to the
+raw data; copy the three into profiles/.  Register / LDS figures come from the code object (scripts/kernel_resources.py), not from
+the trace's granule-encoded VGPR_Count column."""
 import csv
 import collections
 import json
@@ -8,13 +10,15 @@ import os
 import sys
 
 tag = sys.argv[1]
-src = os.path.join("gpurun_out", "prof_" + tag)
-out_md = os.path.join("profiles", tag + "_summary.md")
+src = sys.argv[2] if len(sys.argv) > 2 else os.path.join("gpurun_out", "prof_" + tag)
+out_md = os.path.join(src, tag + "_summary.md")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
 lines = ["# rocprofv3 summary `%s`" % tag, "",
          "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu` "
          "(scripts/profile_bench.sh); PMC passes: `rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --small "
          "--steps 1 --warmup 0 --no-cpu` with `MST_BENCH_OVERLAP=1` (12 blocks of 4000x4000 in ONE launch), one pass per counter "
-         "group.  The traced run uses bench.py's default of 4 launches per step (31 blocks each) on alternating streams.", ""]
+         "group, all in the same session as the trace.  The traced run uses bench.py's default of 4 launches per step on alternating streams.", ""]
 
 # ---- kernel stats ------------------------------------------------------------------------------------------------
 st = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
@@ -53,8 +57,22 @@ if all_dense:
               % (len(all_dense), blocks_dense, sum(all_dense) / len(all_dense), sum(all_dense) / blocks_dense,
                  124 * sum(all_dense) / blocks_dense)]
 r0 = ss[0]
-lines += ["", "VGPR_Count %s, Accum_VGPR_Count %s, SGPR_Count %s, Scratch_Size %s B/lane, workgroup %s threads."
-          % (r0["VGPR_Count"], r0["Accum_VGPR_Count"], r0["SGPR_Count"], r0["Scratch_Size"], r0["Workgroup_Size_X"]), ""]
+try:
+    import kernel_resources
+    res = [k for k in kernel_resources.kernels(os.path.join(ROOT, "mustache_amd", "libmustache_hip.so"))]
+    lines += ["", "## Registers / LDS / spills from the code object (`scripts/kernel_resources.py`)", "",
+              "| kernel | VGPR | AGPR | SGPR | SGPR spills | VGPR spills | scratch B/lane |", "|---|---|---|---|---|---|---|"]
+    for k in res:
+        nm = kernel_resources.demangle(k.get("name", "?")).replace("(anonymous namespace)::", "").replace("void ", "")
+        if not any(t in nm for t in ("scale_space_kernel", "normalize_walk", "diag_stats", "diff_dog", "normalize_prefix_kernel<13>")):
+            continue
+        lines.append("| `%s` | %d | %d | %d | %d | %d | %d |" % (nm.split("(")[0][:80], k.get("vgpr_count", -1), k.get("agpr_count", -1),
+                                                              k.get("sgpr_count", -1), k.get("sgpr_spill_count", -1),
+                                                              k.get("vgpr_spill_count", -1), k.get("private_segment_fixed_size", -1)))
+    lines += ["", "(The trace's `VGPR_Count` column reads %s for the fused kernel: it is an allocation-granule field, not the register "
+              "count.)  Workgroup %s threads, dynamic LDS %s B." % (r0["VGPR_Count"], r0["Workgroup_Size_X"], r0.get("LDS_Block_Size", "?")), ""]
+except Exception as e:                                      # llvm tools missing: say so instead of printing a wrong number
+    lines += ["", "(code-object metadata unavailable: %r)" % (e,), ""]
 
 # ---- PMC -----------------------------------------------------------------------------------------------------------
 def pmc(dirname, kernel_sub):
@@ -108,11 +126,56 @@ if "SQ_WAVE_CYCLES" in allc:
 if "SQ_LDS_BANK_CONFLICT" in allc and allc.get("SQ_LDS_IDX_ACTIVE"):
     lines += ["LDS: bank-conflict cycles / LDS active cycles = %.1f %%."
               % (100 * allc["SQ_LDS_BANK_CONFLICT"] / allc["SQ_LDS_IDX_ACTIVE"])]
-os.makedirs("profiles", exist_ok=True)
+# ---- the other kernels of the path: durations from the trace, HBM bytes from the PMC passes ------------------------------
+def pmc_all(kernel_sub):
+    """{counter: [values per dispatch, dispatch order]} over all PMC passes for kernels whose name holds kernel_sub."""
+    out = collections.defaultdict(list)
+    for d in sorted(os.listdir(src)):
+        if d.startswith("pmc_"):
+            per = pmc(d, kernel_sub)
+            for disp in sorted(per):
+                for k, v in per[disp].items():
+                    if k != "_grid":
+                        out[k].append((per[disp]["_grid"], v))
+    return out
+
+def durations(kernel_sub):
+    return [(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+            for r in tr if kernel_sub in r["Kernel_Name"]]
+
+lines += ["", "## Normalisation (row 1) and two-sample kernels", "",
+          "Trace durations are from the full bench run (normalisation of the chr1 @ 1 kb band: n = 248,957, 2,002 diagonals, "
+          "5.0e8 samples; two-sample path on the chr21 @ 5 kb shape: 6 block pairs of 2000 x 2000).  PMC bytes are from the "
+          "--small runs (n = 26,000: 5.2e7 band samples), FETCH_SIZE x2 + WRITE_SIZE of the largest dispatch of each kernel.", "",
+          "| kernel | launches | largest-launch ms (trace) | PMC fetch MB (x2) | PMC write MB | note |", "|---|---|---|---|---|---|"]
+extra = {}
+for sub, note in (("diag_stats_kernel", "one read of the band (8 B / sample)"),
+                  ("normalize_walk_kernel", "8 B read (+ priming block, + the centre samples from cache) + 8 B written per sample"),
+                  ("diff_dog_kernel", "two bands in, D_2 per octave out (16 B / pixel pair written)"),
+                  ("pair_pvalue_dog_kernel", "gather of D_2 at the found pixels")):
+    du = durations(sub)
+    if not du:
+        continue
+    big = max(g for g, _ in du)
+    dd = [t for g, t in du if g == big]
+    pm = pmc_all(sub)
+    fe = max((v for g, v in pm.get("FETCH_SIZE", [(0, 0.0)])), default=0.0) * 1024 * 2 / 1e6
+    wr = max((v for g, v in pm.get("WRITE_SIZE", [(0, 0.0)])), default=0.0) * 1024 / 1e6
+    extra[sub] = {"launches": len(du), "largest_ms_mean": sum(dd) / len(dd), "pmc_fetch_mb_small": fe, "pmc_write_mb_small": wr}
+    lines.append("| `%s` | %d | %.3f (x%d) | %.1f | %.1f | %s |" % (sub, len(du), sum(dd) / len(dd), len(dd), fe, wr, note))
+if "diag_stats_kernel" in extra and "normalize_walk_kernel" in extra:
+    tot = extra["diag_stats_kernel"]["largest_ms_mean"] + extra["normalize_walk_kernel"]["largest_ms_mean"]
+    samples = 248957 * 2002
+    lines += ["", "mst_normalize_band on chr1 @ 1 kb = %.3f ms (statistics) + %.3f ms (windows) = **%.3f ms** for %.2e samples: "
+              "%.0f GB/s of the 16 B / sample model = %.3f of 8 TB/s." % (extra["diag_stats_kernel"]["largest_ms_mean"],
+              extra["normalize_walk_kernel"]["largest_ms_mean"], tot, samples, 16.0 * samples / tot / 1e6,
+              16.0 * samples / tot / 1e6 / 8000.0)]
 open(out_md, "w").write("\n".join(lines) + "\n")
 if traffic:
-    json.dump(traffic, open(os.path.join("profiles", "pmc_traffic.json"), "w"), indent=1)
+    traffic["command"] = "MST_BENCH_OVERLAP=1 rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --small --steps 1 --warmup 0 --no-cpu"
+    traffic["other_kernels"] = extra
+    json.dump(traffic, open(os.path.join(src, tag + "_pmc_traffic.json"), "w"), indent=1)
 # keep the raw stats csv next to the summary
 import shutil
-shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join("profiles", tag + "_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(src, tag + "_kernel_stats.csv"))
 print("\n".join(lines))

@@ -459,3 +459,34 @@ def test_whole_genome_cool_path_two_ranks_equals_oracle(tmp_path):
         np.testing.assert_allclose([q for _, _, q, _ in g], [q for _, _, q, _ in exp], rtol=1e-9)
         total += len(exp)
     assert total > 30
+
+
+def test_repeated_pixels_last_entry_wins():
+    """A contact list that repeats a pixel (same (x, y) twice with different counts, or (y, x) after (x, y)): the reference's
+    scatters keep the LAST entry (mustache.py:633-635, :921-924).  The pipeline detects the repeats and does the same,
+    deterministically, instead of letting the device scatter's racing stores pick one."""
+    import warnings
+    from mustache_amd.normalize import band_from_host_coo
+    from mustache_amd.synth import synth_coo
+    n, dpx = 700, 60
+    x, y, v = synth_coo(n, dpx, depth=30.0, seed=77)
+    rng = np.random.default_rng(1)
+    dup = rng.choice(len(v), 500, replace=False)
+    x2 = np.concatenate([x, x[dup[:250]], y[dup[250:]]])         # 250 exact repeats, 250 mirrored ones
+    y2 = np.concatenate([y, y[dup[:250]], x[dup[250:]]])
+    v2 = np.concatenate([v, v[dup] + 7.0])
+    exp = np.zeros((dpx + 2, n))
+    for a, b, c in zip(x2, y2, v2):                                # the reference's rule, entry by entry
+        lo, hi = min(a, b), max(a, b)
+        if hi - lo <= dpx + 1:
+            exp[hi - lo, lo] = c
+    for _ in range(3):                                             # deterministic, run after run
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            band = band_from_host_coo(x2, y2, v2, n, dpx, "cuda").cpu().numpy()
+        assert np.array_equal(band, exp)
+        assert any("repeated pixel" in str(m.message) for m in w)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                            # no repeats -> no warning, no host pass
+        band = band_from_host_coo(x, y, v, n, dpx, "cuda").cpu().numpy()
+    assert np.count_nonzero(band) == np.count_nonzero((y - x) <= dpx + 1)

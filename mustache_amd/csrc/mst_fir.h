@@ -275,100 +275,20 @@ __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__r
         }
     }
     if constexpr (MAINC < NC) if (!MST_VARIANT(8)) {  // [ablation 8] no leftover pieces
+        constexpr int PR = 4;                        // rows per leftover piece (2-row pieces halve the skew between the waves
+                                                     // but double the pieces' window loads: +2 % kernel time, measured)
         constexpr int XC = NC - MAINC;               // leftover columns
-        constexpr int XRG = T::RGR / 4;              // 4-row pieces per column
+        constexpr int XRG = T::RGR / PR;             // pieces per column
         for (int it = ptid; it < XRG * XC; it += T::NT) {
             const int rgp = it / XC;
             const int col = MAINC + (it - rgp * XC);
-            const int row0 = rgp * 4;
+            const int row0 = rgp * PR;
             const double *p = ct + ((T::RMAX - R) + col) * T::CTP + (row0 + T::RMAX - R - OFF);
-            double t[4];
-            fir_chunk<4, R, OFF, T::FMA>(p, w, t);
+            double t[PR];
+            fir_chunk<PR, R, OFF, T::FMA>(p, w, t);
             double *q = vb + row0 * T::VP + col;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) q[k * T::VP] = t[k];
-        }
-    }
-}
-
-// Axis-0 pass of TWO consecutive levels (radii RA <= RB <= RA + 1) over level B's strip.  Items and thread mapping are those
-// of vpass<T, RB>; an item's ct column serves level B's strip column `col` and level A's strip column col - (RB - RA).
-// Level A's samples go to vb at once; level B's stay in registers (hold_main: this thread's K-row item; hold_piece: its 4-row
-// leftover piece, if it has one) until level A's axis-1 pass has read vb -- vpass2_flush then writes them.
-template <class T, int RA, int RB>
-__device__ __forceinline__ void vpass2(const double *__restrict__ ct, double *__restrict__ vb,
-                                       const double (&walla)[T::RMAX + 1], const double (&wallb)[T::RMAX + 1], int ptid,
-                                       const double *__restrict__ vsrc, double *__restrict__ vdst, int v_col,
-                                       double (&hold_main)[T::K], double (&hold_piece)[4]) {
-    static_assert(RB - RA == 0 || RB - RA == 1, "paired levels differ by at most one in radius");
-    constexpr int K = T::K, KC = Chunk<T::K, RB>::KC;
-    constexpr int DELTA = RB - RA;
-    constexpr int NCB = T::RGC + 2 * RB, NCA = T::RGC + 2 * RA;
-    constexpr int NRG = T::RGR / K;
-    constexpr int MAINC = T::NT / NRG;
-    static_assert(MAINC <= NCB, "one full-length item per thread");
-    constexpr int OFF = (T::RMAX - RB) & 1;
-    double wa[RA + 1], wb[RB + 1];
-#pragma unroll
-    for (int j = 0; j <= RA; ++j) wa[j] = walla[j];
-#pragma unroll
-    for (int j = 0; j <= RB; ++j) wb[j] = wallb[j];
-    {
-        const double *p = vsrc + (T::RMAX - RB) * T::CTP + (T::RMAX - RB - OFF);
-        const int cola = v_col - DELTA;                  // level A's strip column of this ct column
-        const bool a_ok = cola >= 0 && cola < NCA;
-        double *qa = vdst - DELTA;
-#pragma unroll
-        for (int h = 0; h < K / KC; ++h) {
-            double ta[KC], tb[KC];
-            fir_chunk2<KC, RA, RB, OFF, T::FMA>(p + h * KC, wa, wb, ta, tb);
-#pragma unroll
-            for (int k = 0; k < KC; ++k) hold_main[h * KC + k] = tb[k];
-            if (a_ok) {
-#pragma unroll
-                for (int k = 0; k < KC; ++k) qa[(h * KC + k) * T::VP] = ta[k];
-            }
-        }
-    }
-    if constexpr (MAINC < NCB) {
-        constexpr int XC = NCB - MAINC;                  // leftover columns of level B's strip
-        constexpr int XRG = T::RGR / 4;
-        static_assert(XRG * XC <= T::NT, "at most one leftover piece per thread");
-        if (ptid < XRG * XC) {
-            const int rgp = ptid / XC;
-            const int col = MAINC + (ptid - rgp * XC);
-            const int row0 = rgp * 4;
-            const double *p = ct + ((T::RMAX - RB) + col) * T::CTP + (row0 + T::RMAX - RB - OFF);
-            double ta[4];
-            fir_chunk2<4, RA, RB, OFF, T::FMA>(p, wa, wb, ta, hold_piece);
-            const int cola = col - DELTA;
-            if (cola < NCA) {
-                double *q = vb + row0 * T::VP + cola;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) q[k * T::VP] = ta[k];
-            }
-        }
-    }
-}
-
-// level B's held axis-0 samples -> vb (after a barrier that follows level A's axis-1 pass)
-template <class T, int RB>
-__device__ __forceinline__ void vpass2_flush(double *__restrict__ vb, int ptid, double *__restrict__ vdst,
-                                             const double (&hold_main)[T::K], const double (&hold_piece)[4]) {
-    constexpr int K = T::K;
-    constexpr int NCB = T::RGC + 2 * RB;
-    constexpr int MAINC = T::NT / (T::RGR / K);
-#pragma unroll
-    for (int k = 0; k < K; ++k) vdst[k * T::VP] = hold_main[k];
-    if constexpr (MAINC < NCB) {
-        constexpr int XC = NCB - MAINC;
-        constexpr int XRG = T::RGR / 4;
-        if (ptid < XRG * XC) {
-            const int rgp = ptid / XC;
-            const int col = MAINC + (ptid - rgp * XC);
-            double *q = vb + (rgp * 4) * T::VP + col;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) q[k * T::VP] = hold_piece[k];
+            for (int k = 0; k < PR; ++k) q[k * T::VP] = t[k];
         }
     }
 }

@@ -423,10 +423,15 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
             uint32_t en = 0, gn = 0;   // en: D_new == M_new;  gn: D_new > M_prev (M of the level before it)
             double m[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                m[k] = dmax(dmax(lane_prev(hm[k]), hm[k]), lane_next(hm[k]));
-                if (d[k] == m[k]) en |= 1u << k;
-                if (d[k] > Mc[k]) gn |= 1u << k;
+            for (int k = 0; k < K; ++k) m[k] = dmax(dmax(lane_prev(hm[k]), hm[k]), lane_next(hm[k]));
+            // the comparisons belong to the sieve, which the reference evaluates on the tested pixels only
+            // (LocMaxC[nz] == Lc[nz] ..., mustache.py:760-765): a wave that owns none never reads these bits
+            if (wave_has_nz) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if (d[k] == m[k]) en |= 1u << k;
+                    if (d[k] > Mc[k]) gn |= 1u << k;
+                }
             }
             if (kl >= 4) {
                 // tested level = D_{kl-2}: previous = D_{kl-3} (ep), current (Dc, ec, gp), next = this one (m, en)
@@ -451,8 +456,9 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
                         lsum = lsum + a;
                     }
                 }
-                // fixed-order DPP reduction inside the wave (total lands in lane 63), one slot per (level, wave)
-                if (!MST_VARIANT(2)) wave_reduce_min_sum(lmin, lsum);
+                // fixed-order DPP reduction inside the wave (total lands in lane 63), one slot per (level, wave); a wave without
+                // a tested pixel holds the identities {inf, 0} in every lane already
+                if (wave_has_nz && !MST_VARIANT(2)) wave_reduce_min_sum(lmin, lsum);
                 if (lane == 63) {
                     st[(tested * T::NW + wave) * 2] = lmin;
                     st[(tested * T::NW + wave) * 2 + 1] = lsum;

@@ -12,9 +12,11 @@
 //   mst_blocks_from_band  mustache.py:919-924 + :699-706 fused: filled dense blocks + nz mask straight from the band
 //
 // Reproducibility note: the reference's window sums come from np.convolve -> BLAS ddot, whose
-// accumulation order depends on the host's BLAS build, so bit-equality with "the" reference does not exist for
-// this stage.  We sum every window directly (no running/prefix sums), in a fixed order, which stays within a few
-// ulp of any such order; tests hold the result to 1e-9 relative on z-scores and require identical loop sets.
+// accumulation order depends on the host's BLAS build, so bit-equality with "the" reference does not exist for this stage.
+// Every window sum here is the sum of two partial sums of at most W terms each (the walking kernel below), accumulated in a
+// fixed order: deterministic, and within 1.2e-12 (relative, z-scores) of the same formula evaluated in extended precision --
+// the distance the reference's own float64 path has from it (scripts/norm_accuracy.py).  Tests hold 1e-11 against the oracle
+// and require identical loop sets downstream.
 #include <cmath>
 #include <cstdlib>
 #include "mst_common.h"
@@ -582,7 +584,7 @@ normalize_walk_kernel(const double *__restrict__ band_in, double *__restrict__ b
                 // 1/cnt and 1/(cnt-1) from ONE division; a window with c < 30 -- including c = 1, where the product form
                 // gives NaN -- takes the fallback below
                 const double cnt = (double)c;
-                const double rcc = 1.0 / (cnt * (cnt - 1.0));
+                const double rcc = 1.0 / (cnt * (cnt - 1.0));       // (a table of these quotients in LDS was measured: no gain)
                 const double inv_c = rcc * (cnt - 1.0), inv_cm1 = rcc * cnt;
                 double var = (s2w - s1w * s1w * inv_c) * inv_cm1;        // (:650)
                 if (!isfinite(var)) var = std2;                          // (:653-654)
@@ -795,7 +797,10 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
         const size_t nblk = (size_t)(kSeg + window + 2 * kBlk + kBlk - 1) / kBlk;
         const size_t lds = sizeof(double) * (2 * nblk * kBlk + 2 * nblk) + sizeof(int) * nblk + 16;
         if (window < 2 || lds > 160 * 1024)
-            return mst::fail(MST_E_ARG, "mst_normalize_band: window %d outside [2, ~8800]", window);
+            return mst::fail(MST_E_ARG,
+                             "mst_normalize_band: window of %d bins (= 2 Mb / resolution) is outside [2, ~8400]: the sliding-window "
+                             "normalisation supports resolutions down to ~240 bp",
+                             window);
         static unsigned long long lds_allowed = 0;      // per device (mst_common.h)
         MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&normalize_local_kernel), 160 * 1024,
                                        &lds_allowed));

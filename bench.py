@@ -188,15 +188,21 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # MST_BENCH_FORCE_DIST=1: join a process group even with one rank, so that the RCCL calls of the N > 1 path (init with
+    # device_id, barrier, all_gather of the timings) execute on a single-GPU box
+    force_dist = bool(os.environ.get("MST_BENCH_FORCE_DIST")) and world == 1
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29561")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    grouped = world > 1 or force_dist
+
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -222,7 +228,7 @@ def main():
         # the closing barrier) -- max/min over ranks shows the imbalance of the block split
         torch.cuda.synchronize()
         t = torch.tensor([dt, own[0]], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        if world > 1:
+        if grouped:
             allt = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(allt, t)
             dt = max(float(a[0]) for a in allt)
@@ -387,7 +393,7 @@ def main():
             out["speedup_vs_cpu_node"] = round(value / out["cpu_baseline_node"]["value"], 1)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

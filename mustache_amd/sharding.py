@@ -32,11 +32,12 @@ def assign_chromosomes(weights, world_size):
     return owner
 
 
-def gather_records(rec, device=None, group=None):
-    """all_gather of a float64 [m, w] array per rank (m differs per rank) -> list of the ranks' arrays, on every rank."""
+def gather_records(rec, device=None, group=None, force=False):
+    """all_gather of a float64 [m, w] array per rank (m differs per rank) -> list of the ranks' arrays, on every rank.
+    `force=True` runs the two collectives even in a 1-rank group (the RCCL smoke test on single-GPU boxes)."""
     rank, ws = world()
     rec = np.ascontiguousarray(rec, dtype=np.float64)
-    if ws == 1:
+    if ws == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return [rec]
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"

@@ -56,3 +56,30 @@ def test_bench_two_ranks_gloo_one_device():
     _check_line(j, 2, 2, 1)
     assert j["ranks"]["blocks_per_rank_max"] == 6 and "2 rank" in j["config"]["sharding"]
     assert "cpu_baseline" not in j and "chr21_5kb" not in j        # rank-0-at-N=1-only legs stay out of the N > 1 line
+
+
+def test_rccl_calls_run_in_a_one_rank_group(tmp_path):
+    """No multi-GPU box is available to these tests, but the RCCL code path itself can run: a 1-rank `nccl` process group on
+    this GPU through (a) bench.py's N > 1 control flow (MST_BENCH_FORCE_DIST: init_process_group(..., device_id), barrier,
+    all_gather of the timings on device tensors) and (b) sharding.gather_records with force=True (all_gather of the counts
+    and of the padded record block, device tensors)."""
+    env = dict(os.environ, MST_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29563")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "1", "--warmup", "0", "--small", "--no-cpu"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    _check_line(_last_json(r.stdout), 1, 1, 0)
+    script = tmp_path / "g.py"
+    script.write_text(
+        "import numpy as np, torch, torch.distributed as dist\\n"
+        "from mustache_amd.sharding import gather_records, gather_loops\\n"
+        "torch.cuda.set_device(0)\\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\\n"
+        "rec = np.arange(12, dtype=np.float64).reshape(3, 4)\\n"
+        "out = gather_records(rec, force=True)\\n"
+        "assert len(out) == 1 and np.array_equal(out[0], rec)\\n"
+        "assert gather_records(np.zeros((0, 4)), force=True)[0].shape == (0, 4)\\n"
+        "dist.barrier(); dist.destroy_process_group(); print('rccl ok')\\n")
+    env2 = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29565", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-3000:]

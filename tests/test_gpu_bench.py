@@ -71,15 +71,15 @@ def test_rccl_calls_run_in_a_one_rank_group(tmp_path):
     _check_line(_last_json(r.stdout), 1, 1, 0)
     script = tmp_path / "g.py"
     script.write_text(
-        "import numpy as np, torch, torch.distributed as dist\\n"
-        "from mustache_amd.sharding import gather_records, gather_loops\\n"
-        "torch.cuda.set_device(0)\\n"
-        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\\n"
-        "rec = np.arange(12, dtype=np.float64).reshape(3, 4)\\n"
-        "out = gather_records(rec, force=True)\\n"
-        "assert len(out) == 1 and np.array_equal(out[0], rec)\\n"
-        "assert gather_records(np.zeros((0, 4)), force=True)[0].shape == (0, 4)\\n"
-        "dist.barrier(); dist.destroy_process_group(); print('rccl ok')\\n")
+        "import numpy as np, torch, torch.distributed as dist\n"
+        "from mustache_amd.sharding import gather_records, gather_loops\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "rec = np.arange(12, dtype=np.float64).reshape(3, 4)\n"
+        "out = gather_records(rec, force=True)\n"
+        "assert len(out) == 1 and np.array_equal(out[0], rec)\n"
+        "assert gather_records(np.zeros((0, 4)), force=True)[0].shape == (0, 4)\n"
+        "dist.barrier(); dist.destroy_process_group(); print('rccl ok')\n")
     env2 = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29565", PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=env2, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-3000:]

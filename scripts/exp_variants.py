@@ -31,10 +31,11 @@ def one(reps=5, blocks=12):
     raw = band_counts(n, dpx, 400.0, 800, 1, device=dev)
     band, _, _ = normalize_band(raw, n, dpx, res)
     del raw
-    pipe = ChromosomePipeline((1.6, 3.2), device=dev)
+    octs = tuple(float(o) for o in os.environ.get("EXP_OCTAVES", "1.6,3.2").split(","))      # e.g. 3.2,6.4 -> the wide-radius tile
+    pipe = ChromosomePipeline(octs, device=dev)
     CH, start, end = block_tiling(n, dpx)
     eng = pipe.engine
-    out = {"lib": os.environ.get("MUSTACHE_HIP_LIB", "default"), "blocks": len(start)}
+    out = {"lib": os.environ.get("MUSTACHE_HIP_LIB", "default"), "blocks": len(start), "octaves": list(octs)}
     modes = os.environ.get("EXP_MODES", "dense,skip").split(",")
     for mode, skip in (("dense", False), ("skip", True)):
         if mode not in modes:
@@ -56,7 +57,7 @@ def one(reps=5, blocks=12):
             pix += int((w & 0xFFFFFFFF).sum())
             lvl += int((w >> 32).sum())
             val += int(rec[b, :cnt[b], 1].astype(np.uint64).sum(dtype=np.uint64))
-        fsum = float(np.nansum(fit.cpu().numpy()[:, :18, :]))
+        fsum = float(np.nansum(fit.cpu().numpy()[:, :eng.levels.n_tested, :]))
         out[mode] = {"ms": round(ms[len(ms) // 2], 3), "min_ms": round(ms[0], 3),
                      "gpix_s": round(len(start) * CH * CH / 1e9 / (ms[len(ms) // 2] * 1e-3), 3),
                      "check": "%d/%d/%d/%d/%r/%d" % (int(cnt.sum()), pix, lvl, val % (1 << 61), fsum,

@@ -179,7 +179,8 @@ int mst_band_to_coo(const double *band, const int64_t *x, const int64_t *y, int6
 /* normalize_sparse (mustache.py:622-686) on the band, out of place (band_in != band_out).
  *   local != 0 : branch A (:628-669), taken by the caller when (n - dpx) * res > 2e6; `window` = int(2e6 / res).
  *                (local == 1: the library picks the kernel -- the walking kernel (blocks of `window` samples along each
- *                diagonal, one scan per sample) for windows up to 4096, blocked sums above; local == 2: the blocked-sum
+ *                diagonal, one scan per sample) for windows up to 4096, blocked sums up to ~8400, a slow spilling form
+ *                of the walking kernel up to 16384, an error beyond; local == 2: the blocked-sum
  *                kernel whatever the window; local == 3: the segment kernel with prefix arrays in LDS (windows up to
  *                ~3000, blocked sums above).  Three formulations of the same sums, selectable so they can be cross-checked.)
  *                Per diagonal d <= dpx+1: vals = v + 0.001; counts / sum / sum of squares over the zero-padded

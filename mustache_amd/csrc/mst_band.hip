@@ -742,7 +742,13 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
     const int nd = dpx + 2;
     diag_stats_kernel<<<nd, kThreads, 0, s>>>(band_in, n, diag_stats);
     MST_LAUNCH_CHECK();
-    if (local == 1 && window >= 2 && window <= 512 * 8) {
+    // walking kernel: windows up to 4096 bins at full speed; windows beyond what the blocked-sum kernel's LDS holds (~8400) run
+    // through the <1024, 16> instantiation (128-VGPR cap: it spills, it is slow, it is correct) so that resolutions down to
+    // ~125 bp work at all, as they do in the reference
+    const size_t blocked_nblk = (size_t)(kSeg + (window > 0 ? window : 0) + 2 * kBlk + kBlk - 1) / kBlk;
+    const size_t blocked_lds = sizeof(double) * (2 * blocked_nblk * kBlk + 2 * blocked_nblk) + sizeof(int) * blocked_nblk + 16;
+    const bool huge = local == 1 && blocked_lds > 160 * 1024 && window <= 1024 * 16;
+    if (local == 1 && window >= 2 && (window <= 512 * 8 || huge)) {
         // default: the walking kernel -- one scan per sample, blocks of `window` samples along each diagonal
         const int nb = (int)((n + window - 1) / window);                  // output blocks per diagonal (covers [0, n))
         int run = (int)(((int64_t)nb * nd + 8191) / 8192);                // >= ~8 k workgroups when the band is large enough
@@ -759,7 +765,8 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
         else if (window <= 256 * 4) MST_WALK_CASE(256, 4)
         // (measured at W = 2000: <512, 4> 3.4 ms, <256, 8> 4.0 ms, <1024, 2> 5.8 ms)
         else if (window <= 512 * 4) MST_WALK_CASE(512, 4)
-        else MST_WALK_CASE(512, 8)
+        else if (window <= 512 * 8) MST_WALK_CASE(512, 8)
+        else MST_WALK_CASE(1024, 16)
 #undef MST_WALK_CASE
         MST_LAUNCH_CHECK();
         return MST_OK;
@@ -799,8 +806,8 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
         const size_t lds = sizeof(double) * (2 * nblk * kBlk + 2 * nblk) + sizeof(int) * nblk + 16;
         if (window < 2 || lds > 160 * 1024)
             return mst::fail(MST_E_ARG,
-                             "mst_normalize_band: window of %d bins (= 2 Mb / resolution) is outside [2, ~8400]: the sliding-window "
-                             "normalisation supports resolutions down to ~240 bp",
+                             "mst_normalize_band: window of %d bins (= 2 Mb / resolution) is outside [2, 16384]: the sliding-window "
+                             "normalisation supports resolutions down to ~125 bp",
                              window);
         static unsigned long long lds_allowed = 0;      // per device (mst_common.h)
         MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&normalize_local_kernel), 160 * 1024,

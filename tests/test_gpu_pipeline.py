@@ -369,6 +369,24 @@ def test_normalisation_kernel_vs_oracle_at_real_window_sizes(n, dpx, res, depth)
         np.testing.assert_allclose(alt, got, rtol=3e-11, atol=3e-12)
 
 
+def test_normalisation_window_beyond_the_blocked_kernel():
+    """Resolutions finer than ~240 bp give windows (2 Mb / res) of more than ~8400 bins, beyond what the blocked-sum kernel's
+    LDS holds; they run through the walking kernel's <1024, 16> instantiation (slow, correct) instead of being refused, as
+    the reference accepts any resolution.  Here: res = 222 bp -> window 9009 bins."""
+    import oracle
+    from mustache_amd.mustache import normalize_sparse
+    from mustache_amd.synth import synth_coo
+    n, dpx, res = 30000, 40, 222
+    assert int(2000000 / res) == 9009 and (n - dpx) * res > 2000000
+    x, y, v = synth_coo(n, dpx, depth=25.0, seed=19)
+    exp = v.copy()
+    oracle.normalize_sparse(x, y, exp, res, dpx)
+    got = v.copy()
+    normalize_sparse(x, y, got, res, dpx)
+    np.testing.assert_allclose(got, exp, rtol=1e-10, atol=1e-11)
+    assert np.count_nonzero(got) > 0.9 * len(got)
+
+
 def test_two_rank_cli_equals_one_process(golden_dir, tmp_path):
     """`torchrun --nproc-per-node 2 -m mustache_amd ...` (both ranks on this box's one GPU, gloo process group -- the test
     hooks of sharding.init_from_env) writes the same TSV as the plain single-process CLI, for both sharding modes: three

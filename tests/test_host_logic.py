@@ -159,3 +159,35 @@ def test_read_bias_on_the_reference_bundled_krnorm(tmp_path, golden_dir):
     assert int(np.isinf(got).sum()) == 2817 + 185
     assert d[1e9] == 1.0                                      # bins the file does not list default to 1
     assert len(read_bias(str(path), "20", res)) == int(g["other_chrom_entries"]) == 0
+
+
+@pytest.mark.parametrize("quantum", [0.05, 0.01])
+def test_cluster_representative_with_tied_q_values(golden_dir, quantum):
+    """BH maps runs of records to one q-value, and the reference takes the FIRST arg-min of q over a cluster's pixels in raster
+    order (mustache.py:843-848).  Stress that rule: the found p-values of a fixture block are quantised so that most clusters
+    hold several pixels with exactly equal q; the product's host tail must still pick the same representatives as the oracle's
+    restatement of the reference's tail."""
+    import oracle
+    from mustache_amd.levels import LevelTable
+    from mustache_amd.tail import block_tail
+    g = np.load(os.path.join(golden_dir, "block_512.npz"), allow_pickle=True)
+    n, dpx = int(g["n"]), int(g["dpx"])
+    c = np.zeros((n, n))
+    c[g["x"], g["y"]] = g["v"]
+    nz = oracle.block_prologue(c, dpx)
+    ss = oracle.scale_space_levels(c, nz, OCT)
+    fm = ss.pval != 2
+    pq = ss.pval.copy()
+    pq[fm] = np.minimum(1.0, np.ceil(ss.pval[fm] / quantum) * quantum * 0.1)      # few distinct values, small enough to be selected
+    exp = oracle.block_tail(c, nz, pq, ss.scale, int(g["start"]), 0.5, 0.5)
+    found = dict(pixel=np.flatnonzero(nz.ravel())[fm].astype(np.uint32), level=ss.level[fm].astype(np.uint32),
+                 value=ss.best[fm], pval=pq[fm])
+    got = block_tail(_FakeBatch(c, nz, found, LevelTable(OCT)), 0, int(g["start"]), 0.5, 0.5)
+    ga = np.array([[float(a), float(b), q, s] for a, b, q, s in got]).reshape(-1, 4)
+    ea = np.array([[float(a), float(b), q, s] for a, b, q, s in exp]).reshape(-1, 4)
+    assert len(ea) > 20 and np.array_equal(ga, ea)
+    # the stress is real: many selected records share their q-value with another one
+    from mustache_amd.tail import benjamini_hochberg
+    q = benjamini_hochberg(found["pval"])
+    sel = q[q < 0.5]
+    assert len(sel) - len(np.unique(sel)) > len(sel) // 2

@@ -415,19 +415,11 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
             const double dl = de_left[0], dr = de_right[0];
             double hm[K];
 #pragma unroll
-#ifdef MST_EXP_OLDMAX
-            for (int k = 0; k < K; ++k) {
-                const double a = k == 0 ? dl : d[k - 1];
-                const double bb = k == K - 1 ? dr : d[k + 1];
-                hm[k] = dmax(dmax(a, d[k]), bb);
-            }
-#else
             for (int j = 0; j < K / 2; ++j) {      // max(d[2j], d[2j+1]) serves both of its pixels: 12 v_max_f64, not 16
                 const double pj = dmax(d[2 * j], d[2 * j + 1]);
                 hm[2 * j] = dmax(j == 0 ? dl : d[2 * j - 1], pj);
                 hm[2 * j + 1] = dmax(pj, 2 * j + 2 == K ? dr : d[2 * j + 2]);
             }
-#endif
             uint32_t en = 0, gn = 0;   // en: D_new == M_new;  gn: D_new > M_prev (M of the level before it)
             double m[K];
 #pragma unroll

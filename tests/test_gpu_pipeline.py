@@ -512,3 +512,57 @@ def test_repeated_pixels_last_entry_wins():
         warnings.simplefilter("error")                            # no repeats -> no warning, no host pass
         band = band_from_host_coo(x, y, v, n, dpx, "cuda").cpu().numpy()
     assert np.count_nonzero(band) == np.count_nonzero((y - x) <= dpx + 1)
+
+
+@pytest.mark.gpu
+def test_bh_select_on_crafted_pvalue_distributions():
+    """mst_bh_select on synthetic p-value sets per block, against the NumPy BH restatement over ALL records followed by
+    q < pt: empty block, single record, all-significant, none-significant, heavy ties, zeros, ones, values below the
+    histogram's lowest edge (2^-40), a subset just under / over the LDS sort capacity (8192: the radix-sort route), and the
+    thresholds 0.05 / 0.1 / 0.5 / 1.0.  Pixels, levels and q-values must be identical bit for bit."""
+    import torch
+    from mustache_amd.engine import ScaleSpaceEngine
+    from mustache_amd.tail import benjamini_hochberg
+    eng = ScaleSpaceEngine(OCT)
+    rng = np.random.default_rng(5)
+    cap = 40000
+
+    def uniform(m):
+        return rng.random(m)
+
+    def mixture(m, k, scale):          # k strong signals among m nulls
+        p = rng.random(m)
+        p[:k] = rng.random(k) * scale
+        return rng.permutation(p)
+
+    blocks = [
+        np.zeros(0), np.array([0.03]), np.array([0.7]), uniform(30000), mixture(30000, 60, 1e-6), mixture(25000, 900, 1e-4),
+        mixture(38000, 8100, 1e-3), mixture(38000, 8300, 1e-3), mixture(39000, 20000, 1e-2),
+        np.round(uniform(20000), 2), np.where(uniform(5000) < 0.3, 0.0, 1.0), mixture(20000, 300, 2.0 ** -60),
+        np.full(1000, 0.01), np.concatenate([np.full(500, 1e-5), uniform(9000)]), uniform(200) * 1e-3,
+    ]
+    B = len(blocks)
+    found = torch.zeros((B, cap, 2), dtype=torch.int64, device=eng.device)
+    pval = torch.full((B, cap), 2.0, dtype=torch.float64, device=eng.device)
+    count = torch.tensor([len(p) for p in blocks], dtype=torch.int32, device=eng.device)
+    fit = torch.zeros((B, 64, 2), dtype=torch.float64, device=eng.device)
+    pix, lvl = [], []
+    for b, p in enumerate(blocks):
+        m = len(p)
+        px = rng.permutation(4000 * 4000)[:m].astype(np.int64)
+        lv = rng.integers(1, 19, m).astype(np.int64)
+        pix.append(px)
+        lvl.append(lv)
+        if m:
+            found[b, :m, 0] = torch.from_numpy(px | (lv << 32)).to(eng.device)
+            pval[b, :m] = torch.from_numpy(p).to(eng.device)
+    for pt in (0.05, 0.1, 0.5, 1.0):
+        eng._select_cap = 4096
+        sel, _ = eng._download_selected(found, pval, count, fit, eng.levels.n_tested, cap, pt)
+        for b, p in enumerate(blocks):
+            q = benjamini_hochberg(p) if len(p) else np.zeros(0)
+            keep = q < pt
+            order = np.argsort(pix[b][keep], kind="stable")
+            assert np.array_equal(sel[b]["pixel"].astype(np.int64), pix[b][keep][order]), (pt, b)
+            assert np.array_equal(sel[b]["level"].astype(np.int64), lvl[b][keep][order]), (pt, b)
+            assert np.array_equal(sel[b]["q"], q[keep][order]), (pt, b)

@@ -179,69 +179,6 @@ __device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const do
 #undef MST_LD
 }
 
-// Two levels at once (axis 0 only).  The pair sums  s = x[c-j] + x[c+j]  of the axis-0 pass depend on the image alone, not
-// on the level: consecutive levels A, B with radii RA <= RB share them for the taps j <= RA, and share every window load.
-// Per output and level the operation sequence is still SciPy's (t = x[c] w0, then j = R..1: t += s_j w_j), so both results
-// are bit-identical to two separate passes; the FP64 work drops from 3 (RA + RB) + 2 to 3 RB + 2 RA + 2 operations per sample.
-template <int KC, int RA, int RB, int OFF, bool FMA>
-__device__ __forceinline__ void fir_chunk2(const double *__restrict__ p, const double (&wa)[RA + 1], const double (&wb)[RB + 1],
-                                           double (&ta)[KC], double (&tb)[KC]) {
-    static_assert(RA <= RB, "level A has the smaller radius");
-    constexpr int R = RB;
-    constexpr int NP = (KC + 2 * R + OFF + 1) / 2;
-    constexpr int QC0 = (R + OFF) >> 1, QC1 = (R + KC - 1 + OFF) >> 1;
-    const double2 *p2 = reinterpret_cast<const double2 *>(p);
-    double x[2 * NP];
-#define MST_LD(q_)                     \
-    {                                  \
-        const double2 v_ = p2[q_];     \
-        x[2 * (q_)] = v_.x;            \
-        x[2 * (q_) + 1] = v_.y;        \
-    }
-#pragma unroll
-    for (int q = QC0; q <= QC1; ++q) MST_LD(q)
-    int lq_hi = -1, rq_lo = NP;
-#pragma unroll
-    for (int k = 0; k < KC; ++k) tb[k] = x[R + k + OFF] * wb[0];
-#pragma unroll
-    for (int k = 0; k < KC; ++k) ta[k] = x[R + k + OFF] * wa[0];
-#pragma unroll
-    for (int j = R; j >= 1; --j) {
-        const int lq1 = (R - j + KC - 1 + OFF) >> 1, rq0 = (R + j + OFF) >> 1;
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            if (q > lq_hi && q <= lq1 && q < QC0) MST_LD(q)
-            if (q < rq_lo && q >= rq0 && q > QC1) MST_LD(q)
-        }
-        lq_hi = lq1 > lq_hi ? lq1 : lq_hi;
-        rq_lo = rq0 < rq_lo ? rq0 : rq_lo;
-        double s[KC];
-#pragma unroll
-        for (int k = 0; k < KC; ++k) s[k] = x[R + k - j + OFF] + x[R + k + j + OFF];
-        if constexpr (FMA) {
-#pragma unroll
-            for (int k = 0; k < KC; ++k) tb[k] = __builtin_fma(s[k], wb[j], tb[k]);
-            if (j <= RA) {
-#pragma unroll
-                for (int k = 0; k < KC; ++k) ta[k] = __builtin_fma(s[k], wa[j], ta[k]);
-            }
-        } else {
-            double u[KC];
-#pragma unroll
-            for (int k = 0; k < KC; ++k) u[k] = s[k] * wb[j];
-#pragma unroll
-            for (int k = 0; k < KC; ++k) tb[k] = tb[k] + u[k];
-            if (j <= RA) {
-#pragma unroll
-                for (int k = 0; k < KC; ++k) u[k] = s[k] * wa[j];
-#pragma unroll
-                for (int k = 0; k < KC; ++k) ta[k] = ta[k] + u[k];
-            }
-        }
-    }
-#undef MST_LD
-}
-
 // Axis-0 pass for radius R over the (RGR rows) x (RGC + 2R columns) strip the axis-1 pass will need.  The c tile is
 // stored transposed (ct[col][row]), so a thread's window of consecutive rows is contiguous in LDS.
 // Work split: the first NT items are (8-row group, column) pairs over the first NT*8/RGR columns -- exactly one per

@@ -152,10 +152,6 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
 
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-#ifdef MST_EXP_PRIO
-    // the two waves that share a SIMD get different static priorities (hardware wave slot parity, HW_REG_HW_ID[3:0])
-    if (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) __builtin_amdgcn_s_setprio(MST_EXP_PRIO);
-#endif
     // XCD-aware order: hardware places workgroup i on XCD i % 8 (gridDim.x is a multiple of 8), so give each XCD a
     // contiguous run of slots -- neighbouring tiles share their halo through that XCD's L2.  A slot is a tile, or, when
     // the host passes the list of tiles that can reach the tested band (skip_empty on the band source), an entry of

@@ -131,7 +131,7 @@ int mst_bh_fdr(const double *pval, const uint32_t *count, int32_t B, uint32_t ca
  * subset is sorted: the selected records are the BH ranks 1..j*, all below p = threshold * j* / m, and a histogram of the
  * p-values bounds j* from above (fixed point of J -> #{p < threshold * J / m}) -- typically a few hundred of ~150 000
  * records, sorted by one workgroup in LDS; the suffix minimum over the rest is >= threshold, and the global test count
- * m = found_count[b] enters every division.  A block whose subset exceeds 8192 records (threshold near 1) goes through the
+ * m = found_count[b] enters every division.  A block whose subset exceeds 4096 records (threshold near 1) goes through the
  * segmented radix sort instead, same results.  Synchronises `stream` once (the subset sizes choose the route).  Outputs as
  * mst_select_below; workspace from mst_bh_workspace_bytes(B, found_cap).  (mustache.py:778-797) */
 int mst_bh_select(const mst_found *found, const double *pval, const uint32_t *found_count, int32_t B, uint32_t found_cap,

@@ -262,18 +262,22 @@ bh_threshold_kernel(uint32_t *__restrict__ hist, const uint32_t *__restrict__ co
 }
 
 // One workgroup sorts a block's subset in LDS (bitonic network on (p pattern, record index) -- a total order, so the result
-// does not depend on the order the compaction happened to append in) and applies BH with the global m.
-constexpr int kSortMax = 8192;
+// does not depend on the order the compaction happened to append in) and applies BH with the global m.  The LDS request is
+// sized to the largest subset of the call (p_max = next power of two), normally 12-20 KB: in the pipeline this kernel runs
+// while the NEXT group's fused kernel fills every CU with 2 x 77 KB, and a workgroup that needs more than the 83 KB one
+// retiring fused workgroup frees is never placed until that kernel has drained (measured: a fixed 104 KB request cost the
+// chromosome run its copy/compute overlap, 76 -> 92 ms).
+constexpr int kSortMax = 4096;
 
 __global__ void __launch_bounds__(kBH)
 bh_select_lds_kernel(const double *__restrict__ keys, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ k_sub,
                      const uint32_t *__restrict__ count, uint32_t cap, const mst_found *__restrict__ found, double threshold,
                      uint32_t out_cap, uint32_t *__restrict__ out_pixel, uint32_t *__restrict__ out_level,
-                     double *__restrict__ out_q, uint32_t *__restrict__ out_count) {
+                     double *__restrict__ out_q, uint32_t *__restrict__ out_count, uint32_t p_max) {
     extern __shared__ unsigned long long lds_sort[];
-    unsigned long long *sk = lds_sort;                                      // [P] p patterns
-    uint32_t *si = reinterpret_cast<uint32_t *>(lds_sort + kSortMax);       // [P] record indices
-    double *chunk_min = reinterpret_cast<double *>(si + kSortMax);          // [kBH]
+    unsigned long long *sk = lds_sort;                                      // [p_max] p patterns
+    double *chunk_min = reinterpret_cast<double *>(lds_sort + p_max);       // [kBH]
+    uint32_t *si = reinterpret_cast<uint32_t *>(chunk_min + kBH);           // [p_max] record indices
     __shared__ uint32_t n_out;
     const int b = blockIdx.x, t = threadIdx.x;
     const uint32_t m = count[b] < cap ? count[b] : cap;
@@ -342,7 +346,9 @@ bh_select_lds_kernel(const double *__restrict__ keys, const uint32_t *__restrict
     if (t == 0) out_count[b] = n_out;
 }
 
-constexpr size_t kSortLdsBytes = (size_t)kSortMax * (sizeof(unsigned long long) + sizeof(uint32_t)) + kBH * sizeof(double);
+constexpr size_t sort_lds_bytes(uint32_t p_max) {
+    return (size_t)p_max * (sizeof(unsigned long long) + sizeof(uint32_t)) + kBH * sizeof(double);
+}
 
 }  // namespace
 
@@ -393,10 +399,11 @@ extern "C" int mst_bh_select(const mst_found *found, const double *pval, const u
     uint32_t k_max = 0;
     for (uint32_t k : k_host) k_max = k > k_max ? k : k_max;
     if (k_max <= (uint32_t)kSortMax) {
-        static unsigned long long attr_done = 0;
-        MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&bh_select_lds_kernel), (int)kSortLdsBytes, &attr_done));
-        bh_select_lds_kernel<<<B, kBH, kSortLdsBytes, s>>>(keys_in, idx_in, k_sub, count, cap, found, threshold, out_cap,
-                                                          out_pixel, out_level, out_q, out_count);
+        uint32_t p_max = 2;
+        while (p_max < k_max) p_max <<= 1;
+        static_assert(sort_lds_bytes(kSortMax) <= 64 * 1024, "stays under the default dynamic LDS limit");
+        bh_select_lds_kernel<<<B, kBH, sort_lds_bytes(p_max), s>>>(keys_in, idx_in, k_sub, count, cap, found, threshold,
+                                                                  out_cap, out_pixel, out_level, out_q, out_count, p_max);
         MST_LAUNCH_CHECK();
         return MST_OK;
     }

@@ -518,7 +518,7 @@ def test_repeated_pixels_last_entry_wins():
 def test_bh_select_on_crafted_pvalue_distributions():
     """mst_bh_select on synthetic p-value sets per block, against the NumPy BH restatement over ALL records followed by
     q < pt: empty block, single record, all-significant, none-significant, heavy ties, zeros, ones, values below the
-    histogram's lowest edge (2^-40), a subset just under / over the LDS sort capacity (8192: the radix-sort route), and the
+    histogram's lowest edge (2^-40), a subset just under / over the LDS sort capacity (4096: the radix-sort route), and the
     thresholds 0.05 / 0.1 / 0.5 / 1.0.  Pixels, levels and q-values must be identical bit for bit."""
     import torch
     from mustache_amd.engine import ScaleSpaceEngine
@@ -537,7 +537,7 @@ def test_bh_select_on_crafted_pvalue_distributions():
 
     blocks = [
         np.zeros(0), np.array([0.03]), np.array([0.7]), uniform(30000), mixture(30000, 60, 1e-6), mixture(25000, 900, 1e-4),
-        mixture(38000, 8100, 1e-3), mixture(38000, 8300, 1e-3), mixture(39000, 20000, 1e-2),
+        mixture(38000, 4000, 1e-3), mixture(38000, 4200, 1e-3), mixture(38000, 8300, 1e-3), mixture(39000, 20000, 1e-2),
         np.round(uniform(20000), 2), np.where(uniform(5000) < 0.3, 0.0, 1.0), mixture(20000, 300, 2.0 ** -60),
         np.full(1000, 0.01), np.concatenate([np.full(500, 1e-5), uniform(9000)]), uniform(200) * 1e-3,
     ]

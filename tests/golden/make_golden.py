@@ -29,7 +29,7 @@ def subsample(a):
     return f[::97].copy()
 
 
-def run_mustache_traced(ref, c, start, dpx, st, pt):
+def run_mustache_traced(ref, c, start, dpx, st, pt, octaves=None):
     """Call ref.mustache and capture SciPy-call arguments/results and the function's final locals."""
     import scipy.stats
     cap = dict(gauss=[], maxf=[], fit=[], bh=[])
@@ -73,7 +73,7 @@ def run_mustache_traced(ref, c, start, dpx, st, pt):
     ref.expon.fit = fit
     sys.settrace(tracer)
     try:
-        loops = ref.mustache(c, "1", "1", 5000, [], start, start + c.shape[0], 0, dpx, OCTAVES, st, pt)
+        loops = ref.mustache(c, "1", "1", 5000, [], start, start + c.shape[0], 0, dpx, octaves or OCTAVES, st, pt)
     finally:
         sys.settrace(None)
         ref.gaussian_filter, ref.maximum_filter, ref.multipletests = g0, m0, bh0
@@ -150,14 +150,15 @@ def make_block(ref, name, n, dpx, seed, start, st, pt, depth=300.0, nloops=None,
           "pzero", int((locs["pAll"] == 0).sum()) if "pAll" in locs else None)
 
 
-def make_big_block(ref, name="block_2000", n=2000, dpx=400, seed=3, start=3200, st=0.8, pt=0.1):
+def make_big_block(ref, name="block_2000", n=2000, dpx=400, seed=3, start=3200, st=0.8, pt=0.1, octaves=None):
     """One block of BASELINE's 5 kb geometry (2000 x 2000, distance limit 400 px) -- or, as `block_4000`, of the headline
     1 kb geometry (4000 x 4000, distance limit 2000 px; the reference needs ~80 s and ~3 GB for it).  The input is the raw
     synthetic map (regenerated from the seed by the tests, so only its checksum is stored) and the outputs are kept
-    compact: loops, the 18 expon fits, per-level Gaussian sums, and order-independent checksums of the found set."""
+    compact: loops, the 18 expon fits, per-level Gaussian sums, and order-independent checksums of the found set.
+    `octaves`: the list the reference's main() builds from -sz / -oc (mustache.py:874): sigma0 * 2^i, i < octaves."""
     x, y, v = synth_coo(n, dpx, depth=300.0, seed=seed)
     c = dense(x, y, v, n)
-    loops, cap, locs = run_mustache_traced(ref, c, start, dpx, st, pt)
+    loops, cap, locs = run_mustache_traced(ref, c, start, dpx, st, pt, octaves)
     nz = locs["nz"]
     found = locs["pAll"] != 2
     pix = np.flatnonzero(nz.ravel())[found].astype(np.int64)
@@ -165,6 +166,7 @@ def make_big_block(ref, name="block_2000", n=2000, dpx=400, seed=3, start=3200, 
     np.savez_compressed(os.path.join(HERE, name + ".npz"), n=n, dpx=dpx, seed=seed, depth=300.0, start=start, st=st,
                         pt=pt, in_nnz=len(v), in_checksum=float(v.sum()), nz_count=int(nz.sum()),
                         loops=loops_array(loops), fit=np.array(cap["fit"]).reshape(-1, 3),
+                        octaves=np.array(octaves or OCTAVES, dtype=np.float64), g_sigma=np.array([g[0] for g in cap["gauss"]]),
                         g_sum=np.array([g[2] for g in cap["gauss"]]), found_count=int(found.sum()),
                         found_pixel_sum=int(pix.sum()), found_pixel_xor=int(np.bitwise_xor.reduce(pix)),
                         found_sigma_sum=float(np.sum(sig)), found_value_sum=float(np.sum(locs["vAll"][found])),
@@ -438,6 +440,9 @@ if __name__ == "__main__":
         make_big_block(ref)
     if "big4000" in which:          # BASELINE config 4's block geometry (not in the default list: ~2 min, ~3 GB)
         make_big_block(ref, "block_4000", n=4000, dpx=2000, seed=4, start=8000, st=0.8, pt=0.1)
+    if "octaves" in which:          # -sz / -oc variants (not in the default list): 3 octaves, and sigma0 = 2.0
+        make_big_block(ref, "block_700_oc3", n=700, dpx=160, seed=21, start=1400, st=0.7, pt=0.2, octaves=[1.6, 3.2, 6.4])
+        make_big_block(ref, "block_640_sz2", n=640, dpx=150, seed=22, start=0, st=0.7, pt=0.2, octaves=[2.0, 4.0])
     if "edges" in which:
         make_edges(ref)
     if "tiling" in which:

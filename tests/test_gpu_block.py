@@ -206,3 +206,34 @@ def test_baseline_size_block_vs_reference_fixture(eng, golden_dir, name):
     assert got.shape == exp.shape and len(exp) > 100
     assert np.array_equal(got[:, :2], exp[:, :2]) and np.array_equal(got[:, 3], exp[:, 3])
     np.testing.assert_allclose(got[:, 2], exp[:, 2], rtol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["block_700_oc3.npz", "block_640_sz2.npz"])
+def test_sigma_zero_and_octave_variants_vs_reference_fixture(golden_dir, name):
+    """-sz / -oc (mustache.py:874: octave_values = sigma0 * 2^i) against outputs of the REFERENCE ITSELF: three octaves
+    (1.6, 3.2, 6.4 -- radii up to 28: the wide-halo tile, 27 tested levels) and sigma0 = 2.0 (2.0, 4.0).  Found set, expon
+    fits and final loops as in the BASELINE-size test; dense-block and band-direct source, with and without tile skipping."""
+    import torch
+    from mustache_amd.engine import ScaleSpaceEngine
+    from mustache_amd.mustache import mustache
+    from mustache_amd.normalize import band_from_coo
+    g = _load(golden_dir, name)
+    octs = [float(o) for o in g["octaves"]]
+    eng = ScaleSpaceEngine(octs)
+    assert eng.levels.n_tested == len(g["fit"])
+    c, n, dpx = _big_block(g)
+    for skip_empty in (True, False):
+        dev, nz_d, nzc, found, fit = _run_block(eng, c.copy(), dpx, skip_empty)
+        _check_found_set(eng, g, nzc, found, fit)
+    x, y = np.nonzero(c)
+    band = band_from_coo(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(c[x, y]).cuda(), n, dpx)
+    for skip_empty in (True, False):
+        found, fits, nzc = eng.sigma_loop_band(band, n, dpx, [0], n, skip_empty=skip_empty)
+        _check_found_set(eng, g, int(nzc.cpu().numpy().view(np.uint32)[0]), found[0], fits[0])
+    start = int(g["start"])
+    loops = mustache(c, "1", "1", 5000, [], start, start + n, 0, dpx, octs, float(g["st"]), float(g["pt"]))
+    exp = g["loops"]
+    got = np.array([[float(a), float(b), q, s] for a, b, q, s in loops])
+    assert got.shape == exp.shape and len(exp) > 10
+    assert np.array_equal(got[:, :2], exp[:, :2]) and np.array_equal(got[:, 3], exp[:, 3])
+    np.testing.assert_allclose(got[:, 2], exp[:, 2], rtol=1e-9)

@@ -171,12 +171,15 @@ def test_diff_block_vs_reference(golden_dir):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("name", ["block_2000.npz", "block_4000.npz"])
+@pytest.mark.parametrize("name", ["block_2000.npz", "block_4000.npz", "block_700_oc3.npz", "block_640_sz2.npz"])
 def test_baseline_size_block_vs_reference(golden_dir, name):
     """The oracle on BASELINE's block geometries (5 kb: 2000 x 2000, dpx 400; 1 kb headline: 4000 x 4000, dpx 2000) against
-    the reference's own outputs (block_2000.npz / block_4000.npz): fits, found-set checksums, loops -- bit for bit."""
+    the reference's own outputs (block_2000.npz / block_4000.npz): fits, found-set checksums, loops -- bit for bit.  The two
+    small fixtures pin the -sz / -oc variants on the reference: three octaves (1.6, 3.2, 6.4: radii up to 28, 27 tested
+    levels) and sigma0 = 2.0 (octaves 2.0, 4.0: radii 4-18)."""
     from mustache_amd.synth import synth_coo
     g = _load(golden_dir, name)
+    OCT = [float(o) for o in g["octaves"]] if "octaves" in g.files else [1.6, 3.2]
     n, dpx = int(g["n"]), int(g["dpx"])
     x, y, v = synth_coo(n, dpx, depth=float(g["depth"]), seed=int(g["seed"]))
     assert len(v) == int(g["in_nnz"]) and v.sum() == float(g["in_checksum"])

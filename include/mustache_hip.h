@@ -137,6 +137,12 @@ int mst_bh_fdr(const double *pval, const uint32_t *count, int32_t B, uint32_t ca
 int mst_bh_select(const mst_found *found, const double *pval, const uint32_t *found_count, int32_t B, uint32_t found_cap,
                   double threshold, uint32_t out_cap, uint32_t *out_pixel, uint32_t *out_level, double *out_q,
                   uint32_t *out_count, void *workspace, uint64_t workspace_bytes, void *stream);
+/* The same, and also the selected records' positions in their block's found list (out_index: dev [B][out_cap] u32), so that
+ * further per-record arrays (the pair p-values of the two-sample path) can be gathered for the selected records only. */
+int mst_bh_select_records(const mst_found *found, const double *pval, const uint32_t *found_count, int32_t B,
+                          uint32_t found_cap, double threshold, uint32_t out_cap, uint32_t *out_pixel, uint32_t *out_level,
+                          double *out_q, uint32_t *out_index, uint32_t *out_count, void *workspace,
+                          uint64_t workspace_bytes, void *stream);
 
 /* mustache.py:789-797 (selection of the pixels with o < pt) on the device: the found records of each block whose q-value
  * is below `threshold`, compacted into out_pixel / out_level / out_q [B][out_cap] (order within a block unspecified).
@@ -262,6 +268,14 @@ int mst_diff_dog_band(const double *band1, const double *band2, int64_t n, int32
 int mst_pair_pvalues_dog(const mst_found *found, uint32_t found_cap, const uint32_t *found_count, const double *dog,
                          const double *fit, int32_t B, int32_t CH, int32_t n_octaves, int32_t tested_per_octave,
                          int32_t sample_offset, double *ppair, void *stream);
+/* The differential test's inputs for the SELECTED records only (diff_mustache.py:450-453, :567-568): for record `slot` of
+ * block fb (2P blocks: sample 1 = [0, P), sample 2 = [P, 2P); sel_* = the outputs of mst_bh_select_records):
+ * out_pair = ppair of the record, out_value = its winning DoG value, out_other = the partner block's (fb +- P) winning value
+ * at the same pixel, NaN if the partner did not find that pixel.  out_*: dev [2P][out_cap] f64; max_selected = the largest
+ * sel_count (host value: the grid's width). */
+int mst_pair_gather(const mst_found *found, uint32_t found_cap, const uint32_t *found_count, const double *ppair, int32_t P,
+                    const uint32_t *sel_index, const uint32_t *sel_pixel, const uint32_t *sel_count, uint32_t out_cap,
+                    uint32_t max_selected, double *out_pair, double *out_value, double *out_other, void *stream);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "mst_bh_workspace_bytes": (_u64, [_i32, _u32]),
     "mst_bh_fdr": (ctypes.c_int, [_p, _p, _i32, _u32, _p, _p, _u64, _p]),
     "mst_bh_select": (ctypes.c_int, [_p, _p, _p, _i32, _u32, ctypes.c_double, _u32, _p, _p, _p, _p, _p, _u64, _p]),
+    "mst_bh_select_records": (ctypes.c_int, [_p, _p, _p, _i32, _u32, ctypes.c_double, _u32, _p, _p, _p, _p, _p, _p, _u64, _p]),
     "mst_select_below": (ctypes.c_int, [_p, _p, _p, _i32, _u32, ctypes.c_double, _u32, _p, _p, _p, _p, _p]),
     "mst_candidate_features": (ctypes.c_int, [_p, _p, _i32, _i32, _p, _p, _i32, _p, _p, _p, _p]),
     "mst_gather_diagonals": (ctypes.c_int, [_p, _i32, _i32, _p, _i32, _p, _p]),
@@ -75,6 +76,7 @@ _SIGNATURES = {
     "mst_diff_dog_band": (ctypes.c_int, [_p, _p, _i64, _i32, ctypes.POINTER(_i64), _i32, _i32, ctypes.POINTER(MstLevels),
                                          _p, _p, _p, _p, _u64, _p]),
     "mst_pair_pvalues_dog": (ctypes.c_int, [_p, _u32, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    "mst_pair_gather": (ctypes.c_int, [_p, _u32, _p, _p, _i32, _p, _p, _p, _u32, _u32, _p, _p, _p, _p]),
     "mst_pair_pvalues": (ctypes.c_int, [_p, _u32, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
 }
 

@@ -476,7 +476,53 @@ extern "C" int mst_pair_pvalues_dog(const mst_found *found, uint32_t found_cap, 
 }
 
 namespace {
+
+// The differential test of diff_mustache.py:567-568 needs, for a selected record of one sample, its pair p-value, its own
+// winning DoG value and the OTHER sample's value at the same pixel (v = ones; v[nz] = vAll: the other sample's winning value
+// if it found that pixel, else 0 on a tested pixel / 1 elsewhere -- the caller resolves "not found" with the nz mask).  One
+// workgroup per selected record scans the partner block's found list (pixels are unique): a few dozen records per block
+// against ~20 000, instead of sorting and downloading both found sets.
+__global__ void __launch_bounds__(kThreads)
+pair_gather_kernel(const mst_found *__restrict__ found, uint32_t found_cap, const uint32_t *__restrict__ found_count,
+                   const double *__restrict__ ppair, int P, const uint32_t *__restrict__ sel_index,
+                   const uint32_t *__restrict__ sel_pixel, const uint32_t *__restrict__ sel_count, uint32_t out_cap,
+                   double *__restrict__ out_pair, double *__restrict__ out_value, double *__restrict__ out_other) {
+    __shared__ double hit;
+    const int fb = blockIdx.y, slot = blockIdx.x;
+    const uint32_t nsel = sel_count[fb] < out_cap ? sel_count[fb] : out_cap;
+    if ((uint32_t)slot >= nsel) return;
+    const size_t o = (size_t)fb * out_cap + slot;
+    const uint32_t idx = sel_index[o], pixel = sel_pixel[o];
+    if (threadIdx.x == 0) hit = __longlong_as_double(0x7FF8000000000000ll);     // NaN = the partner did not find this pixel
+    __syncthreads();
+    const int pb = fb < P ? fb + P : fb - P;
+    const uint32_t np = found_count[pb] < found_cap ? found_count[pb] : found_cap;
+    const mst_found *pf = found + (size_t)pb * found_cap;
+    for (uint32_t i = threadIdx.x; i < np; i += kThreads)
+        if (pf[i].pixel == pixel) hit = pf[i].value;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out_pair[o] = ppair[(size_t)fb * found_cap + idx];
+        out_value[o] = found[(size_t)fb * found_cap + idx].value;
+        out_other[o] = hit;
+    }
+}
+
 }  // namespace
+
+extern "C" int mst_pair_gather(const mst_found *found, uint32_t found_cap, const uint32_t *found_count, const double *ppair,
+                               int32_t P, const uint32_t *sel_index, const uint32_t *sel_pixel, const uint32_t *sel_count,
+                               uint32_t out_cap, uint32_t max_selected, double *out_pair, double *out_value,
+                               double *out_other, void *stream) {
+    if (!found || !found_count || !ppair || !sel_index || !sel_pixel || !sel_count || !out_pair || !out_value ||
+        !out_other || P <= 0 || 2 * P > 65535 || found_cap == 0 || out_cap == 0 || max_selected > out_cap)
+        return mst::fail(MST_E_ARG, "mst_pair_gather: bad argument");
+    if (max_selected == 0) return MST_OK;
+    pair_gather_kernel<<<dim3(max_selected, 2 * P), kThreads, 0, mst::as_stream(stream)>>>(
+        found, found_cap, found_count, ppair, P, sel_index, sel_pixel, sel_count, out_cap, out_pair, out_value, out_other);
+    MST_LAUNCH_CHECK();
+    return MST_OK;
+}
 
 extern "C" int mst_diff_image(const double *c1, const double *c2, const uint8_t *nz1, const uint8_t *nz2, int32_t B,
                               int32_t CH, double *cd, uint8_t *nzb, uint32_t *nzb_count, void *stream) {

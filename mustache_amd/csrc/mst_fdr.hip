@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(kBH)
 bh_select_kernel(const double *__restrict__ ps, const uint32_t *__restrict__ idx_sorted, const uint32_t *__restrict__ k_sub,
                  const uint32_t *__restrict__ count, uint32_t cap, const mst_found *__restrict__ found, double threshold,
                  uint32_t out_cap, uint32_t *__restrict__ out_pixel, uint32_t *__restrict__ out_level,
-                 double *__restrict__ out_q, uint32_t *__restrict__ out_count) {
+                 double *__restrict__ out_q, uint32_t *__restrict__ out_count, uint32_t *__restrict__ out_index) {
     __shared__ double chunk_min[kBH];
     __shared__ uint32_t n_out;
     const int b = blockIdx.x, t = threadIdx.x;
@@ -191,6 +191,7 @@ bh_select_kernel(const double *__restrict__ ps, const uint32_t *__restrict__ idx
                 out_pixel[(size_t)b * out_cap + slot] = r.pixel;
                 out_level[(size_t)b * out_cap + slot] = r.level;
                 out_q[(size_t)b * out_cap + slot] = q;
+                if (out_index) out_index[(size_t)b * out_cap + slot] = id[i - 1];
             }
         }
     }
@@ -273,7 +274,8 @@ __global__ void __launch_bounds__(kBH)
 bh_select_lds_kernel(const double *__restrict__ keys, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ k_sub,
                      const uint32_t *__restrict__ count, uint32_t cap, const mst_found *__restrict__ found, double threshold,
                      uint32_t out_cap, uint32_t *__restrict__ out_pixel, uint32_t *__restrict__ out_level,
-                     double *__restrict__ out_q, uint32_t *__restrict__ out_count, uint32_t p_max) {
+                     double *__restrict__ out_q, uint32_t *__restrict__ out_count, uint32_t *__restrict__ out_index,
+                     uint32_t p_max) {
     extern __shared__ unsigned long long lds_sort[];
     unsigned long long *sk = lds_sort;                                      // [p_max] p patterns
     double *chunk_min = reinterpret_cast<double *>(lds_sort + p_max);       // [kBH]
@@ -339,6 +341,7 @@ bh_select_lds_kernel(const double *__restrict__ keys, const uint32_t *__restrict
                 out_pixel[(size_t)b * out_cap + slot] = r.pixel;
                 out_level[(size_t)b * out_cap + slot] = r.level;
                 out_q[(size_t)b * out_cap + slot] = q;
+                if (out_index) out_index[(size_t)b * out_cap + slot] = si[i - 1];
             }
         }
     }
@@ -352,9 +355,10 @@ constexpr size_t sort_lds_bytes(uint32_t p_max) {
 
 }  // namespace
 
-extern "C" int mst_bh_select(const mst_found *found, const double *pval, const uint32_t *count, int32_t B, uint32_t cap,
-                             double threshold, uint32_t out_cap, uint32_t *out_pixel, uint32_t *out_level, double *out_q,
-                             uint32_t *out_count, void *workspace, uint64_t workspace_bytes, void *stream) {
+namespace {
+int bh_select_impl(const mst_found *found, const double *pval, const uint32_t *count, int32_t B, uint32_t cap,
+                   double threshold, uint32_t out_cap, uint32_t *out_pixel, uint32_t *out_level, double *out_q,
+                   uint32_t *out_count, uint32_t *out_index, void *workspace, uint64_t workspace_bytes, void *stream) {
     if (!found || !pval || !count || !out_pixel || !out_level || !out_q || !out_count || !workspace || B <= 0 ||
         B > 65535 || cap == 0 || out_cap == 0 || (size_t)B * cap > 0x7FFFFFFFull)
         return mst::fail(MST_E_ARG, "mst_bh_select: bad argument (B * cap must fit in int32)");
@@ -403,7 +407,8 @@ extern "C" int mst_bh_select(const mst_found *found, const double *pval, const u
         while (p_max < k_max) p_max <<= 1;
         static_assert(sort_lds_bytes(kSortMax) <= 64 * 1024, "stays under the default dynamic LDS limit");
         bh_select_lds_kernel<<<B, kBH, sort_lds_bytes(p_max), s>>>(keys_in, idx_in, k_sub, count, cap, found, threshold,
-                                                                  out_cap, out_pixel, out_level, out_q, out_count, p_max);
+                                                                  out_cap, out_pixel, out_level, out_q, out_count, out_index,
+                                                                  p_max);
         MST_LAUNCH_CHECK();
         return MST_OK;
     }
@@ -412,9 +417,26 @@ extern "C" int mst_bh_select(const mst_found *found, const double *pval, const u
     MST_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(w, temp, keys_in, keys_out, idx_in, idx_out, (int)n, B, seg_begin,
                                                         seg_end, 0, 64, s));
     bh_select_kernel<<<B, kBH, 0, s>>>(keys_out, idx_out, k_sub, count, cap, found, threshold, out_cap, out_pixel,
-                                       out_level, out_q, out_count);
+                                       out_level, out_q, out_count, out_index);
     MST_LAUNCH_CHECK();
     return MST_OK;
+}
+}  // namespace
+
+extern "C" int mst_bh_select(const mst_found *found, const double *pval, const uint32_t *count, int32_t B, uint32_t cap,
+                             double threshold, uint32_t out_cap, uint32_t *out_pixel, uint32_t *out_level, double *out_q,
+                             uint32_t *out_count, void *workspace, uint64_t workspace_bytes, void *stream) {
+    return bh_select_impl(found, pval, count, B, cap, threshold, out_cap, out_pixel, out_level, out_q, out_count, nullptr,
+                          workspace, workspace_bytes, stream);
+}
+
+extern "C" int mst_bh_select_records(const mst_found *found, const double *pval, const uint32_t *count, int32_t B,
+                                     uint32_t cap, double threshold, uint32_t out_cap, uint32_t *out_pixel,
+                                     uint32_t *out_level, double *out_q, uint32_t *out_index, uint32_t *out_count,
+                                     void *workspace, uint64_t workspace_bytes, void *stream) {
+    if (!out_index) return mst::fail(MST_E_ARG, "mst_bh_select_records: bad argument");
+    return bh_select_impl(found, pval, count, B, cap, threshold, out_cap, out_pixel, out_level, out_q, out_count, out_index,
+                          workspace, workspace_bytes, stream);
 }
 
 extern "C" int mst_select_below(const mst_found *found, const double *q, const uint32_t *found_count, int32_t B,

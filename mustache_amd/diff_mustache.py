@@ -52,15 +52,21 @@ def _pair_tail(batch, b1, b2, start, pt, pt2, st, intra):
         # differential subset (:567-568): pair < pt2 and v_self > v_other, where v = 1 off-nz, vAll on nz (0 if not found)
         pix = rec["pixel"][reps] if reps else np.zeros(0, np.uint32)
         nz_other, _, _ = batch.candidate_features(bo, pix, np.zeros(len(pix), np.int64))
-        opix = other["pixel"].astype(np.int64)
+        looked_up = "v_other" in rec           # selected-only records (engine.run_band_pairs(select_below=pt)): device look-up
+        opix = None if looked_up else other["pixel"].astype(np.int64)
         diff = []
         for j, r in enumerate(reps):
             p = int(pix[j])
-            k = int(np.searchsorted(opix, p))
-            if k < len(opix) and opix[k] == p:
-                v_other = other["value"][k]
+            if looked_up:
+                v_other = rec["v_other"][r]
+                if np.isnan(v_other):                                      # the other sample did not find this pixel
+                    v_other = 0.0 if nz_other[j] else 1.0
             else:
-                v_other = 0.0 if nz_other[j] else 1.0
+                k = int(np.searchsorted(opix, p))
+                if k < len(opix) and opix[k] == p:
+                    v_other = other["value"][k]
+                else:
+                    v_other = 0.0 if nz_other[j] else 1.0
             if rec["pair"][r] < pt2 and rec["value"][r] > v_other:
                 diff.append(loops[j])
         out.extend([loops, diff])
@@ -138,7 +144,7 @@ def call_diff_loops_coo(coo1, coo2, res, distance_in_px, octave_values, st, pt, 
     for g0 in range(0, len(idx), bs):
         grp = idx[g0:g0 + bs]
         st_g = [start[i] for i in grp]
-        batch = _pairs_from_filled(eng, pipe, dbands, n, distance_in_px, st_g, CH)
+        batch = _pairs_from_filled(eng, pipe, dbands, n, distance_in_px, st_g, CH, pt=pt)
         P = len(grp)
         for j, i in enumerate(grp):
             mask = block_mask_size(i, start, end, distance_in_px)
@@ -147,13 +153,13 @@ def call_diff_loops_coo(coo1, coo2, res, distance_in_px, octave_values, st, pt, 
     return o
 
 
-def _pairs_from_filled(eng, pipe, dbands, n, dpx, starts, CH, dense=False):
+def _pairs_from_filled(eng, pipe, dbands, n, dpx, starts, CH, dense=False, pt=None):
     """Sigma loops of both samples + pair p-values for the block pairs that start at `starts`.  Default: band-direct -- both
     samples' tiles are cut out of their bands inside the kernels (engine.run_band_pairs), no dense block, difference image or
     blurred level of it is ever materialised.  dense=True: the reference's own data flow (filled dense blocks of both
     samples, difference image, its two blurs per octave) -- kept as the cross-check path."""
     if not dense:
-        return eng.run_band_pairs(dbands, n, dpx, starts, CH)
+        return eng.run_band_pairs(dbands, n, dpx, starts, CH, select_below=pt)
     import torch
     from .engine import BlockBatch
     c1, nz1, cnt1 = pipe.blocks_from_band(dbands[0], n, dpx, starts, CH)

@@ -387,10 +387,11 @@ class ScaleSpaceEngine:
             _lib.check(self.lib.mst_bh_fdr(_ptr(pval), _ptr(count), B, found_cap, _ptr(q), _ptr(ws), ws_bytes, _stream()))
         return q
 
-    def _download_selected(self, found, pval, count, fit, nt, found_cap, pt, full_sort=False):
+    def _download_selected(self, found, pval, count, fit, nt, found_cap, pt, full_sort=False, pair=None):
         """BH-FDR and the selection q < pt on the device; only the selected records come back.  Default: mst_bh_select
-        (sorts only the records with p < pt -- same selected set, bit-identical q); full_sort=True runs mst_bh_fdr over all
-        records and then mst_select_below (kept as the cross-check)."""
+        (sorts only the records that can be selected -- same selected set, bit-identical q); full_sort=True runs mst_bh_fdr
+        over all records and then mst_select_below (kept as the cross-check).  pair = (ppair [2P, found_cap], P), two-sample
+        path: the selected records also carry `pair`, `value` and `v_other` (mst_pair_gather)."""
         B = count.shape[0]
         cap = self._select_cap
         ws_bytes = int(self.lib.mst_bh_workspace_bytes(B, found_cap))
@@ -407,6 +408,11 @@ class ScaleSpaceEngine:
                 if full_sort:
                     _lib.check(self.lib.mst_select_below(_ptr(found), _ptr(q), _ptr(count), B, found_cap, pt, cap,
                                                          _ptr(pix), _ptr(lvl), _ptr(qs), _ptr(n_sel), _stream()))
+                elif pair is not None:
+                    idx = torch.empty((B, cap), dtype=torch.int32, device=self.device)
+                    _lib.check(self.lib.mst_bh_select_records(_ptr(found), _ptr(pval), _ptr(count), B, found_cap, pt, cap,
+                                                              _ptr(pix), _ptr(lvl), _ptr(qs), _ptr(idx), _ptr(n_sel),
+                                                              _ptr(ws), ws_bytes, _stream()))
                 else:
                     _lib.check(self.lib.mst_bh_select(_ptr(found), _ptr(pval), _ptr(count), B, found_cap, pt, cap,
                                                       _ptr(pix), _ptr(lvl), _ptr(qs), _ptr(n_sel), _ptr(ws), ws_bytes,
@@ -416,6 +422,15 @@ class ScaleSpaceEngine:
                     break
                 cap = self._select_cap = int(n_h.max()) * 2         # rare: re-run with room for every selected record
             mx = int(n_h.max(initial=0))
+            extra_h = {}
+            if pair is not None:
+                ppair, P = pair
+                g = torch.empty((3, B, cap), dtype=torch.float64, device=self.device)
+                _lib.check(self.lib.mst_pair_gather(_ptr(found), found_cap, _ptr(count), _ptr(ppair), int(P), _ptr(idx),
+                                                    _ptr(pix), _ptr(n_sel), cap, mx, _ptr(g[0]), _ptr(g[1]), _ptr(g[2]),
+                                                    _stream()))
+                g_h = g[:, :, :max(mx, 1)].cpu().numpy()
+                extra_h = {"pair": g_h[0], "value": g_h[1], "v_other": g_h[2]}
             pix_h = pix[:, :max(mx, 1)].cpu().numpy().view(np.uint32)
             lvl_h = lvl[:, :max(mx, 1)].cpu().numpy().view(np.uint32)
             q_h = qs[:, :max(mx, 1)].cpu().numpy()
@@ -424,7 +439,10 @@ class ScaleSpaceEngine:
         for b in range(B):
             m = int(n_h[b])
             order = np.argsort(pix_h[b, :m], kind="stable")        # the kernel appends in arbitrary order; pixels are unique
-            out.append({"pixel": pix_h[b, :m][order], "level": lvl_h[b, :m][order], "q": q_h[b, :m][order]})
+            rec = {"pixel": pix_h[b, :m][order], "level": lvl_h[b, :m][order], "q": q_h[b, :m][order]}
+            for name, arr in extra_h.items():
+                rec[name] = arr[b, :m][order]
+            out.append(rec)
             fits.append((fit_h[b, :nt, 0].copy(), fit_h[b, :nt, 1].copy()))
         return out, fits
 
@@ -552,25 +570,36 @@ class ScaleSpaceEngine:
                                                          n_oct, tpo, off, _ptr(ppair), _stream()))
         return ppair, fit
 
-    def run_band_pairs(self, bands, n, dpx, starts, CH, skip_empty=True):
+    def run_band_pairs(self, bands, n, dpx, starts, CH, skip_empty=True, select_below=None):
         """Both samples' sigma loops straight from their bands + the pair p-values: PairBandBatch over 2P blocks whose
-        records carry `pair` and `q`."""
+        records carry `pair` and `q`.  select_below = pt (what the per-chromosome driver passes): BH, the selection q < pt and
+        the differential test's look-ups happen on the device and only the selected records come back, each with `pair`,
+        `value` and `v_other` (the partner sample's winning value at that pixel, NaN if it did not find it); without it the
+        whole found sets are downloaded, sorted by pixel (the cross-check form)."""
         cap = self._found_cap.get(CH, max(4096, (CH * CH) // 32))
         while True:
-            parts = [self.sigma_loop_band(bd, n, dpx, starts, CH, skip_empty=skip_empty, download=False, found_cap=cap)
-                     for bd in bands]
-            caps = {p[4] for p in parts}
+            # both samples' kernels are queued before either is waited for
+            nzcs = [torch.empty(len(starts), dtype=torch.int32, device=self.device) for _ in bands]
+            sts = [self._ss_launch(None, None, nzc, skip_empty, cap, None, False,
+                                   (bd, int(n), int(dpx), [int(v) for v in starts], int(CH)))
+                   for bd, nzc in zip(bands, nzcs)]
+            sts = [self._ss_finish(st) for st in sts]
+            caps = {st["found_cap"] for st in sts}
             if caps == {cap}:
                 break
             cap = max(caps)                      # a record-capacity overflow re-ran one sample with more room: redo both alike
-        found = torch.cat([p[0] for p in parts])
-        pval = torch.cat([p[1] for p in parts])
-        count = torch.cat([p[2] for p in parts])
-        fit = torch.cat([p[3] for p in parts])
-        nzc = torch.cat([p[5] for p in parts])
+        found = torch.cat([st["found"] for st in sts])
+        pval = torch.cat([st["pval"] for st in sts])
+        count = torch.cat([st["count"] for st in sts])
+        fit = torch.cat([st["fit"] for st in sts])
+        nzc = torch.cat(nzcs)
         ppair, nfit = self.pair_pvalues_band(bands[0], bands[1], n, dpx, starts, CH, found, cap, count)
-        recs, fits = self._download(found, pval, count, fit, self.levels.n_tested, sort=True,
-                                    extra={"pair": ppair, "q": self.fdr(pval, count, cap)})
+        if select_below is not None:
+            recs, fits = self._download_selected(found, pval, count, fit, self.levels.n_tested, cap, float(select_below),
+                                                 pair=(ppair, len(starts)))
+        else:
+            recs, fits = self._download(found, pval, count, fit, self.levels.n_tested, sort=True,
+                                        extra={"pair": ppair, "q": self.fdr(pval, count, cap)})
         batch = PairBandBatch(self, bands, n, dpx, starts, CH, nzc.cpu().numpy().view(np.uint32).astype(np.int64), recs,
                               fits)
         batch.norm_fit = nfit.cpu().numpy()

@@ -13,17 +13,17 @@ def main():
     w5 = bench.Workload("chr21@5kb", 9630, 400, 5000, 300.0, 300, 0, dev, 0, 1)
     band_b, _ = bench.make_band(9630, 400, 260.0, 300, 7, 5000, dev)
     for _ in range(3):
-        _pairs_from_filled(w5.pipe.engine, w5.pipe, [w5.band, band_b], w5.n, w5.dpx, w5.start, w5.CH)
+        _pairs_from_filled(w5.pipe.engine, w5.pipe, [w5.band, band_b], w5.n, w5.dpx, w5.start, w5.CH, pt=0.1)
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(10):
-        _pairs_from_filled(w5.pipe.engine, w5.pipe, [w5.band, band_b], w5.n, w5.dpx, w5.start, w5.CH)
+        _pairs_from_filled(w5.pipe.engine, w5.pipe, [w5.band, band_b], w5.n, w5.dpx, w5.start, w5.CH, pt=0.1)
     torch.cuda.synchronize()
     print("DIFF ms per call %.3f" % ((time.time() - t0) / 10 * 1e3))
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(5):
-        _pairs_from_filled(w5.pipe.engine, w5.pipe, [w5.band, band_b], w5.n, w5.dpx, w5.start, w5.CH)
+        _pairs_from_filled(w5.pipe.engine, w5.pipe, [w5.band, band_b], w5.n, w5.dpx, w5.start, w5.CH, pt=0.1)
     torch.cuda.synchronize()
     pr.disable()
     s = io.StringIO()

@@ -42,8 +42,12 @@ for case in range(ncases):
         xx, yy = np.nonzero(np.triu(c))
         bands.append(band_from_coo(torch.from_numpy(xx).cuda(), torch.from_numpy(yy).cuda(), torch.from_numpy(c[xx, yy]).cuda(),
                                    n, dpx))
-    batch = eng.run_band_pairs(bands, n, dpx, [0], n)
+    batch = eng.run_band_pairs(bands, n, dpx, [0], n, select_below=pt)         # the driver's form (selected records only)
     got_band = _pair_tail(batch, 0, 1, start, pt, pt2, st, True)
+    full = _pair_tail(eng.run_band_pairs(bands, n, dpx, [0], n), 0, 1, start, pt, pt2, st, True)   # whole found sets
+    if [[tuple(l) for l in ls] for ls in full] != [[tuple(l) for l in ls] for ls in got_band]:
+        print("case %d: selected-only and full-download forms differ" % case, flush=True)
+        bad += 1
     got_dense = diff_mustache(cs[0].copy(), cs[1].copy(), "1", "1", 5000, start, start + n, 0, dpx, OCT, st, pt, pt2)
     ok = key(got_band) == key(exp) and key(got_dense) == key(exp)
     qe = 0.0

@@ -109,13 +109,27 @@ def test_baseline_geometry_pairs_vs_reference_fixture(golden_dir):
         np.testing.assert_allclose(float(rec["pair"].sum()), float(g["found_pair_sum" + nm]), rtol=1e-6)
     np.testing.assert_allclose(batch.norm_fit[0, 0], g["norm_fit"][0], rtol=1e-7)
     np.testing.assert_allclose(batch.norm_fit[1, 0], g["norm_fit"][9], rtol=1e-7)
-    out = _pair_tail(batch, 0, 1, start, float(g["pt"]), float(g["pt2"]), float(g["st"]), True)
-    for got, key in zip(out, ("loops1", "diff1", "loops2", "diff2")):
-        exp = g[key]
-        arr = np.array([[float(a), float(b), q, s] for a, b, q, s in got]).reshape(-1, 4)
-        assert arr.shape == exp.shape and len(exp) > 30, key
-        assert np.array_equal(arr[:, :2], exp[:, :2]) and np.array_equal(arr[:, 3], exp[:, 3]), key
-        np.testing.assert_allclose(arr[:, 2], exp[:, 2], rtol=1e-7)
+    # the driver's form: BH, selection and the partner look-ups on the device, only the selected records downloaded
+    lean = eng.run_band_pairs(bands, n, dpx, [0], n, select_below=float(g["pt"]))
+    for b in (0, 1):
+        full, sel = batch.found[b], lean.found[b]
+        keep = full["q"] < float(g["pt"])
+        assert keep.sum() > 30 and np.array_equal(full["pixel"][keep], sel["pixel"])
+        for key in ("level", "q", "pair", "value"):
+            assert np.array_equal(full[key][keep], sel[key]), key
+        other = batch.found[1 - b]
+        k = np.searchsorted(other["pixel"], sel["pixel"])
+        hit = (k < len(other["pixel"])) & (other["pixel"][np.minimum(k, len(other["pixel"]) - 1)] == sel["pixel"])
+        assert hit.any() and (~hit).any()
+        assert np.array_equal(sel["v_other"][hit], other["value"][k[hit]]) and np.isnan(sel["v_other"][~hit]).all()
+    for form in (batch, lean):
+        out = _pair_tail(form, 0, 1, start, float(g["pt"]), float(g["pt2"]), float(g["st"]), True)
+        for got, key in zip(out, ("loops1", "diff1", "loops2", "diff2")):
+            exp = g[key]
+            arr = np.array([[float(a), float(b), q, s] for a, b, q, s in got]).reshape(-1, 4)
+            assert arr.shape == exp.shape and len(exp) > 30, key
+            assert np.array_equal(arr[:, :2], exp[:, :2]) and np.array_equal(arr[:, 3], exp[:, 3]), key
+            np.testing.assert_allclose(arr[:, 2], exp[:, 2], rtol=1e-7)
 
 
 def test_diff_mustache_dropin_vs_reference(golden_dir):

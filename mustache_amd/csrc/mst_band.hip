@@ -90,14 +90,37 @@ diag_stats_kernel(const double *__restrict__ band, int64_t n, double *__restrict
     block_reduce2(hc, hs, sa, sb);
     const double K = hc > 0.0 ? hs / hc : 0.0;
     double cnt = 0.0, s1 = 0.0, s2 = 0.0, dummy = 0.0;
-    for (int64_t i = threadIdx.x; i < L; i += kThreads) {
-        const double v = row[i];
-        if (v != 0.0) {
-            const double t = v - K;
-            cnt = cnt + 1.0;
-            s1 = s1 + t;
-            s2 = s2 + t * t;
+    {
+        // four independent accumulator sets per thread (fixed assignment: sample i goes to set (i / kThreads) % 4), so four
+        // loads are in flight per lane; folded in a fixed order
+        constexpr int U = 4;
+        double c[U] = {0.0, 0.0, 0.0, 0.0}, a[U] = {0.0, 0.0, 0.0, 0.0}, q[U] = {0.0, 0.0, 0.0, 0.0};
+        int64_t i = threadIdx.x;
+        for (; i + (U - 1) * kThreads < L; i += U * kThreads) {
+            double v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = row[i + u * kThreads];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (v[u] != 0.0) {
+                    const double t = v[u] - K;
+                    c[u] = c[u] + 1.0;
+                    a[u] = a[u] + t;
+                    q[u] = q[u] + t * t;
+                }
         }
+        for (int u = 0; i < L; i += kThreads, ++u) {
+            const double v = row[i];
+            if (v != 0.0) {
+                const double t = v - K;
+                c[u] = c[u] + 1.0;
+                a[u] = a[u] + t;
+                q[u] = q[u] + t * t;
+            }
+        }
+        cnt = (c[0] + c[1]) + (c[2] + c[3]);
+        s1 = (a[0] + a[1]) + (a[2] + a[3]);
+        s2 = (q[0] + q[1]) + (q[2] + q[3]);
     }
     block_reduce2(cnt, s1, sa, sb);
     block_reduce2(s2, dummy, sa, sb);

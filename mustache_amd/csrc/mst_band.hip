@@ -465,6 +465,27 @@ normalize_prefix_kernel(const double *__restrict__ band_in, double *__restrict__
 // Numerics: every window sum is the sum of two partial sums of at most W terms each, accumulated in a fixed order
 // (deterministic; relative error of a few 1e-16 on the sums, measured against extended-precision windows by
 // scripts/norm_accuracy.py).  Counts are exact integers.
+// Reciprocal and reciprocal square root for the walking kernel: the hardware estimate (v_rcp_f64 / v_rsq_f64) refined by two
+// Newton steps in FMA arithmetic -- within an ulp of the correctly rounded value, a third of the instructions of the IEEE
+// division / the library rsqrt (no scaling, no special-case selects).  Zero, negative and non-finite arguments produce
+// inf / NaN, which the callers' nan_to_num steps turn into the reference's fall-backs exactly as a true division would.
+__device__ __forceinline__ double rcp_newton(double a) {
+    double y = __builtin_amdgcn_rcp(a);
+    double e = __builtin_fma(-a, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-a, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ double rsqrt_newton(double a) {
+    double y = __builtin_amdgcn_rsq(a);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = __builtin_fma(-(a * y), y, 1.0);      // 1 - a y^2
+        y = __builtin_fma(0.5 * y, e, y);
+    }
+    return y;
+}
+
 template <int NT>
 __device__ __forceinline__ void block_totals3(double &s1, double &s2, int &sc, double *w1, double *w2, int *wc,
                                                double &o1, double &o2, int &oc, double &t1, double &t2, int &tc) {
@@ -518,15 +539,17 @@ normalize_walk_kernel(const double *__restrict__ band_in, double *__restrict__ b
     const double std2 = sd * sd;
     const int k0 = tid * C;                             // this thread's offsets inside a block: k0 .. k0 + C - 1
 
-    // shifted samples (vals[x] = v + 0.001, :635) of this thread's offsets in sample block m; 0 outside the diagonal.  Each
-    // lane reads C consecutive doubles (the scan is serial inside a thread); the C loads of a wave cover the same cache lines.
+    // RAW samples of this thread's offsets in sample block m; 0 outside the diagonal.  Each lane reads C consecutive doubles
+    // (the scan is serial inside a thread); the C loads of a wave cover the same cache lines.  The shift vals[x] = v + 0.001
+    // (:635) is applied where the values are consumed, one block later: a fetch must not touch what it loads, or the wave
+    // waits for the memory right after issuing the loads and nothing is prefetched (that was the case until r02d: the kernel
+    // ran at the speed of one memory round trip per block).
     auto fetch = [&](int m, double (&r)[C]) {
         const int64_t base = (int64_t)m * W - left + k0;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             const int64_t q = base + j;
-            const double v = (k0 + j < W && q >= 0 && q < L) ? row[q] : 0.0;
-            r[j] = v != 0.0 ? v + 0.001 : 0.0;
+            r[j] = (k0 + j < W && q >= 0 && q < L) ? row[q] : 0.0;
         }
     };
     // the outputs' own samples: output i = m W + k is sample offset k + left of block m -- another thread's chunk, so it is
@@ -536,8 +559,7 @@ normalize_walk_kernel(const double *__restrict__ band_in, double *__restrict__ b
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             const int64_t q = base + j;
-            const double v = (k0 + j < W && q < L) ? row[q] : 0.0;
-            x[j] = v != 0.0 ? v + 0.001 : 0.0;
+            x[j] = (k0 + j < W && q < L) ? row[q] : 0.0;
         }
     };
     // exclusive prefix of this thread's first offset (p*) and the block totals (t*) from the chunk totals (a*)
@@ -550,6 +572,7 @@ normalize_walk_kernel(const double *__restrict__ band_in, double *__restrict__ b
         pc = oc + lane_before_i(sc);
     };
 
+    auto shifted = [](double v) { return v != 0.0 ? v + 0.001 : 0.0; };
     double vv[C], nx[C], xv[C];
     double S1[C], S2[C];                                // tail sums of the previous block from each of my offsets: T - P[k]
     int Sc[C];
@@ -557,6 +580,8 @@ normalize_walk_kernel(const double *__restrict__ band_in, double *__restrict__ b
     fetch(m_lo, vv);
     fetch(m_lo + 1, nx);                                // in flight while block m_lo is scanned
     fetch_x(m_lo, xv);
+#pragma unroll
+    for (int j = 0; j < C; ++j) vv[j] = shifted(vv[j]);
     {
         double a1 = 0.0, a2 = 0.0, p1, p2, t1, t2;
         int ac = 0, pc, tc;
@@ -580,10 +605,10 @@ normalize_walk_kernel(const double *__restrict__ band_in, double *__restrict__ b
     int buf = 1;
     for (int m = m_lo; m < m_hi; ++m, buf ^= 1) {
 #pragma unroll
-        for (int j = 0; j < C; ++j) vv[j] = nx[j];      // sample block m + 1
+        for (int j = 0; j < C; ++j) vv[j] = shifted(nx[j]);      // sample block m + 1, loaded one block ago
         double x[C];
 #pragma unroll
-        for (int j = 0; j < C; ++j) x[j] = xv[j];
+        for (int j = 0; j < C; ++j) x[j] = shifted(xv[j]);
         if (m + 1 < m_hi) {                             // next block's loads hide under this block's arithmetic
             fetch(m + 2, nx);
             fetch_x(m + 1, xv);
@@ -607,17 +632,15 @@ normalize_walk_kernel(const double *__restrict__ band_in, double *__restrict__ b
                 // 1/cnt and 1/(cnt-1) from ONE division; a window with c < 30 -- including c = 1, where the product form
                 // gives NaN -- takes the fallback below
                 const double cnt = (double)c;
-                const double rcc = 1.0 / (cnt * (cnt - 1.0));       // (a table of these quotients in LDS was measured: no gain)
+                const double rcc = rcp_newton(cnt * (cnt - 1.0));   // (a table of these quotients in LDS was measured: no gain)
                 const double inv_c = rcc * (cnt - 1.0), inv_cm1 = rcc * cnt;
                 double var = (s2w - s1w * s1w * inv_c) * inv_cm1;        // (:650)
-                if (!isfinite(var)) var = std2;                          // (:653-654)
                 double mu = s1w * inv_c;                                 // (:656)
-                if (c < 30) {                                            // (:657-658)
-                    mu = mean;
-                    var = std2;
-                }
-                if (!isfinite(mu)) mu = mean;                            // (:660-661)
-                zz = (x[j] - mu) * rsqrt(var);                           // (:663-665)  (rsqrt: same accuracy as / sqrt, measured)
+                // non-finite local variance -> global (:653-654); fewer than 30 samples -> global mean and variance (:657-658);
+                // non-finite local mean -> global (:660-661): one select per quantity
+                if (c < 30 || !isfinite(var)) var = std2;
+                if (c < 30 || !isfinite(mu)) mu = mean;
+                zz = (x[j] - mu) * rsqrt_newton(var);                    // (:663-665)
                 if (!isfinite(zz)) zz = 0.0;                             // (:666)
                 zz = zz * wgt;                                           // (:667)
             }

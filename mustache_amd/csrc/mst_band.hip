@@ -527,6 +527,13 @@ normalize_walk_kernel(const double *__restrict__ band_in, double *__restrict__ b
     constexpr int NW = NT / 64;
     __shared__ double w1[2][NW], w2[2][NW];            // wave totals of the block being scanned, double-buffered: ONE barrier per block
     __shared__ int wc[2][NW];
+    // The outputs' own samples (output i = m W + k is sample offset k + left of block m: another thread's chunk) are exchanged
+    // through LDS: every thread parks the shifted samples it scans in a ring of three blocks, and the barrier of the scan
+    // makes them visible -- no second read of the band (it was an L2 hit, but 4 strided loads with bounds arithmetic per
+    // thread and block).  Geometries whose ring would not fit the 64 KB static limit keep the re-read.
+    constexpr bool XLDS = NT * C <= 2048;
+    constexpr int CAPW = NT * C;
+    __shared__ __align__(16) double ring[XLDS ? 3 * CAPW : 2];
     const int tid = threadIdx.x;
     const int d = blockIdx.x / runs_per_diag;
     const int m_lo = (blockIdx.x - d * runs_per_diag) * run;
@@ -579,9 +586,17 @@ normalize_walk_kernel(const double *__restrict__ band_in, double *__restrict__ b
     // prime: sample block m_lo -> its tail sums
     fetch(m_lo, vv);
     fetch(m_lo + 1, nx);                                // in flight while block m_lo is scanned
-    fetch_x(m_lo, xv);
+    if constexpr (!XLDS) fetch_x(m_lo, xv);
 #pragma unroll
     for (int j = 0; j < C; ++j) vv[j] = shifted(vv[j]);
+    auto park = [&](int m, const double (&v)[C]) {      // shifted samples of block m -> its ring slot
+        if constexpr (XLDS) {
+            double *slot = ring + (m % 3) * CAPW + k0;
+#pragma unroll
+            for (int j = 0; j < C; ++j) slot[j] = v[j];
+        }
+    };
+    park(m_lo, vv);
     {
         double a1 = 0.0, a2 = 0.0, p1, p2, t1, t2;
         int ac = 0, pc, tc;
@@ -606,12 +621,15 @@ normalize_walk_kernel(const double *__restrict__ band_in, double *__restrict__ b
     for (int m = m_lo; m < m_hi; ++m, buf ^= 1) {
 #pragma unroll
         for (int j = 0; j < C; ++j) vv[j] = shifted(nx[j]);      // sample block m + 1, loaded one block ago
+        park(m + 1, vv);                                // visible to the other threads after the scan's barrier
         double x[C];
+        if constexpr (!XLDS) {
 #pragma unroll
-        for (int j = 0; j < C; ++j) x[j] = shifted(xv[j]);
+            for (int j = 0; j < C; ++j) x[j] = shifted(xv[j]);
+        }
         if (m + 1 < m_hi) {                             // next block's loads hide under this block's arithmetic
             fetch(m + 2, nx);
-            fetch_x(m + 1, xv);
+            if constexpr (!XLDS) fetch_x(m + 1, xv);
         }
         double a1 = 0.0, a2 = 0.0, p1, p2, t1, t2;
         int ac = 0, pc, tc;
@@ -622,6 +640,14 @@ normalize_walk_kernel(const double *__restrict__ band_in, double *__restrict__ b
             a2 = a2 + vv[j] * vv[j];
         }
         scan(buf, a1, a2, ac, p1, p2, pc, t1, t2, tc);
+        if constexpr (XLDS) {                           // sample offset k + left of block m, continuing into block m + 1
+            const double *sm = ring + (m % 3) * CAPW, *sn = ring + ((m + 1) % 3) * CAPW;
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                const int e = k0 + j + left;
+                x[j] = k0 + j < W ? (e < W ? sm[e] : sn[e - W]) : 0.0;
+            }
+        }
         const int64_t i0 = (int64_t)m * W + k0;
 #pragma unroll
         for (int j = 0; j < C; ++j) {

@@ -13,7 +13,7 @@ from mustache_amd.normalize import band_from_coo
 from mustache_amd.synth import synth_coo
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 25
-rng = np.random.default_rng(4242)
+rng = np.random.default_rng(int(__import__('os').environ.get('FUZZ_SEED', 4242)))   # FUZZ_SEED=... draws another sweep
 eng = ScaleSpaceEngine([1.6, 3.2])
 OCT = [1.6, 3.2]
 

@@ -9,7 +9,7 @@ from mustache_amd.engine import ScaleSpaceEngine
 from mustache_amd.synth import synth_coo
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(2024)
+rng = np.random.default_rng(int(__import__('os').environ.get('FUZZ_SEED', 2024)))   # FUZZ_SEED=... draws another sweep
 eng = ScaleSpaceEngine([1.6, 3.2])
 bad = 0
 for case in range(ncases):

@@ -10,7 +10,7 @@ from mustache_amd.pipeline import ChromosomePipeline
 from mustache_amd.synth import synth_coo
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-rng = np.random.default_rng(77)
+rng = np.random.default_rng(int(__import__('os').environ.get('FUZZ_SEED', 77)))   # FUZZ_SEED=... draws another sweep
 pipe = ChromosomePipeline([1.6, 3.2])
 bad = total = 0
 t0 = time.time()

@@ -52,17 +52,18 @@ def executed_flops_per_pixel():
     return per_region_px * (32 * 64) / (30.0 * 62.0)
 
 
-def band_tile_fraction(CH, dpx, itr=30, itc=62):
-    """Share of a block's 30 x 62 tiles that the band-direct kernel launches with empty tiles skipped: those whose owned pixels
-    can reach the tested band 4 <= col - row <= dpx + 1 (the rule of band_tile_list in mst_scale_space.hip)."""
-    ty, tx = -(-CH // itr), -(-CH // itc)
-    m = 0
-    for j in range(ty):
-        r_lo, r_hi = j * itr, min(j * itr + itr - 1, CH - 1)
-        for i in range(tx):
-            c_lo, c_hi = i * itc, min(i * itc + itc - 1, CH - 1)
-            m += (c_hi - r_lo >= 4) and (c_lo - r_hi <= dpx + 1)
-    return m / float(ty * tx)
+def band_tile_fraction(CH, dpx):
+    """Share of a block's tiles that the band-direct kernel launches with empty tiles skipped (those whose owned pixels can
+    reach the tested band 4 <= col - row <= dpx + 1) -- asked of the library itself (mst_scale_space_band_tiles)."""
+    import ctypes
+    from mustache_amd import _lib
+    from mustache_amd.levels import LevelTable
+    lv = LevelTable((1.6, 3.2)).as_struct()
+    total = ctypes.c_int32(0)
+    m = _lib.load().mst_scale_space_band_tiles(int(CH), int(dpx), ctypes.byref(lv), ctypes.byref(total))
+    if m < 0 or total.value <= 0:
+        raise RuntimeError("mst_scale_space_band_tiles failed")
+    return m / float(total.value)
 
 
 def parse():

@@ -216,6 +216,10 @@ int mst_scale_space_band(const double *band, int64_t n, int32_t dpx, const int64
                          const mst_levels *lv, mst_found *found, uint32_t found_cap, uint32_t *found_count,
                          double *level_stats, uint32_t *nz_count, int32_t flags, void *workspace,
                          uint64_t workspace_bytes, void *stream);
+/* How many of a block's tiles mst_scale_space_band launches with MST_FLAG_SKIP_EMPTY (those whose pixels can reach the tested
+ * band 4 <= col - row <= dpx + 1), and, through tiles_total, how many without it.  Depends on (CH, dpx, lv) only; < 0 on a
+ * bad argument.  For measurement: the share of the dense work the skipping mode really does. */
+int mst_scale_space_band_tiles(int32_t CH, int32_t dpx, const mst_levels *lv, int32_t *tiles_total);
 
 /* mst_candidate_features / mst_gather_diagonals / mst_diag_means for the block that starts at bin `start` of the band. */
 int mst_candidate_features_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,

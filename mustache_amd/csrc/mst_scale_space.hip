@@ -689,6 +689,16 @@ static int band_tile_list(int CH, int dpx, int32_t *out) {
     return m;
 }
 
+extern "C" int mst_scale_space_band_tiles(int32_t CH, int32_t dpx, const mst_levels *lv, int32_t *tiles_total_out) {
+    int mr = 0, nt = 0;
+    if (CH <= 0 || dpx < 0 || check_levels(lv, &mr, &nt) != MST_OK) return -1;
+    const bool wide = mr > TileDefault::RMAX;
+    const int total = wide ? tiles_total<TileWide>(CH) : tiles_total<TileDefault>(CH);
+    std::vector<int32_t> list((size_t)total);
+    if (tiles_total_out) *tiles_total_out = total;
+    return wide ? band_tile_list<TileWide>(CH, dpx, list.data()) : band_tile_list<TileDefault>(CH, dpx, list.data());
+}
+
 // shared body of mst_scale_space (dense blocks) and mst_scale_space_band (blocks cut out of the band on the fly)
 template <bool BAND>
 static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, const int64_t *starts_host, int32_t B,

@@ -191,3 +191,25 @@ def test_cluster_representative_with_tied_q_values(golden_dir, quantum):
     q = benjamini_hochberg(found["pval"])
     sel = q[q < 0.5]
     assert len(sel) - len(np.unique(sel)) > len(sel) // 2
+
+
+def test_launched_tile_count_matches_the_geometric_rule():
+    """mst_scale_space_band_tiles (what bench.py uses to price the skipping mode) == a direct restatement of the rule: a
+    30 x 62 tile is launched iff its pixels can reach the tested band 4 <= col - row <= dpx + 1."""
+    import ctypes
+    from mustache_amd import _lib
+    from mustache_amd.levels import LevelTable
+    lib = _lib.load()
+    lv = LevelTable(OCT).as_struct()
+    for CH, dpx in ((2000, 400), (4000, 2000), (700, 160), (320, 80), (8000, 4000), (2000, 5)):
+        ty, tx = -(-CH // 30), -(-CH // 62)
+        m = 0
+        for j in range(ty):
+            r_lo, r_hi = j * 30, min(j * 30 + 29, CH - 1)
+            for i in range(tx):
+                c_lo, c_hi = i * 62, min(i * 62 + 61, CH - 1)
+                m += (c_hi - r_lo >= 4) and (c_lo - r_hi <= dpx + 1)
+        total = ctypes.c_int32(0)
+        assert lib.mst_scale_space_band_tiles(CH, dpx, ctypes.byref(lv), ctypes.byref(total)) == m
+        assert total.value == ty * tx
+    assert lib.mst_scale_space_band_tiles(0, 5, ctypes.byref(lv), None) < 0

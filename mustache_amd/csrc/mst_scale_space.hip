@@ -407,35 +407,41 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
             if (kl < 2) continue;
             if (MST_VARIANT(1)) continue;     // [ablation 1] blur + DoG only
 
-            // zero-padded 3x3 max at the owned pixels: 3-max along the row in registers, then across rows via lane shifts
-            const double dl = de_left[0], dr = de_right[0];
-            double hm[K];
-#pragma unroll
-            for (int j = 0; j < K / 2; ++j) {      // max(d[2j], d[2j+1]) serves both of its pixels: 12 v_max_f64, not 16
-                const double pj = dmax(d[2 * j], d[2 * j + 1]);
-                hm[2 * j] = dmax(j == 0 ? dl : d[2 * j - 1], pj);
-                hm[2 * j + 1] = dmax(pj, 2 * j + 2 == K ? dr : d[2 * j + 2]);
-            }
+            // zero-padded 3x3 max at the owned pixels: 3-max along the row in registers, then across rows via lane shifts.
+            // A pixel's maximum is only ever compared with DoG values of the SAME pixel (mustache.py:760-765, on the tested
+            // pixels), the row shifts stay inside the wave and the neighbouring column groups read this wave's edge samples
+            // from the strip written above -- so a wave that owns no tested pixel has no observable use for its maxima and
+            // skips them together with the sieve (its Gaussian levels, DoG values and edge samples are produced as before).
             uint32_t en = 0, gn = 0;   // en: D_new == M_new;  gn: D_new > M_prev (M of the level before it)
             double m[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) m[k] = dmax(dmax(lane_prev(hm[k]), hm[k]), lane_next(hm[k]));
-            // the comparisons belong to the sieve, which the reference evaluates on the tested pixels only
-            // (LocMaxC[nz] == Lc[nz] ..., mustache.py:760-765): a wave that owns none never reads these bits
             if (wave_has_nz) {
+                const double dl = de_left[0], dr = de_right[0];
+                double hm[K];
+#pragma unroll
+                for (int j = 0; j < K / 2; ++j) {      // max(d[2j], d[2j+1]) serves both of its pixels: 12 v_max_f64, not 16
+                    const double pj = dmax(d[2 * j], d[2 * j + 1]);
+                    hm[2 * j] = dmax(j == 0 ? dl : d[2 * j - 1], pj);
+                    hm[2 * j + 1] = dmax(pj, 2 * j + 2 == K ? dr : d[2 * j + 2]);
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) m[k] = dmax(dmax(lane_prev(hm[k]), hm[k]), lane_next(hm[k]));
+                // the comparisons belong to the sieve, which the reference evaluates on the tested pixels only
+                // (LocMaxC[nz] == Lc[nz] ..., mustache.py:760-765)
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     if (d[k] == m[k]) en |= 1u << k;
                     if (d[k] > Mc[k]) gn |= 1u << k;
                 }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) m[k] = 0.0;
             }
             if (kl >= 4) {
                 // tested level = D_{kl-2}: previous = D_{kl-3} (ep), current (Dc, ec, gp), next = this one (m, en)
                 double lmin = INFINITY, lsum = 0.0;
                 const uint32_t code = (uint32_t)tested + 1u;
                 // the reference evaluates the sieve and expon.fit on the tested pixels only (Lc[nz], mustache.py:755-768);
-                // a wave that owns none has nothing to do here (its 3x3 maxima above are still computed, as the
-                // reference's maximum_filter runs over the whole block)
+                // a wave that owns none has nothing to do here
                 if (wave_has_nz)
 #pragma unroll
                 for (int k = 0; k < K; ++k) {

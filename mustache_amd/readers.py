@@ -101,7 +101,10 @@ def read_hic_file(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, chr2, res):
             raise NameError('wrong chromosome name!')
         CHRM_SIZE = sizes[key]
     norm = "KR" if not norm_method else str(norm_method)          # (:328-333)
-    if hic_backend() == "native" and chr1 == chr2:
+    backend = hic_backend()
+    print("reading %s through the %s .hic reader (MUSTACHE_HIC_BACKEND=auto|native|hicstraw)"
+          % (os.path.basename(str(f)), backend if chr1 == chr2 or backend == "hicstraw" else "hicstraw"))
+    if backend == "native" and chr1 == chr2:
         # one pass over the zlib blocks near the diagonal: the union of the reference's overlapping straw windows is every
         # record with |x - y| <= dist/res (consecutive windows overlap by exactly `dist`), already de-duplicated
         from .hicfile import HicFile

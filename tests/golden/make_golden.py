@@ -418,9 +418,99 @@ def make_hic_header():
     print("hic header", dref.version, masterindex, genome, chrs, resolutions, metadata)
 
 
+
+def make_readers_ref():
+    """readers_ref.npz: what the REFERENCE's own read_cooler / read_mcooler / read_hic_file (mustache.py:300-592) return for
+    the three-chromosome container of tests/readers_case.py, served through the stand-in `cooler` module and a list-backed
+    `hicstraw` (both absent offline; the reference only ever sees the module objects named `cooler` / `hicstraw`), plus the
+    chromosome lists main() builds for a whole-genome run (mustache.py:1019-1033, captured by running main() with
+    regulator() replaced by a recorder).  Pins the window walk, the set-difference de-duplication between consecutive
+    windows, the NaN / zero / negative-value handling and the distance filter on the reference itself."""
+    import contextlib
+    import io
+    sys.path.insert(0, os.path.dirname(HERE))
+    import readers_case as rc
+    ref = load_reference("mustache")
+
+    class Numpy1(object):
+        """The reference calls np.nan_to_num(<scipy sparse matrix>, copy=False, ...) (mustache.py:428, :526).  Under NumPy 1.x,
+        which the reference was written for, that wraps the matrix in a 0-d object array and returns it untouched (object
+        is not an inexact type) -- the NaNs are dealt with later (`val[np.isnan(val)] = 0`, `val > 0`); NumPy 2 raises
+        instead ("Unable to avoid copy").  The reference module therefore sees NumPy through this proxy, which restores the
+        1.x behaviour of that one call and forwards everything else."""
+
+        def __getattr__(self, name):
+            return getattr(np, name)
+
+        @staticmethod
+        def nan_to_num(x, *a, **kw):
+            from scipy import sparse as sp
+            return x if sp.issparse(x) else np.nan_to_num(x, *a, **kw)
+    ref.np = Numpy1()
+    out = {}
+
+    def put(key, x, y, v):
+        x, y, v = rc.as_sorted(x, y, v)
+        out[key + "_x"], out[key + "_y"], out[key + "_v"] = x.astype(np.int32), y.astype(np.int32), v
+    with tempfile.TemporaryDirectory() as td:
+        cool, mcool = rc.write_cool_files(td)
+        ref.cooler = rc.standin_cooler()                # tests/standins/cooler.py
+        fake = rc.fake_hicstraw(rc.RES)
+        ref.hicstraw = fake
+        sink = io.StringIO()
+        with contextlib.redirect_stdout(sink):
+            for name, size in rc.CHROMS:
+                x, y, v, res = ref.read_cooler(cool, rc.DIST, name, name, False)
+                assert res == rc.RES
+                put("cool_" + name, x, y, v)
+                x, y, v = ref.read_mcooler(mcool, rc.DIST, name, name, 2 * rc.RES, False)
+                put("mcool_" + name, x, y, v)
+                x, y, v = ref.read_hic_file("case.hic", False, False, rc.DIST, name, name, rc.RES)
+                put("hic_" + name, x, y, v)
+            # the whole-genome GPU test's container (tests/test_gpu_pipeline.py): record count and digest per chromosome
+            gcool = os.path.join(td, "genome.cool")
+            ref.cooler.write_cool(gcool, rc.GENOME_RES, rc.genome_container())
+            for name, _, _ in rc.GENOME:
+                x, y, v, res = ref.read_cooler(gcool, rc.GENOME_DPX * rc.GENOME_RES, name, name, False)
+                out["genome_%s_count" % name] = np.array(len(x))
+                out["genome_%s_sha256" % name] = np.array(rc.digest(x, y, v))
+            # chromosome size handed in by the caller (-cz / the whole-genome loop) and an explicit normalisation name
+            del fake.calls[:]
+            x, y, v = ref.read_hic_file("case.hic", "VC", rc.CHROMS[0][1], rc.DIST, "chrA", "chrA", rc.RES)
+            put("hic_chrA_sized_VC", x, y, v)
+            out["hic_calls_chrA_sized_VC"] = np.array([[c[2], c[3]] for c in fake.calls], dtype=np.int64)
+            out["hic_norm_default"] = np.array("KR")
+            # whole-genome chromosome lists of main(): regulator() replaced by a recorder that reports no loops
+            seen = []
+
+            def recorder(f, norm_method, CHRM_SIZE, outdir, **kw):
+                seen.append((str(kw["chromosome"]), str(kw["chromosome2"]), int(CHRM_SIZE) if CHRM_SIZE else 0,
+                             int(kw["distance_filter"]), int(kw["res"])))
+                return []
+            ref.regulator = recorder
+            hicp = os.path.join(td, "case.hic")
+            open(hicp, "wb").write(b"")                  # main() only checks that the path exists
+            argv0 = sys.argv
+            try:
+                for key, path, r in (("cool", cool, "5kb"), ("mcool", mcool, "10kb"), ("hic", hicp, "5kb")):
+                    del seen[:]
+                    sys.argv = ["mustache", "-f", path, "-r", r, "-o", os.path.join(td, "o.tsv")]
+                    ref.main()
+                    out["main_%s_chroms" % key] = np.array([s[0] for s in seen])
+                    out["main_%s_sizes" % key] = np.array([s[2] for s in seen], dtype=np.int64)
+                    out["main_%s_dist_res" % key] = np.array([seen[0][3], seen[0][4]], dtype=np.int64)
+            finally:
+                sys.argv = argv0
+    np.savez_compressed(os.path.join(HERE, "readers_ref.npz"), **out)
+    print("readers_ref", {k: (v.shape if v.ndim else str(v)) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["hic"]:
         make_hic_header()
+        sys.exit(0)
+    if sys.argv[1:] == ["readers"]:
+        make_readers_ref()
         sys.exit(0)
     if sys.argv[1:] == ["diff"]:
         make_diff()

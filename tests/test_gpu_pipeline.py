@@ -438,20 +438,21 @@ def test_whole_genome_cool_path_two_ranks_equals_oracle(tmp_path):
     sys.path.insert(0, standins)
     try:
         import cooler
+        import readers_case as rc
         from mustache_amd.mustache import main
-        from mustache_amd.synth import synth_coo
-        res, dpx = 5000, 400
-        chroms, truth = [], {}
-        for name, n, seed in (("chr1", 5200, 61), ("chr2", 4300, 62), ("chrX", 2900, 63)):
-            x, y, v = synth_coo(n, dpx, depth=150.0, seed=seed)
-            v = v.copy()
-            v[::53] = np.nan                                   # unbalanceable bins: NaN -> 0 -> dropped (mustache.py:463, :487)
-            chroms.append((name, n * res, x, y, v))
-            ok = ~np.isnan(v) & ((y - x) <= dpx) & (v > 0)
-            truth[name] = (x[ok], y[ok], v[ok])
-        chroms.append(("chrM", 16571, np.array([0, 1]), np.array([1, 2]), np.array([3.0, 4.0])))   # < 1 Mb: not enumerated
+        from mustache_amd.readers import read_cooler
+        res, dpx = rc.GENOME_RES, rc.GENOME_DPX
         cool = str(tmp_path / "g.cool")
-        cooler.write_cool(cool, res, chroms)
+        cooler.write_cool(cool, res, rc.genome_container())
+        # the records the pipeline is fed: the package's reader, which must return exactly what the REFERENCE's read_cooler
+        # returned for this container (tests/golden/readers_ref.npz, made by importing the reference)
+        gold = np.load(os.path.join(root, "tests", "golden", "readers_ref.npz"))
+        truth = {}
+        for name, _, _ in rc.GENOME:
+            x, y, v, r = read_cooler(cool, dpx * res, name, name, False)
+            assert r == res and len(x) == int(gold["genome_%s_count" % name])
+            assert rc.digest(x, y, v) == str(gold["genome_%s_sha256" % name]), name
+            truth[name] = (np.asarray(x), np.asarray(y), np.asarray(v))
         common = ["-f", cool, "-r", "5kb", "-pt", "0.1", "-st", "0.8"]
         single, multi = str(tmp_path / "one.tsv"), str(tmp_path / "two.tsv")
         main(common + ["-o", single])

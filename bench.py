@@ -82,7 +82,7 @@ def parse():
 OVERLAP = int(os.environ.get("MST_BENCH_OVERLAP", "4"))   # launches per step (copy/compute overlap), see Workload.step
 
 
-def make_band(n, dpx, depth, nloops, seed, res, device):
+def make_band(n, dpx, depth, nloops, seed, res, device, reps=8):
     """Synthetic chromosome -> normalised band on `device` (input preparation, not timed)."""
     import torch
     from mustache_amd.synth import band_counts
@@ -96,14 +96,14 @@ def make_band(n, dpx, depth, nloops, seed, res, device):
     ms = []
     # steady state: HIP events around mst_normalize_band (both kernels).  The first calls after the generator run slower (the
     # clocks and the TLB settle over ~4 calls: 3.2, 3.0, 2.9, 2.8, 2.8 ... ms), so 3 more untimed calls precede the median of 5
-    for it in range(8):
+    for it in range(reps):
         del band
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         band, _, _ = normalize_band(raw, n, dpx, res)
         e1.record()
         torch.cuda.synchronize()
-        if it >= 3:
+        if it >= 3 or reps < 4:
             ms.append(e0.elapsed_time(e1))
     return band, sorted(ms)[len(ms) // 2] * 1e-3
 
@@ -142,6 +142,43 @@ class Workload:
         return list(pipe.engine.sigma_loop_band_overlapped(
             self.band, self.n, self.dpx, [[self.start[i] for i in g] for g in groups], self.CH, skip_empty=skip_empty,
             download=download, timing=self.kernel_ms, sort=False, with_value=False, with_q=False, fma=fma))
+
+
+# hg19 chromosome lengths (chr1..22, X, Y), bp: the shape of BASELINE configs 3 and 5 (whole genome at 5 kb)
+HG19 = [249250621, 243199373, 198022430, 191154276, 180915260, 171115067, 159138663, 146364022, 141213431, 135534747,
+        135006516, 133851895, 115169878, 107349540, 102531392, 90354753, 81195210, 78077248, 59128983, 63025520, 48129895,
+        51304566, 155270560, 59373566]
+
+
+class GenomeWorkload(Workload):
+    """All chromosomes of a synthetic hg19-shaped genome at `res` in ONE band (pipeline.GenomeLayout): the blocks of every
+    chromosome go through the same launches.  Same step() as the single-chromosome workload."""
+
+    def __init__(self, name, res, dpx, depth, seed, device, sizes=HG19, two_samples=False):
+        import torch
+        from mustache_amd.pipeline import ChromosomePipeline, GenomeLayout
+        self.name, self.dpx, self.res = name, dpx, res
+        self.pipe = ChromosomePipeline((1.6, 3.2), device=device)
+        ns = [-(-s // res) for s in sizes]
+        self.layout = lay = GenomeLayout(ns, dpx)
+        bands = [[], []]
+        self.normalize_s = 0.0
+        for c, n in enumerate(ns):
+            for smp in range(2 if two_samples else 1):
+                b, t = make_band(n, dpx, depth * (1.0 if smp == 0 else 0.87), max(30, n // 30), seed + 100 * smp + c, res,
+                                 device, reps=1)
+                bands[smp].append(b)
+                self.normalize_s += t
+        self.band = lay.band(bands[0], device)
+        self.band2 = lay.band(bands[1], device) if two_samples else None
+        del bands
+        torch.cuda.empty_cache()
+        self.n, self.CH = lay.N, lay.CH
+        self.start = [g[3] for g in lay.blocks]
+        self.end = None
+        self.mine = list(range(len(self.start)))
+        self.total_mpix = len(self.start) * self.CH * self.CH / 1e6
+        self.kernel_ms = []
 
 
 def _dense_raw_block(w, block_index):
@@ -299,8 +336,15 @@ def main():
                  "speedup": round((dt / args.steps) / (dt_s / max(1, args.steps // 2)), 3),
                  "kernel_ms_per_step": round(sum(kms_s) / max(1, args.steps // 2), 3),
                  "launched_tile_fraction": round(band_tile_fraction(w.CH, w.dpx), 4),
-                 "note": "identical results; only the tiles that can reach the tested band are launched -- the rate counts ALL "
-                         "block pixels, so it is not a roofline figure (value / roofline are always the dense run)"}
+                 "roofline": {"bound": "fp64_valu", "peak": peak_tf, "unit": "TFLOP/s",
+                              "achieved": round(len(w.mine) * w.CH * w.CH * band_tile_fraction(w.CH, w.dpx) * FLOPS_PER_PIXEL
+                                                / (sum(kms_s) / max(1, args.steps // 2) * 1e-3) / 1e12, 3),
+                              "note": "the product mode's own roofline: 1152 algorithmic flops per pixel of the LAUNCHED "
+                                      "tiles (all of them band tiles: real staging, sieve, statistics) over the kernel time"},
+                 "note": "identical results; only the tiles that can reach the tested band are launched -- `value` counts ALL "
+                         "block pixels (the headline value / roofline are always the dense run); band_skip.roofline prices the "
+                         "launched tiles alone"}
+    band_skip["roofline"]["frac"] = round(band_skip["roofline"]["achieved"] / peak_tf, 4)
 
     # opt-in relaxed arithmetic (fused multiply-add per tap pair): DoG no longer bit-identical (~1e-16 relative, north_star
     # allows 1e-5), found set unchanged on every case tested.  Reported separately; `value` is always the exact mode.
@@ -359,13 +403,15 @@ def main():
         # (radii 4, 4, 7, 8: 2 x sum(1 + 3 r) = 146 flops); HBM model of SURVEY 8d: 3 x 384 + 3 x 192 + 2 x 24 = 1776 B per pair
         pair_flops = 2 * FLOPS_PER_PIXEL + 146.0
         frac_tiles = band_tile_fraction(w5.CH, w5.dpx)
+        # the two sigma loops skip the tiles that cannot reach the band, mst_diff_dog_band launches every tile
+        pair_flops_launched = 2 * FLOPS_PER_PIXEL * frac_tiles + 146.0
         out["diff_chr21_5kb"] = {"value": round(pairs_s / 1e6, 1), "unit": "Mpix-pairs/s",
                                  "block_pairs": len(w5.start), "chunk": w5.CH,
                                  "roofline": {"bound": "fp64_valu", "flops_per_pixel_pair": pair_flops,
                                               "launched_tile_fraction": round(frac_tiles, 4),
-                                              "achieved": round(pairs_s * pair_flops * frac_tiles / 1e12, 3),
+                                              "achieved": round(pairs_s * pair_flops_launched / 1e12, 3),
                                               "peak": FP64_PEAK_TFLOPS / 2, "unit": "TFLOP/s",
-                                              "frac": round(pairs_s * pair_flops * frac_tiles / 1e12 / (FP64_PEAK_TFLOPS / 2), 4),
+                                              "frac": round(pairs_s * pair_flops_launched / 1e12 / (FP64_PEAK_TFLOPS / 2), 4),
                                               "hbm_model": {"bytes_per_pixel_pair_model": 1776.0,
                                                             "achieved_equivalent": round(pairs_s * 1776.0 / 1e9, 1),
                                                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -373,11 +419,81 @@ def main():
                                               "note": "whole two-sample call (both sigma loops band-direct, mst_diff_dog_band, pair "
                                                       "p-values, BH + selection q < 0.1 + partner look-ups on the device, selected "
                                                       "records to the host), wall clock.  Empty tiles are skipped, so `achieved` "
-                                                      "counts only the launched share of the tiles (launched_tile_fraction x 2450 "
-                                                      "flops per pixel pair): at this size (6 block pairs, 2.2 ms) the call is "
-                                                      "launch- and latency-bound, not FP64-bound"},
+                                                      "counts only the launched share of the sigma loops' tiles (launched_tile_fraction "
+                                                      "x 2304 + 146 flops per pixel pair): at this size (6 block pairs, 2.2 ms) the call "
+                                                      "is launch- and latency-bound, not FP64-bound -- see diff_genome_5kb"},
                                  "note": "two-sample caller, rows 3-7 for both samples + difference image + pair p-values"}
         del w5, band_b
+        # BASELINE configs 3 and 5: a whole hg19-shaped genome at 5 kb (24 chromosomes, ~390 blocks of 2000 x 2000) with all
+        # chromosomes side by side in one band (pipeline.GenomeLayout) -- every launch carries blocks of many chromosomes
+        wg = GenomeWorkload("hg19-shaped genome @5kb synthetic", 5000, 400, 300.0, 1000, device, two_samples=True)
+        gsteps = 3
+        for _ in range(2):
+            wg.step(False)
+        wg.kernel_ms.clear()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(gsteps):
+            wg.step(False)
+        torch.cuda.synchronize()
+        g_dt = (time.time() - t0) / gsteps
+        g_kms = sum(a.elapsed_time(b) for a, b in wg.kernel_ms) / gsteps
+        wg.step(True)
+        wg.kernel_ms.clear()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(gsteps):
+            wg.step(True)
+        torch.cuda.synchronize()
+        g_dt_s = (time.time() - t0) / gsteps
+        g_kms_s = sum(a.elapsed_time(b) for a, b in wg.kernel_ms) / gsteps
+        g_frac = band_tile_fraction(wg.CH, wg.dpx)
+        g_tf = wg.total_mpix * 1e6 * FLOPS_PER_PIXEL / (g_kms * 1e-3) / 1e12
+        g_tf_s = wg.total_mpix * 1e6 * g_frac * FLOPS_PER_PIXEL / (g_kms_s * 1e-3) / 1e12
+        wg.pipe.run_layout(wg.layout, wg.band, 0.88, 0.1)
+        tmg = {}
+        t0 = time.time()
+        gl = wg.pipe.run_layout(wg.layout, wg.band, 0.88, 0.1, timings=tmg)
+        g_e2e = time.time() - t0
+        out["genome_5kb"] = {"value": round(wg.total_mpix / g_dt, 1), "unit": "Mpix/s", "chromosomes": len(HG19),
+                             "blocks": len(wg.start), "chunk": wg.CH, "band_columns": wg.n,
+                             "megapixels_per_step": round(wg.total_mpix, 1), "ms_per_step": round(g_dt * 1e3, 3),
+                             "vs_chr1_1kb_value": round(wg.total_mpix / g_dt / value, 4),
+                             "roofline": {"bound": "fp64_valu", "achieved": round(g_tf, 3), "peak": peak_tf, "unit": "TFLOP/s",
+                                          "frac": round(g_tf / peak_tf, 4), "kernel_ms_per_step": round(g_kms, 3)},
+                             "band_skip": {"value": round(wg.total_mpix / g_dt_s, 1), "unit": "Mpix/s",
+                                           "launched_tile_fraction": round(g_frac, 4),
+                                           "roofline": {"bound": "fp64_valu", "achieved": round(g_tf_s, 3), "peak": peak_tf,
+                                                        "unit": "TFLOP/s", "frac": round(g_tf_s / peak_tf, 4),
+                                                        "kernel_ms_per_step": round(g_kms_s, 3)}},
+                             "end_to_end": {"rows_2_to_9_s": round(g_e2e, 3), "tail_s": round(tmg.get("tail_s", 0.0), 3),
+                                            "launches": tmg.get("launches"), "loops": sum(len(o) for o in gl),
+                                            "normalize_s_all_chromosomes": round(wg.normalize_s, 4)},
+                             "note": "same timed region as `value` (dense step: fused kernel, p-values, found records to the "
+                                     "host), all chromosomes' blocks batched into the same launches; band_skip / end_to_end = "
+                                     "the product mode (tile lists; + BH, selection, filters, clustering, overlap masks)"}
+        # two-sample whole genome (config 5): every block pair of every chromosome in ONE run_band_pairs call
+        eng = wg.pipe.engine
+        for _ in range(2):
+            eng.run_band_pairs([wg.band, wg.band2], wg.n, wg.dpx, wg.start, wg.CH, select_below=0.1)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(gsteps):
+            eng.run_band_pairs([wg.band, wg.band2], wg.n, wg.dpx, wg.start, wg.CH, select_below=0.1)
+        torch.cuda.synchronize()
+        gp_s = wg.total_mpix * 1e6 / ((time.time() - t0) / gsteps)
+        gp_flops = 2 * FLOPS_PER_PIXEL * g_frac + 146.0
+        out["diff_genome_5kb"] = {"value": round(gp_s / 1e6, 1), "unit": "Mpix-pairs/s", "block_pairs": len(wg.start),
+                                  "chunk": wg.CH, "chromosomes": len(HG19),
+                                  "roofline": {"bound": "fp64_valu", "flops_per_pixel_pair_launched": round(gp_flops, 1),
+                                               "launched_tile_fraction": round(g_frac, 4),
+                                               "achieved": round(gp_s * gp_flops / 1e12, 3), "peak": peak_tf,
+                                               "unit": "TFLOP/s", "frac": round(gp_s * gp_flops / 1e12 / peak_tf, 4)},
+                                  "note": "two-sample caller over the whole genome in one call (both sigma loops with tile "
+                                          "lists, mst_diff_dog_band over all tiles, pair p-values, BH + selection + partner "
+                                          "look-ups on the device, selected records to the host), wall clock"}
+        del wg, eng
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1:
         # informational: the whole per-chromosome run from the normalised band (rows 2-9, empty tiles skipped as the
         # pipeline does by default), next to the untimed normalisation -- NOT part of `value`

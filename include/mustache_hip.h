@@ -181,6 +181,13 @@ int mst_diag_means(const double *c, int32_t CH, int32_t b, const int32_t *diag_k
 int mst_band_from_coo(const int64_t *x, const int64_t *y, const double *v, int64_t nnz, int64_t n, int32_t dpx,
                       double *band, void *stream);
 
+/* The same scatter from the packed records of the native `.hic` reader (include/mustache_io.h,
+ * mst_hic_read_intra_packed: binX, binY - binX >= 0, float32 value; dev arrays): band[dist][x] = (double)v.  What
+ * read_hic_file() -> `cc[xc, yc] = vc` amounts to (mustache.py:300-396, :921-924) without an int64 / float64 COO triple on
+ * the host or across PCIe.  band is zero-filled first; records with dist > dpx + 1 are ignored. */
+int mst_band_from_packed(const int32_t *x, const int32_t *dist, const float *v, int64_t nnz, int64_t n, int32_t dpx,
+                         double *band, void *stream);
+
 /* band -> COO order: v[e] = band[|y-x|][min(x, y)]  (the `v[indices] = vals[x[indices]]` write-back, :669). */
 int mst_band_to_coo(const double *band, const int64_t *x, const int64_t *y, int64_t nnz, int64_t n, int32_t dpx,
                     double *v, void *stream);

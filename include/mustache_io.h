@@ -72,6 +72,15 @@ int32_t mst_hic_resolution(const mst_hic *h, int32_t i);
 int64_t mst_hic_read_intra(mst_hic *h, const char *chrom, int32_t resolution, const char *norm, int64_t max_dist_bins,
                            int32_t n_threads, int64_t **x, int64_t **y, double **v);
 
+/* The same records in the form the GPU loader takes (mst_band_from_packed, include/mustache_hip.h): binX as int32, the
+ * distance binY - binX (>= 0) as int32 and the value as the float32 straw computes -- 12 bytes per record instead of 24, no
+ * int64 / float64 widening on the host.  chrom_size_bp > 0 additionally drops records with binY * resolution >= the size
+ * (the end of straw's last window when the caller passes the chromosome size, mustache.py:320-333).  *n_bins receives
+ * max(binY) + 1 over the returned records = the `n` of mustache.py:894.  Arrays are malloc'ed (mst_io_free). */
+int64_t mst_hic_read_intra_packed(mst_hic *h, const char *chrom, int32_t resolution, const char *norm, int64_t max_dist_bins,
+                                  int64_t chrom_size_bp, int32_t n_threads, int32_t **x, int32_t **dist, float **v,
+                                  int64_t *n_bins);
+
 /* ---- text contact maps ------------------------------------------------------------------------------------------------
  * The parse step of read_pd() (reference mustache/mustache.py:254-258): `pd.read_csv(f, sep=sep, header=None)` followed
  * by `df.dropna()`, for the two layouts the reference accepts -- 3 columns (pos1 pos2 count) or 5 columns (chr1 pos1 chr2

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "mst_candidate_features": (ctypes.c_int, [_p, _p, _i32, _i32, _p, _p, _i32, _p, _p, _p, _p]),
     "mst_gather_diagonals": (ctypes.c_int, [_p, _i32, _i32, _p, _i32, _p, _p]),
     "mst_band_from_coo": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
+    "mst_band_from_packed": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
     "mst_band_to_coo": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
     "mst_normalize_band": (ctypes.c_int, [_p, _p, _i64, _i32, _i32, _i32, _p, _p]),
     "mst_blocks_from_band": (ctypes.c_int, [_p, _i64, _i32, ctypes.POINTER(_i64), _i32, _i32, _p, _p, _p, _p]),

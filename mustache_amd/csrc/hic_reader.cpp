@@ -465,69 +465,97 @@ extern "C" int32_t mst_hic_resolution(const mst_hic *h, int32_t i) {
     return (h && i >= 0 && (size_t)i < h->bp_res.size()) ? h->bp_res[(size_t)i] : 0;
 }
 
+// Shared body of the two record readers: every near-diagonal block of the chromosome's intra matrix inflated and decoded on
+// the worker threads, one Records per block in file block order.  Returns 0 or an MST_IO_E_* code (message set).
+static int read_intra_parts(mst_hic *h, const char *chrom, int32_t resolution, const char *norm, int64_t max_dist_bins,
+                            int32_t n_threads, std::vector<Records> &part, int *threads_used) {
+    const int ci = find_chromosome(h, chrom);
+    if (ci < 0) return fail(MST_IO_E_NOTFOUND, "chromosome %s is not in the file", chrom);
+    const std::string key = std::to_string(ci) + "_" + std::to_string(ci);
+    auto it = h->matrices.find(key);
+    if (it == h->matrices.end()) return fail(MST_IO_E_NOTFOUND, "no intra-chromosomal matrix for %s", chrom);
+    ZoomData z = read_zoom(h, it->second.first, resolution);
+    if (!z.found) return fail(MST_IO_E_NOTFOUND, "resolution %d is not in the file", resolution);
+
+    std::vector<double> norm_vec;
+    const bool use_norm = norm && *norm && strcmp(norm, "NONE") != 0;
+    if (use_norm) {
+        read_norm_index(h);
+        auto nit = h->norm_index.find(norm_key(norm, ci, "BP", resolution));
+        if (nit == h->norm_index.end())
+            return fail(MST_IO_E_NOTFOUND, "no %s normalisation vector for %s at %d bp", norm, chrom, resolution);
+        norm_vec = read_norm_vector(h, nit->second);
+    }
+
+    std::vector<const BlockRef *> todo;
+    for (const BlockRef &b : z.blocks) {
+        if (b.size <= 0) continue;
+        if (b.pos < 0 || (uint64_t)b.pos + (uint64_t)b.size > h->size) throw FormatError{"block outside the file"};
+        if (block_near_diagonal(h->version, b.number, z.block_bin_count, z.block_column_count, max_dist_bins))
+            todo.push_back(&b);
+    }
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if ((size_t)nt > todo.size()) nt = todo.empty() ? 1 : (int)todo.size();
+    part.assign(todo.size(), Records());
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    const char *bad_what = nullptr;
+    auto work = [&]() {
+        std::vector<uint8_t> buf;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= todo.size() || bad.load()) return;
+            try {
+                decode_block(h->version, h->map + todo[i]->pos, (size_t)todo[i]->size, buf, part[i],
+                             use_norm ? &norm_vec : nullptr, max_dist_bins);
+            } catch (const FormatError &e) {
+                bad_what = e.what;
+                bad.store(1);
+                return;
+            } catch (...) {
+                bad_what = "out of memory";
+                bad.store(1);
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    if (bad.load()) return fail(MST_IO_E_ZLIB, "block decode failed: %s", bad_what ? bad_what : "?");
+    *threads_used = nt;
+    return MST_IO_OK;
+}
+
+// run `fn(i)` for i in [0, n) on nt threads (dynamic dealing)
+template <class F>
+static void parallel_for(size_t n, int nt, F fn) {
+    std::atomic<size_t> next(0);
+    auto body = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n) return;
+            fn(i);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(body);
+    body();
+    for (auto &t : pool) t.join();
+}
+
 extern "C" int64_t mst_hic_read_intra(mst_hic *h, const char *chrom, int32_t resolution, const char *norm,
                                       int64_t max_dist_bins, int32_t n_threads, int64_t **x, int64_t **y, double **v) {
     if (!h || !chrom || !x || !y || !v || resolution <= 0) return fail(MST_IO_E_ARG, "mst_hic_read_intra: bad argument");
     *x = *y = nullptr;
     *v = nullptr;
     try {
-        const int ci = find_chromosome(h, chrom);
-        if (ci < 0) return fail(MST_IO_E_NOTFOUND, "chromosome %s is not in the file", chrom);
-        const std::string key = std::to_string(ci) + "_" + std::to_string(ci);
-        auto it = h->matrices.find(key);
-        if (it == h->matrices.end()) return fail(MST_IO_E_NOTFOUND, "no intra-chromosomal matrix for %s", chrom);
-        ZoomData z = read_zoom(h, it->second.first, resolution);
-        if (!z.found) return fail(MST_IO_E_NOTFOUND, "resolution %d is not in the file", resolution);
-
-        std::vector<double> norm_vec;
-        const bool use_norm = norm && *norm && strcmp(norm, "NONE") != 0;
-        if (use_norm) {
-            read_norm_index(h);
-            auto nit = h->norm_index.find(norm_key(norm, ci, "BP", resolution));
-            if (nit == h->norm_index.end())
-                return fail(MST_IO_E_NOTFOUND, "no %s normalisation vector for %s at %d bp", norm, chrom, resolution);
-            norm_vec = read_norm_vector(h, nit->second);
-        }
-
-        std::vector<const BlockRef *> todo;
-        for (const BlockRef &b : z.blocks) {
-            if (b.size <= 0) continue;
-            if (b.pos < 0 || (uint64_t)b.pos + (uint64_t)b.size > h->size) throw FormatError{"block outside the file"};
-            if (block_near_diagonal(h->version, b.number, z.block_bin_count, z.block_column_count, max_dist_bins))
-                todo.push_back(&b);
-        }
-        int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
-        if (nt < 1) nt = 1;
-        if ((size_t)nt > todo.size()) nt = todo.empty() ? 1 : (int)todo.size();
-        std::vector<Records> part(todo.size());
-        std::atomic<size_t> next(0);
-        std::atomic<int> bad(0);
-        const char *bad_what = nullptr;
-        auto work = [&]() {
-            std::vector<uint8_t> buf;
-            for (;;) {
-                const size_t i = next.fetch_add(1);
-                if (i >= todo.size() || bad.load()) return;
-                try {
-                    decode_block(h->version, h->map + todo[i]->pos, (size_t)todo[i]->size, buf, part[i],
-                                 use_norm ? &norm_vec : nullptr, max_dist_bins);
-                } catch (const FormatError &e) {
-                    bad_what = e.what;
-                    bad.store(1);
-                    return;
-                } catch (...) {
-                    bad_what = "out of memory";
-                    bad.store(1);
-                    return;
-                }
-            }
-        };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
-        if (bad.load()) return fail(MST_IO_E_ZLIB, "block decode failed: %s", bad_what ? bad_what : "?");
-
+        std::vector<Records> part;
+        int nt = 1;
+        const int rc = read_intra_parts(h, chrom, resolution, norm, max_dist_bins, n_threads, part, &nt);
+        if (rc != MST_IO_OK) return rc;
         std::vector<size_t> offs(part.size() + 1, 0);
         for (size_t i = 0; i < part.size(); ++i) offs[i + 1] = offs[i] + part[i].v.size();
         const size_t total = offs[part.size()];
@@ -541,28 +569,91 @@ extern "C" int64_t mst_hic_read_intra(mst_hic *h, const char *chrom, int32_t res
             return fail(MST_IO_E_FILE, "out of memory for %zu records", total);
         }
         // concatenate in file block order (deterministic), the copies spread over the same worker threads
-        next.store(0);
-        auto gather = [&]() {
-            for (;;) {
-                const size_t i = next.fetch_add(1);
-                if (i >= part.size()) return;
-                Records &r = part[i];
-                if (r.v.empty()) continue;
-                memcpy(ox + offs[i], r.x.data(), r.v.size() * sizeof(int64_t));
-                memcpy(oy + offs[i], r.y.data(), r.v.size() * sizeof(int64_t));
-                memcpy(ov + offs[i], r.v.data(), r.v.size() * sizeof(double));
-                std::vector<int64_t>().swap(r.x);                      // release the block's buffers as we go
-                std::vector<int64_t>().swap(r.y);
-                std::vector<double>().swap(r.v);
-            }
-        };
-        pool.clear();
-        for (int t = 1; t < nt; ++t) pool.emplace_back(gather);
-        gather();
-        for (auto &t : pool) t.join();
+        parallel_for(part.size(), nt, [&](size_t i) {
+            Records &r = part[i];
+            if (r.v.empty()) return;
+            memcpy(ox + offs[i], r.x.data(), r.v.size() * sizeof(int64_t));
+            memcpy(oy + offs[i], r.y.data(), r.v.size() * sizeof(int64_t));
+            memcpy(ov + offs[i], r.v.data(), r.v.size() * sizeof(double));
+            std::vector<int64_t>().swap(r.x);                      // release the block's buffers as we go
+            std::vector<int64_t>().swap(r.y);
+            std::vector<double>().swap(r.v);
+        });
         *x = ox;
         *y = oy;
         *v = ov;
+        return (int64_t)total;
+    } catch (const FormatError &e) {
+        return fail(MST_IO_E_FORMAT, "%s", e.what);
+    } catch (...) {
+        return fail(MST_IO_E_FORMAT, "unreadable file (out of memory?)");
+    }
+}
+
+extern "C" int64_t mst_hic_read_intra_packed(mst_hic *h, const char *chrom, int32_t resolution, const char *norm,
+                                             int64_t max_dist_bins, int64_t chrom_size_bp, int32_t n_threads,
+                                             int32_t **x, int32_t **dist, float **v, int64_t *n_bins) {
+    if (!h || !chrom || !x || !dist || !v || !n_bins || resolution <= 0)
+        return fail(MST_IO_E_ARG, "mst_hic_read_intra_packed: bad argument");
+    *x = *dist = nullptr;
+    *v = nullptr;
+    *n_bins = 0;
+    try {
+        std::vector<Records> part;
+        int nt = 1;
+        const int rc = read_intra_parts(h, chrom, resolution, norm, max_dist_bins, n_threads, part, &nt);
+        if (rc != MST_IO_OK) return rc;
+        // straw's window end (mustache.py:320-333): no position at or past the chromosome size the caller gave
+        const int64_t y_limit = chrom_size_bp > 0 ? (chrom_size_bp + resolution - 1) / resolution : INT64_MAX;
+        std::vector<size_t> keep(part.size(), 0);
+        std::vector<int64_t> ymax(part.size(), -1);
+        parallel_for(part.size(), nt, [&](size_t i) {
+            const Records &r = part[i];
+            size_t k = 0;
+            int64_t m = -1;
+            for (size_t e = 0; e < r.v.size(); ++e)
+                if (r.y[e] < y_limit) {
+                    ++k;
+                    m = r.y[e] > m ? r.y[e] : m;
+                }
+            keep[i] = k;
+            ymax[i] = m;
+        });
+        std::vector<size_t> offs(part.size() + 1, 0);
+        int64_t top = -1;
+        for (size_t i = 0; i < part.size(); ++i) {
+            offs[i + 1] = offs[i] + keep[i];
+            top = ymax[i] > top ? ymax[i] : top;
+        }
+        if (top >= INT32_MAX) return fail(MST_IO_E_FORMAT, "bin index %lld does not fit 32 bits", (long long)top);
+        const size_t total = offs[part.size()];
+        int32_t *ox = (int32_t *)malloc((total ? total : 1) * sizeof(int32_t));
+        int32_t *od = (int32_t *)malloc((total ? total : 1) * sizeof(int32_t));
+        float *ov = (float *)malloc((total ? total : 1) * sizeof(float));
+        if (!ox || !od || !ov) {
+            free(ox);
+            free(od);
+            free(ov);
+            return fail(MST_IO_E_FILE, "out of memory for %zu records", total);
+        }
+        parallel_for(part.size(), nt, [&](size_t i) {
+            Records &r = part[i];
+            size_t o = offs[i];
+            for (size_t e = 0; e < r.v.size(); ++e)
+                if (r.y[e] < y_limit) {
+                    ox[o] = (int32_t)r.x[e];
+                    od[o] = (int32_t)(r.y[e] - r.x[e]);
+                    ov[o] = (float)r.v[e];             // exact: the values are straw's float32 results held in doubles
+                    ++o;
+                }
+            std::vector<int64_t>().swap(r.x);
+            std::vector<int64_t>().swap(r.y);
+            std::vector<double>().swap(r.v);
+        });
+        *x = ox;
+        *dist = od;
+        *v = ov;
+        *n_bins = top + 1;
         return (int64_t)total;
     } catch (const FormatError &e) {
         return fail(MST_IO_E_FORMAT, "%s", e.what);

@@ -36,6 +36,18 @@ band_scatter_kernel(const int64_t *__restrict__ x, const int64_t *__restrict__ y
     }
 }
 
+// the `.hic` reader's packed records (include/mustache_io.h, mst_hic_read_intra_packed): x = binX, dist = binY - binX >= 0,
+// value = the float32 straw computes; 12 bytes per record
+__global__ void __launch_bounds__(kThreads)
+band_scatter_packed_kernel(const int32_t *__restrict__ x, const int32_t *__restrict__ dist, const float *__restrict__ v,
+                           int64_t nnz, int64_t n, int dpx, double *__restrict__ band) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride) {
+        const int64_t lo = x[e], d = dist[e];
+        if (d >= 0 && d <= dpx + 1 && lo >= 0 && lo + d < n) band[d * n + lo] = (double)v[e];
+    }
+}
+
 __global__ void __launch_bounds__(kThreads)
 band_gather_kernel(const double *__restrict__ band, const int64_t *__restrict__ x, const int64_t *__restrict__ y,
                    int64_t nnz, int64_t n, int dpx, double *__restrict__ v) {
@@ -790,6 +802,19 @@ extern "C" int mst_band_from_coo(const int64_t *x, const int64_t *y, const doubl
     if (nnz == 0) return MST_OK;
     int64_t want = (nnz + kThreads - 1) / kThreads;
     band_scatter_kernel<<<(int)(want < 65536 ? want : 65536), kThreads, 0, s>>>(x, y, v, nnz, n, dpx, band);
+    MST_LAUNCH_CHECK();
+    return MST_OK;
+}
+
+extern "C" int mst_band_from_packed(const int32_t *x, const int32_t *dist, const float *v, int64_t nnz, int64_t n,
+                                    int32_t dpx, double *band, void *stream) {
+    if (!band || n <= 0 || dpx < 0 || nnz < 0 || (nnz > 0 && (!x || !dist || !v)))
+        return mst::fail(MST_E_ARG, "mst_band_from_packed: bad argument");
+    hipStream_t s = mst::as_stream(stream);
+    MST_HIP(hipMemsetAsync(band, 0, sizeof(double) * (size_t)(dpx + 2) * n, s));
+    if (nnz == 0) return MST_OK;
+    int64_t want = (nnz + kThreads - 1) / kThreads;
+    band_scatter_packed_kernel<<<(int)(want < 65536 ? want : 65536), kThreads, 0, s>>>(x, dist, v, nnz, n, dpx, band);
     MST_LAUNCH_CHECK();
     return MST_OK;
 }

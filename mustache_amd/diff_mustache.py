@@ -108,49 +108,67 @@ def _append_tagged(o, res4, start_i, mask_size):
                 o.append([loop[0], loop[1], loop[2], loop[3], tag])
 
 
-def call_diff_loops_coo(coo1, coo2, res, distance_in_px, octave_values, st, pt, pt2, verbose=True):
-    """regulator's body after the readers (diff_mustache.py:628-685): normalise both samples on the GPU, cut the same
-    tiling out of both bands, run all block pairs."""
+def normalized_pair_bands(pipe, coo1, coo2, res, distance_in_px):
+    """Both samples' normalised bands over the common width n = max(n1, n2) (diff_mustache.py:628-635): each sample is
+    normalised with ITS OWN n, blocks are cut with the common one."""
     import torch
     from .normalize import band_from_host_coo, normalize_band
-    from .pipeline import ChromosomePipeline
-    pipe = ChromosomePipeline(octave_values)
-    eng, dev = pipe.engine, pipe.device
-    ns, bands = [], []
+    dev = pipe.device
+    ns, coos = [], []
     for (x, y, v) in (coo1, coo2):
         x = np.ascontiguousarray(np.asarray(x), dtype=np.int64)
         y = np.ascontiguousarray(np.asarray(y), dtype=np.int64)
         v = np.ascontiguousarray(np.asarray(v), dtype=np.float64)
         ns.append(int(max(x.max(), y.max())) + 1)                          # (:630-631)
-        bands.append((x, y, v))
+        coos.append((x, y, v))
     n = max(ns)                                                            # (:632)
     dbands = []
-    for (x, y, v), n_s in zip(bands, ns):
-        band = band_from_host_coo(x, y, v, n_s, distance_in_px, dev)       # each sample is normalised with ITS OWN n
+    for (x, y, v), n_s in zip(coos, ns):
+        band = band_from_host_coo(x, y, v, n_s, distance_in_px, dev)
         band, _, _ = normalize_band(band, n_s, distance_in_px, res)       # (:634-635 -> mustache.py:623)
-        if n_s < n:                                                        # blocks are cut with the common n
+        if n_s < n:
             pad = torch.zeros((distance_in_px + 2, n), dtype=torch.float64, device=dev)
             pad[:, :n_s] = band
             band = pad
         dbands.append(band)
-    CH, start, end = block_tiling(n, distance_in_px)                       # (:637-651)
+    return dbands, n
+
+
+def run_pair_genome(pipe, pairs, distance_in_px, st, pt, pt2):
+    """pairs: [(dbands, n)] per chromosome (normalized_pair_bands).  ALL block pairs of all chromosomes go through the same
+    launches: the two samples' bands are laid side by side per chromosome (pipeline.GenomeLayout) and every group of block
+    pairs is one engine.run_band_pairs call.  Returns the tagged rows [x, y, fdr, sigma, tag] per chromosome, identical to
+    call_diff_loops_coo on each chromosome alone."""
+    from .pipeline import GenomeLayout
+    eng = pipe.engine
+    lay = GenomeLayout([n for _, n in pairs], distance_in_px)
+    CH = lay.CH
+    gbands = [lay.band([d[s_] for d, _ in pairs], pipe.device) for s_ in (0, 1)]
+    # per block pair in HBM: D_2 of the difference image for every octave + the two samples' record buffers
+    per_pair = len(eng.levels.octave_values) * CH * CH * 8 + 2 * max(4096, CH * CH // 32) * 48
+    bs = max(1, int(pipe.max_batch_bytes // per_pair))
+    out = [[] for _ in pairs]
+    for g0 in range(0, len(lay.blocks), bs):
+        grp = lay.blocks[g0:g0 + bs]
+        batch = eng.run_band_pairs(gbands, lay.N, distance_in_px, [g[3] for g in grp], CH, select_below=pt)
+        P = len(grp)
+        for j, (c, i, s_loc, _) in enumerate(grp):
+            _, start, end = lay.tiling[c]
+            mask = block_mask_size(i, start, end, distance_in_px)
+            _append_tagged(out[c], _pair_tail(batch, j, P + j, s_loc, pt, pt2, st, True), s_loc, mask)
+        del batch
+    return out
+
+
+def call_diff_loops_coo(coo1, coo2, res, distance_in_px, octave_values, st, pt, pt2, verbose=True):
+    """regulator's body after the readers (diff_mustache.py:628-685): normalise both samples on the GPU, cut the same
+    tiling out of both bands, run all block pairs."""
+    from .pipeline import ChromosomePipeline
+    pipe = ChromosomePipeline(octave_values)
+    dbands, n = normalized_pair_bands(pipe, coo1, coo2, res, distance_in_px)
     if verbose:
         print("Loop calling...")
-    # per block pair in HBM: D_2 of the difference image for every octave + the two samples' record buffers
-    per_pair = len(octave_values) * CH * CH * 8 + 2 * max(4096, CH * CH // 32) * 48
-    bs = max(1, int(pipe.max_batch_bytes // per_pair))
-    o = []
-    idx = list(range(len(start)))
-    for g0 in range(0, len(idx), bs):
-        grp = idx[g0:g0 + bs]
-        st_g = [start[i] for i in grp]
-        batch = _pairs_from_filled(eng, pipe, dbands, n, distance_in_px, st_g, CH, pt=pt)
-        P = len(grp)
-        for j, i in enumerate(grp):
-            mask = block_mask_size(i, start, end, distance_in_px)
-            _append_tagged(o, _pair_tail(batch, j, P + j, start[i], pt, pt2, st, True), start[i], mask)
-        del batch
-    return o
+    return run_pair_genome(pipe, [(dbands, n)], distance_in_px, st, pt, pt2)[0]
 
 
 def _pairs_from_filled(eng, pipe, dbands, n, dpx, starts, CH, dense=False, pt=None):
@@ -177,16 +195,12 @@ def _pairs_from_filled(eng, pipe, dbands, n, dpx, starts, CH, dense=False, pt=No
     return batch
 
 
-def regulator(f1, f2, norm_method, CHRM_SIZE, outdir, bed1="", bed2="", res=5000, sigma0=1.6, s=10, pt=0.1, pt2=0.1,
-              st=0.88, octaves=2, verbose=True, nprocesses=4, distance_filter=2000000, bias1=False, bias2=False,
-              chromosome='n', chromosome2=None):
-    """Two-sample loop calling for one chromosome (diff_mustache.py:572-690); returns [x, y, fdr, sigma, tag] rows."""
+def read_pair(f1, f2, norm_method, CHRM_SIZE, res, distance_in_bp, bias1, bias2, chromosome, chromosome2, verbose=True):
+    """The reading half of regulator() (diff_mustache.py:591-626): -> (coo1, coo2, res) or None when a sample is empty."""
     if not chromosome2 or chromosome2 == 'n':
         chromosome2 = chromosome
     if chromosome != chromosome2:
         raise NotImplementedError("inter-chromosomal mode is non-functional in the reference (diff_mustache.py:687-690)")
-    octave_values = [sigma0 * (2 ** i) for i in range(octaves)]
-    distance_in_bp = distance_filter
     if verbose:
         print("Reading contact map...")
     coos = []
@@ -207,11 +221,23 @@ def regulator(f1, f2, norm_method, CHRM_SIZE, outdir, bed1="", bed2="", res=5000
             coo = read_pd(f, distance_in_bp, bias, chromosome, res)
         coos.append(coo)
     if coos[0] is None or coos[1] is None or len(coos[0][2]) == 0 or len(coos[1][2]) == 0:
+        return None
+    return coos[0], coos[1], res
+
+
+def regulator(f1, f2, norm_method, CHRM_SIZE, outdir, bed1="", bed2="", res=5000, sigma0=1.6, s=10, pt=0.1, pt2=0.1,
+              st=0.88, octaves=2, verbose=True, nprocesses=4, distance_filter=2000000, bias1=False, bias2=False,
+              chromosome='n', chromosome2=None):
+    """Two-sample loop calling for one chromosome (diff_mustache.py:572-690); returns [x, y, fdr, sigma, tag] rows."""
+    octave_values = [sigma0 * (2 ** i) for i in range(octaves)]
+    got = read_pair(f1, f2, norm_method, CHRM_SIZE, res, distance_filter, bias1, bias2, chromosome, chromosome2, verbose)
+    if got is None:
         return []
+    coo1, coo2, res = got
     if verbose:
         print("Normalizing contact map...")
-    distance_in_px = int(math.ceil(distance_in_bp // res))
-    return call_diff_loops_coo(coos[0], coos[1], res, distance_in_px, octave_values, st, pt, pt2, verbose=verbose)
+    distance_in_px = int(math.ceil(distance_filter // res))
+    return call_diff_loops_coo(coo1, coo2, res, distance_in_px, octave_values, st, pt, pt2, verbose=verbose)
 
 
 def parse_args(args):
@@ -335,12 +361,10 @@ def main(argv=None):
         return counts
 
     results = {}
-    for i in mine:
-        chromosome, chromosome2 = pairs[i]
-        o = regulator(f1, f2, args.norm_method, False, args.outdir, bed1=args.bed1, bed2=args.bed2, res=res,
-                      sigma0=args.s_z, s=args.s, verbose=args.verbose, pt=args.pt, pt2=args.pt2, st=args.st,
-                      distance_filter=distFilter, nprocesses=args.nprocesses, bias1=biasf1, bias2=biasf2,
-                      chromosome=chromosome, chromosome2=chromosome2, octaves=args.octaves)
+
+    def emit(i, o):
+        nonlocal t0
+        chromosome = pairs[i][0]
         if world_size > 1:
             results[i] = o
             counts = {t: sum(1 for r in o if r[4] == t) for t in (1, 2, 3, 4)}
@@ -349,6 +373,50 @@ def main(argv=None):
         print(f"({counts[1]},{counts[3]}) loops and ({counts[2]},{counts[4]}) differential-loops found in "
               f"chrmosome={chromosome} for detection-fdr<{args.pt} and difference-fdr<{args.pt2} in {time.time() - t0:.2f}sec")
         t0 = time.time()
+
+    # Several chromosomes on this rank (the whole-genome run of BASELINE config 5): both samples' normalised bands are
+    # collected in HBM and the block pairs of ALL chromosomes go through the same launches (run_pair_genome); the reference
+    # runs chromosome after chromosome (diff_mustache.py:858-906).  Same rows, in the same chromosome order.
+    batched = len(mine) > 1
+    genome_budget = int(os.environ.get("MUSTACHE_GENOME_BATCH_GB", "64")) << 30
+    held, held_bytes, pipe = [], 0, None
+
+    def flush():
+        nonlocal held, held_bytes
+        if held:
+            rows = run_pair_genome(pipe, [(h[1], h[2]) for h in held], held[0][3], args.st, args.pt, args.pt2)
+            for (i, _, _, _), o in zip(held, rows):
+                emit(i, o)
+        held, held_bytes = [], 0
+
+    for i in mine:
+        chromosome, chromosome2 = pairs[i]
+        if not batched:
+            emit(i, regulator(f1, f2, args.norm_method, False, args.outdir, bed1=args.bed1, bed2=args.bed2, res=res,
+                              sigma0=args.s_z, s=args.s, verbose=args.verbose, pt=args.pt, pt2=args.pt2, st=args.st,
+                              distance_filter=distFilter, nprocesses=args.nprocesses, bias1=biasf1, bias2=biasf2,
+                              chromosome=chromosome, chromosome2=chromosome2, octaves=args.octaves))
+            continue
+        got = read_pair(f1, f2, args.norm_method, False, res, distFilter, biasf1, biasf2, chromosome, chromosome2,
+                        args.verbose)
+        if got is None:
+            flush()                               # keeps the output in chromosome order
+            emit(i, [])
+            continue
+        if pipe is None:
+            from .pipeline import ChromosomePipeline
+            pipe = ChromosomePipeline([args.s_z * (2 ** o_) for o_ in range(args.octaves)])
+        coo1, coo2, res_c = got
+        dpx = int(math.ceil(distFilter // res_c))
+        if args.verbose:
+            print("Normalizing contact map...")
+        dbands, n = normalized_pair_bands(pipe, coo1, coo2, res_c, dpx)
+        nbytes = sum(b.numel() * 8 for b in dbands)
+        if held and (held[0][3] != dpx or held_bytes + nbytes > genome_budget):
+            flush()
+        held.append((i, dbands, n, dpx))
+        held_bytes += nbytes
+    flush()
     if world_size > 1:
         rec = np.array([[i, float(r[0]), float(r[1]), float(r[2]), float(r[3]), float(r[4])]
                         for i, o in results.items() for r in o], dtype=np.float64).reshape(-1, 6)

@@ -246,13 +246,20 @@ def _check_pair(f, chromosome, chromosome2):
     return chromosome2
 
 
-def read_contacts(f, norm_method, CHRM_SIZE, res, distance_filter, bias, chromosome, chromosome2, verbose=True):
+def read_contacts(f, norm_method, CHRM_SIZE, res, distance_filter, bias, chromosome, chromosome2, verbose=True,
+                  packed=False):
     """The reading half of regulator() (reference mustache.py:866-889): host I/O only, so main() can fetch the next
-    chromosome while the GPU works on the current one.  Returns (x, y, v, res) or None when nothing was read."""
+    chromosome while the GPU works on the current one.  Returns (x, y, v, res) or None when nothing was read.
+    packed=True: a `.hic` file read by the native reader comes back as hicfile.PackedContacts (12 bytes per record, what
+    the GPU loader takes) instead of the int64 / float64 triple."""
     chromosome2 = _check_pair(f, chromosome, chromosome2)
     distance_in_bp = distance_filter
     if verbose:
         print("Reading contact map...")
+    if f.endswith(".hic") and packed:
+        from .readers import hic_backend, read_hic_packed
+        if hic_backend() == "native":
+            return read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chromosome, res)
     if f.endswith(".hic"):
         from .readers import read_hic_file
         x, y, v = read_hic_file(f, norm_method, CHRM_SIZE, distance_in_bp, chromosome, chromosome2, res)
@@ -285,6 +292,12 @@ def regulator(f, norm_method, CHRM_SIZE, outdir, bed="", res=5000, sigma0=1.6, s
         contacts = read_contacts(f, norm_method, CHRM_SIZE, res, distance_filter, bias, chromosome, chromosome2, verbose)
         if contacts is None:
             return []
+    from .hicfile import PackedContacts
+    if isinstance(contacts, PackedContacts):
+        from .pipeline import ChromosomePipeline
+        distance_in_px = int(math.ceil(distance_filter // contacts.res))
+        return ChromosomePipeline(octave_values).run_packed(contacts, distance_in_px, st, pt, verbose=verbose,
+                                                            distributed=shard_blocks)
     x, y, v, res = contacts
     distance_in_px = int(math.ceil(distance_filter // res))
     return call_loops_coo(x, y, v, res, distance_in_px, octave_values, st, pt, chromosome, chromosome2, verbose=verbose,
@@ -416,7 +429,7 @@ def main(argv=None):
         CHRM_SIZE = chrSize_in_bp["chr" + str(chromosome).replace('chr', '')] if chrSize_in_bp else False
         try:
             return read_contacts(f, args.norm_method, CHRM_SIZE, res, distFilter, biasf, chromosome, chromosome2,
-                                 verbose=args.verbose)
+                                 verbose=args.verbose, packed=True)
         except BaseException as e:          # re-raised in the main thread, at this chromosome's turn
             return e
 
@@ -437,6 +450,34 @@ def main(argv=None):
     # the current one -- the reference reads and computes strictly in turn (mustache.py:1057-1080)
     from concurrent.futures import ThreadPoolExecutor
     results = {}
+
+    def emit(i, o):
+        nonlocal start_time
+        chromosome, chromosome2 = pairs[i]
+        print("{0} loops found for chrmosome={1}, fdr<{2} in {3}sec".format(
+            len(o), chromosome, args.pt, "%.2f" % (time.time() - start_time)))
+        if by_chromosome:
+            results[i] = o
+        elif rank == 0 and (i == 0 or o):
+            write_loops(args.outdir, chromosome, chromosome2, res, o, first=(i == 0))
+        start_time = time.time()
+
+    # Several chromosomes on this rank (a whole-genome run): their normalised bands are collected in HBM and ALL their
+    # blocks go through one sequence of launches (pipeline.run_genome) -- same loops as chromosome by chromosome, without
+    # the launch-bound tail of 5-31 blocks per chromosome.  `genome_budget` bounds the bands held at once.
+    batched = len(mine) > 1 and (_world == 1 or by_chromosome)
+    genome_budget = int(os.environ.get("MUSTACHE_GENOME_BATCH_GB", "64")) << 30
+    held, held_bytes, pipe = [], 0, None
+
+    def flush():
+        nonlocal held, held_bytes
+        if held:
+            dpx = held[0][3]
+            loops = pipe.run_genome([h[1] for h in held], [h[2] for h in held], dpx, args.st, args.pt)
+            for (i, _, _, _), o in zip(held, loops):
+                emit(i, o)
+        held, held_bytes = [], 0
+
     with ThreadPoolExecutor(max_workers=1) as pool:
         ahead = pool.submit(fetch, mine[0]) if mine else None
         for k, i in enumerate(mine):
@@ -445,20 +486,41 @@ def main(argv=None):
             ahead = pool.submit(fetch, mine[k + 1]) if k + 1 < len(mine) else None
             if isinstance(contacts, BaseException):
                 raise contacts
+            if batched:
+                if contacts is None:
+                    flush()                       # keeps the output in chromosome order
+                    emit(i, [])
+                    continue
+                if pipe is None:
+                    from .pipeline import ChromosomePipeline
+                    pipe = ChromosomePipeline([args.s_z * (2 ** o_) for o_ in range(args.octaves)])
+                _check_pair(f, chromosome, chromosome2)
+                from .hicfile import PackedContacts
+                is_packed = isinstance(contacts, PackedContacts)
+                res_c = contacts.res if is_packed else contacts[3]
+                dpx = int(math.ceil(distFilter // res_c))
+                if args.verbose:
+                    print("Normalizing contact map...")
+                if is_packed:
+                    band, n = pipe.normalized_band_packed(contacts, dpx)
+                else:
+                    band, n = pipe.normalized_band(contacts[0], contacts[1], contacts[2], res_c, dpx)
+                del contacts
+                if held and (held[0][3] != dpx or held_bytes + band.numel() * 8 > genome_budget):
+                    flush()
+                held.append((i, band, n, dpx))
+                held_bytes += band.numel() * 8
+                continue
             if contacts is None:
                 o = []
             else:
-                o = regulator(f, args.norm_method, False, args.outdir, bed=args.bed, res=contacts[3], sigma0=args.s_z,
+                o = regulator(f, args.norm_method, False, args.outdir, bed=args.bed,
+                              res=getattr(contacts, "res", None) or contacts[3], sigma0=args.s_z,
                               s=args.s, verbose=args.verbose, pt=args.pt, st=args.st, distance_filter=distFilter,
                               nprocesses=args.nprocesses, bias=biasf, chromosome=chromosome, chromosome2=chromosome2,
                               octaves=args.octaves, contacts=contacts, shard_blocks=not by_chromosome)
-            print("{0} loops found for chrmosome={1}, fdr<{2} in {3}sec".format(
-                len(o), chromosome, args.pt, "%.2f" % (time.time() - start_time)))
-            if by_chromosome:
-                results[i] = o
-            elif rank == 0 and (i == 0 or o):
-                write_loops(args.outdir, chromosome, chromosome2, res, o, first=(i == 0))
-            start_time = time.time()
+            emit(i, o)
+        flush()
     if by_chromosome:
         # one gather of (chromosome index, x, y, fdr, sigma) records; rank 0 writes the chromosomes in their order
         from .sharding import gather_records

@@ -46,6 +46,19 @@ def band_from_host_coo(x, y, v, n, dpx, device):
     return band
 
 
+def band_from_packed(pc, dpx, device):
+    """hicfile.PackedContacts (host views of the native reader's buffers) -> raw band [dpx+2, n] on `device`: three
+    pageable uploads of 4 bytes per record each and one scatter (mst_band_from_packed).  A `.hic` matrix holds every pixel
+    once, so there is no repeated-pixel check here (band_from_host_coo has one for free-form text input)."""
+    lib = require_gpu()
+    n = int(pc.n)
+    xd, dd, vd = (torch.from_numpy(a).to(device) for a in (pc.x, pc.dist, pc.v))
+    band = torch.empty((dpx + 2, n), dtype=torch.float64, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.mst_band_from_packed(_ptr(xd), _ptr(dd), _ptr(vd), int(pc.count), n, int(dpx), _ptr(band), _stream()))
+    return band
+
+
 def band_to_coo(band, x, y, v_out, n, dpx):
     lib = require_gpu()
     with torch.cuda.device(band.device):

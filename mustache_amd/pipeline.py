@@ -27,6 +27,36 @@ def block_mask_size(i, start, end, overlap):
     return _bm(i, start, end, overlap)
 
 
+class GenomeLayout:
+    """Several chromosomes of one run side by side in ONE band, so that all their blocks go through the same launches
+    (BASELINE configs 3 and 5; the reference walks the chromosomes one after the other, mustache.py:1057-1067, and a 5 kb
+    chromosome is only 5-31 blocks -- too few to fill the chip).  Chromosome c owns the columns [off[c], off[c] + slot[c]) of
+    the band, slot[c] >= max(n_c, CHUNK) rounded up to 64 columns and zero beyond n_c: a block that starts at off[c] + s reads
+    exactly what it reads from the chromosome's own band at s -- pixels past the chromosome's end are 0 = "no contact" in
+    both (the kernels' `start + column < n` test against the total width never has to know the chromosome), and no block
+    reaches into the next slot.  Nothing in the kernels or the C ABI changes; block statistics, found sets and loops are
+    those of the per-chromosome run, bit for bit."""
+
+    def __init__(self, ns, dpx):
+        self.ns, self.dpx = [int(n) for n in ns], int(dpx)
+        self.CH = max(2 * self.dpx, 2000)
+        self.slot = [-(-max(n, self.CH) // 64) * 64 for n in self.ns]
+        self.off = [0]
+        for w in self.slot[:-1]:
+            self.off.append(self.off[-1] + w)
+        self.N = self.off[-1] + self.slot[-1] if self.ns else 0
+        self.tiling = [block_tiling(n, self.dpx) for n in self.ns]
+        # global block list in chromosome order: (chromosome, block index, local start, global start)
+        self.blocks = [(c, i, t[1][i], self.off[c] + t[1][i]) for c, t in enumerate(self.tiling) for i in range(len(t[1]))]
+
+    def band(self, bands, device):
+        """bands[c]: [dpx + 2, n_c] normalised band of chromosome c (device) -> the [dpx + 2, N] genome band."""
+        g = torch.zeros((self.dpx + 2, self.N), dtype=torch.float64, device=device)
+        for b, n, off in zip(bands, self.ns, self.off):
+            g[:, off:off + n] = b.view(self.dpx + 2, -1)[:, :n]
+        return g
+
+
 class ChromosomePipeline:
     def __init__(self, octave_values=(1.6, 3.2), device=None, max_batch_bytes=48 << 30):
         self.engine = ScaleSpaceEngine(octave_values, device=device)
@@ -104,6 +134,80 @@ class ChromosomePipeline:
             timings.update(scale_space_s=t_dev, tail_s=t_tail, blocks=len(mine), chunk=CH,
                            mpix=len(mine) * CH * CH / 1e6)
         return gather_loops(loops, device=self.device) if (distributed and ws > 1) else loops
+
+    def blocks_per_launch(self, CH):
+        """Blocks per fused-kernel launch on the band path: 16 of 4000 x 4000, 64 of 2000 x 2000 (>= 256 Mpix per launch)."""
+        return max(self.overlap_blocks, (1 << 28) // (CH * CH))
+
+    def run_genome(self, bands, ns, dpx, st, pt, skip_empty=True, timings=None):
+        """Whole-genome batched form of run_band (single process / one rank's own chromosomes): bands[c] is the normalised
+        band of chromosome c.  All blocks of all chromosomes go through the same groups of launches, BH / selection /
+        download and host tail of one group under the kernel of the next.  Returns the list of loops per chromosome
+        (chromosome coordinates), identical to run_band on each chromosome alone."""
+        lay = GenomeLayout(ns, dpx)
+        return self.run_layout(lay, lay.band(bands, self.device), st, pt, skip_empty=skip_empty, timings=timings)
+
+    def run_layout(self, lay, gband, st, pt, skip_empty=True, timings=None):
+        """run_genome's body on a prepared layout + genome band."""
+        CH, dpx, ns = lay.CH, lay.dpx, lay.ns
+        per = self.blocks_per_launch(CH)
+        groups = [lay.blocks[i:i + per] for i in range(0, len(lay.blocks), per)]
+        loops = [[] for _ in ns]
+        t0 = time.time()
+        t_tail = 0.0
+        for group, (found, fits, nzc) in zip(groups, self.engine.sigma_loop_band_overlapped(
+                gband, lay.N, dpx, [[g[3] for g in grp] for grp in groups], CH, skip_empty=skip_empty, with_value=False,
+                select_below=pt)):
+            t1 = time.time()
+            batch = BandBatch(self.engine, gband, lay.N, dpx, [g[3] for g in group], CH,
+                              nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
+            tails = batch_tail(batch, list(range(len(group))), [g[2] for g in group], pt, st, intra=True)
+            for j, (c, i, s_loc, _) in enumerate(group):
+                _, start, end = lay.tiling[c]
+                mask = block_mask_size(i, start, end, dpx)
+                for lp in tails[j]:
+                    if lp[0] >= s_loc + mask or lp[1] >= s_loc + mask:            # mustache.py:957-959
+                        loops[c].append([lp[0], lp[1], lp[2], lp[3]])
+            t_tail += time.time() - t1
+            del batch
+        if timings is not None:
+            timings.update(scale_space_s=time.time() - t0 - t_tail, tail_s=t_tail, blocks=len(lay.blocks), chunk=CH,
+                           mpix=len(lay.blocks) * CH * CH / 1e6, launches=len(groups))
+        return loops
+
+    def normalized_band_packed(self, pc, dpx, normalized=False):
+        """hicfile.PackedContacts of one chromosome -> (normalised band on the device, n)."""
+        from .normalize import band_from_packed
+        band = band_from_packed(pc, dpx, self.device)
+        if not normalized:
+            band, _, _ = normalize_band(band, pc.n, dpx, pc.res)
+        return band, int(pc.n)
+
+    def run_packed(self, pc, dpx, st, pt, verbose=False, skip_empty=True, distributed=True, timings=None):
+        """run() for the native `.hic` reader's packed records."""
+        t0 = time.time()
+        if verbose:
+            print("Normalizing contact map...")
+        band, n = self.normalized_band_packed(pc, dpx)
+        torch.cuda.synchronize(self.device)
+        t1 = time.time()
+        if verbose:
+            print("Loop calling...")
+        loops = self.run_band(band, n, dpx, st, pt, skip_empty=skip_empty, distributed=distributed, timings=timings)
+        if timings is not None:
+            timings["normalize_s"] = t1 - t0
+        return loops
+
+    def normalized_band(self, x, y, v, res, dpx, normalized=False):
+        """Host COO of one chromosome -> (normalised band on the device, n)   (mustache.py:894-895)."""
+        x = np.ascontiguousarray(np.asarray(x), dtype=np.int64)
+        y = np.ascontiguousarray(np.asarray(y), dtype=np.int64)
+        v = np.ascontiguousarray(np.asarray(v), dtype=np.float64)
+        n = int(max(x.max(), y.max())) + 1
+        band = band_from_host_coo(x, y, v, n, dpx, self.device)
+        if not normalized:
+            band, _, _ = normalize_band(band, n, dpx, res)
+        return band, n
 
     def run(self, x, y, v, res, dpx, st, pt, normalized=False, verbose=False, skip_empty=True, distributed=True,
             timings=None):

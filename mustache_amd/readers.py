@@ -136,6 +136,28 @@ def read_hic_file(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, chr2, res):
     return _finish(x, y, v, distance_in_bp, res, chr1 == chr2, chr1)
 
 
+def read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, res):
+    """read_hic_file's records for an intra-chromosomal run as hicfile.PackedContacts (int32 bin, int32 distance, float32
+    value: what the GPU loader mst_band_from_packed takes) -- same record set as read_hic_file through the native reader,
+    without the int64 / float64 COO triple; None when the chromosome has no contact.  Native backend only."""
+    from .hicfile import HicFile, read_intra_packed
+    norm = "KR" if not norm_method else str(norm_method)
+    with HicFile(f) as h:
+        if not CHRM_SIZE:
+            sizes = {"chr" + name.replace("chr", ''): length for name, length in h.chromosomes()[1:]}
+            key = "chr" + str(chr1).replace("chr", '')
+            if key not in sizes:
+                raise NameError('wrong chromosome name!')
+            CHRM_SIZE = sizes[key]
+        print("reading %s through the native .hic reader, packed records (MUSTACHE_HIC_BACKEND=auto|native|hicstraw)"
+              % os.path.basename(str(f)))
+        pc = read_intra_packed(h, chr1, res, norm, int(distance_in_bp // res), int(CHRM_SIZE))
+    if len(pc) == 0:
+        print(f'There is no contact in chrmosome {chr1} to work on.')
+        return None
+    return pc
+
+
 def _read_cooler_obj(clr, distance_in_bp, chr1, chr2, res, cooler_balance):
     sparse = _need("scipy.sparse")
     if chr1 not in clr.chromnames or chr2 not in clr.chromnames:

@@ -216,3 +216,23 @@ def test_diff_cli_two_ranks_equal_one_process(tmp_path):
         assert a == b, suf
         total += a.count("\n") - 1
     assert total > 30
+
+
+def test_pair_genome_batched_equals_chromosome_by_chromosome():
+    """run_pair_genome (both samples' bands of several chromosomes side by side, all block pairs through the same launches:
+    BASELINE config 5) == call_diff_loops_coo on each chromosome alone: same tagged rows in the same order."""
+    from mustache_amd.diff_mustache import call_diff_loops_coo, normalized_pair_bands, run_pair_genome
+    from mustache_amd.pipeline import ChromosomePipeline
+    from mustache_amd.synth import synth_coo
+    dpx, res = 200, 10000
+    chroms = [(synth_coo(n, dpx, depth=300.0, seed=s1), synth_coo(n2, dpx, depth=300.0, seed=s2))
+              for n, n2, s1, s2 in ((2300, 2300, 61, 62), (1700, 1650, 63, 64), (3100, 3100, 65, 66))]
+    alone = [call_diff_loops_coo((a[0], a[1], a[2].copy()), (b[0], b[1], b[2].copy()), res, dpx, OCT, 0.8, 0.2, 0.2,
+                                 verbose=False) for a, b in chroms]
+    pipe = ChromosomePipeline(OCT)
+    pairs = [normalized_pair_bands(pipe, (a[0], a[1], a[2].copy()), (b[0], b[1], b[2].copy()), res, dpx) for a, b in chroms]
+    together = run_pair_genome(pipe, pairs, dpx, 0.8, 0.2, 0.2)
+    assert sum(len(o) for o in alone) > 30
+    for a, b in zip(alone, together):
+        assert [(int(r[0]), int(r[1]), float(r[2]), float(r[3]), int(r[4])) for r in a] == \
+               [(int(r[0]), int(r[1]), float(r[2]), float(r[3]), int(r[4])) for r in b]

@@ -567,3 +567,50 @@ def test_bh_select_on_crafted_pvalue_distributions():
             assert np.array_equal(sel[b]["pixel"].astype(np.int64), pix[b][keep][order]), (pt, b)
             assert np.array_equal(sel[b]["level"].astype(np.int64), lvl[b][keep][order]), (pt, b)
             assert np.array_equal(sel[b]["q"], q[keep][order]), (pt, b)
+
+
+def test_genome_batched_run_equals_chromosome_by_chromosome():
+    """pipeline.run_genome (all chromosomes of a run in one band, all their blocks through the same launches: BASELINE
+    configs 3 and 5) == run() on each chromosome alone, loop for loop and bit for bit (coordinates, q, scale, order) --
+    including a chromosome shorter than one block (its single block reaches past the chromosome's end into the slot's
+    padding, not into the next chromosome) and one of exactly one block."""
+    from mustache_amd.pipeline import ChromosomePipeline, GenomeLayout
+    from mustache_amd.synth import synth_coo
+    dpx, res = 400, 5000
+    pipe = ChromosomePipeline(OCT)
+    pipe.overlap_blocks = 2                    # several launch groups even on this small genome
+    pipe.blocks_per_launch = lambda CH: 5
+    coos = [synth_coo(n, dpx, depth=200.0, seed=sd) for n, sd in ((5200, 31), (1500, 32), (2000, 33), (4300, 34), (700, 35))]
+    alone = [pipe.run(x, y, v.copy(), res, dpx, 0.8, 0.15, distributed=False) for x, y, v in coos]
+    bands, ns = zip(*[pipe.normalized_band(x, y, v.copy(), res, dpx) for x, y, v in coos])
+    timings = {}
+    together = pipe.run_genome(list(bands), list(ns), dpx, 0.8, 0.15, timings=timings)
+    assert timings["blocks"] == len(GenomeLayout(ns, dpx).blocks) == 3 + 1 + 1 + 3 + 1 and timings["launches"] == 2
+    assert sum(len(o) for o in alone) > 40
+    for a, b in zip(alone, together):
+        assert len(a) == len(b)
+        assert [(int(r[0]), int(r[1]), float(r[2]), float(r[3])) for r in a] == \
+               [(int(r[0]), int(r[1]), float(r[2]), float(r[3])) for r in b]
+
+
+def test_genome_batched_cli_equals_per_chromosome_cli(tmp_path):
+    """The CLI on several chromosomes (one text file serves all -ch names): the batched whole-genome path writes the same
+    TSV as the chromosome-by-chromosome path (MUSTACHE_GENOME_BATCH_GB=0 holds one chromosome at a time)."""
+    from mustache_amd.mustache import main
+    from mustache_amd.synth import synth_coo
+    n, dpx, res = 4200, 400, 5000
+    x, y, v = synth_coo(n, dpx, depth=200.0, seed=41)
+    f = str(tmp_path / "m.txt")
+    with open(f, "w") as fh:
+        for a, b, c in zip(x, y, v):
+            fh.write("%d\t%d\t%r\n" % (a * res, b * res, float(c)))
+    common = ["-f", f, "-ch", "chrA", "chrB", "chrC", "-r", "5kb", "-pt", "0.15", "-st", "0.8"]
+    one, two = str(tmp_path / "batched.tsv"), str(tmp_path / "single.tsv")
+    main(common + ["-o", one])
+    os.environ["MUSTACHE_GENOME_BATCH_GB"] = "0"
+    try:
+        main(common + ["-o", two])
+    finally:
+        del os.environ["MUSTACHE_GENOME_BATCH_GB"]
+    a, b = open(one).read(), open(two).read()
+    assert a == b and a.count("\n") > 30

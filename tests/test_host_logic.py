@@ -213,3 +213,31 @@ def test_launched_tile_count_matches_the_geometric_rule():
         assert lib.mst_scale_space_band_tiles(CH, dpx, ctypes.byref(lv), ctypes.byref(total)) == m
         assert total.value == ty * tx
     assert lib.mst_scale_space_band_tiles(0, 5, ctypes.byref(lv), None) < 0
+
+
+def test_genome_layout_windows_equal_the_chromosome_windows():
+    """pipeline.GenomeLayout (whole-genome batching): every block window [start, start + CHUNK) of the side-by-side band
+    holds exactly the chromosome's own window, zero past the chromosome's end, never the next chromosome's data."""
+    import torch
+    from mustache_amd.pipeline import GenomeLayout
+    from mustache_amd.mustache import block_tiling
+    dpx = 400
+    ns = [5200, 1500, 2000, 4300, 700, 2001]
+    lay = GenomeLayout(ns, dpx)
+    assert lay.CH == 2000 and all(s >= max(n, 2000) and s % 64 == 0 for s, n in zip(lay.slot, ns))
+    assert lay.off == [sum(lay.slot[:i]) for i in range(len(ns))] and lay.N == sum(lay.slot)
+    rng = np.random.default_rng(0)
+    bands = [torch.from_numpy(rng.uniform(0.5, 2.0, (dpx + 2, n))) for n in ns]
+    g = lay.band(bands, "cpu")
+    assert g.shape == (dpx + 2, lay.N)
+    k = 0
+    for c, n in enumerate(ns):
+        CH, start, end = block_tiling(n, dpx)
+        for i, s in enumerate(start):
+            assert lay.blocks[k] == (c, i, s, lay.off[c] + s)
+            win = g[:, lay.off[c] + s: lay.off[c] + s + CH]
+            own = torch.zeros((dpx + 2, CH), dtype=torch.float64)
+            own[:, :min(CH, n - s)] = bands[c][:, s:s + CH]
+            assert torch.equal(win, own), (c, i)
+            k += 1
+    assert k == len(lay.blocks)

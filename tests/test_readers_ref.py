@@ -127,3 +127,28 @@ def test_whole_genome_gpu_test_container_equals_the_reference(standins, tmp_path
         x, y, v, res = read_cooler(gcool, rc.GENOME_DPX * rc.GENOME_RES, name, name, False)
         assert len(x) == int(GOLD["genome_%s_count" % name]) > 100000
         assert rc.digest(x, y, v) == str(GOLD["genome_%s_sha256" % name])
+
+
+@pytest.mark.parametrize("version", [8, 9])
+def test_packed_hic_records_equal_the_reference(tmp_path, monkeypatch, version):
+    """The packed form the GPU loader takes (mst_hic_read_intra_packed: int32 bin, int32 distance, float32 value) holds the
+    record set the reference's read_hic_file returns, and n = max bin + 1 (mustache.py:894)."""
+    from mustache_amd.readers import read_hic_packed
+    p = str(tmp_path / "case.hic")
+    write_case_hic(p, version)
+    for name, size in rc.CHROMS:
+        pc = read_hic_packed(p, False, False, rc.DIST, name, rc.RES)
+        assert pc.x.dtype == np.int32 and pc.dist.dtype == np.int32 and pc.v.dtype == np.float32 and pc.res == rc.RES
+        x, y, v = pc.coo()
+        same((x, y, v), "hic_" + name)
+        assert pc.n == int(expect("hic_" + name)[1].max()) + 1
+    # a caller-supplied chromosome size cuts the last window like straw does: nothing at or past it
+    pc = read_hic_packed(p, "KR", 20_000_000, rc.DIST, "chrA", rc.RES)
+    x, y, v = pc.coo()
+    ex, ey, ev = expect("hic_chrA")
+    keep = ey * rc.RES < 20_000_000
+    gx, gy, gv = rc.as_sorted(x, y, v)
+    assert np.array_equal(gx, ex[keep]) and np.array_equal(gy, ey[keep]) and np.array_equal(gv, ev[keep])
+    assert pc.n == int(ey[keep].max()) + 1
+    with pytest.raises(NameError):
+        read_hic_packed(p, False, False, rc.DIST, "chrQ", rc.RES)

@@ -72,11 +72,18 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-procs", type=int, default=0,
-                    help="extra CPU leg: this many blocks in as many worker processes at once (SURVEY 8d (c): one process "
-                         "per physical core); off by default, it adds ~20 s")
+    ap.add_argument("--cpu-procs", type=int, default=16,
+                    help="CPU leg (c) of BASELINE.md section 3: this many blocks in as many worker processes at once (one "
+                         "process per core, capped at 16 by default; 0 = off)")
+    ap.add_argument("--no-file", action="store_true", help="skip the end-to-end-from-a-.hic-file leg")
+    ap.add_argument("--core", action="store_true",
+                    help="headline workload only (plus chr21 / band_skip / fma): no genome, variants, file or CPU legs -- "
+                         "what the PMC passes of scripts/profile_bench.sh run")
     ap.add_argument("--small", action="store_true", help="debug: 12 blocks instead of 124")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.core:
+        a.no_cpu = a.no_file = True
+    return a
 
 
 OVERLAP = int(os.environ.get("MST_BENCH_OVERLAP", "4"))   # launches per step (copy/compute overlap), see Workload.step
@@ -181,6 +188,100 @@ class GenomeWorkload(Workload):
         self.kernel_ms = []
 
 
+def write_synthetic_hic(path, n, dpx, res, depth, nloops, seed, keep, device, block_bins=1000):
+    """A config-4-shaped `.hic` file (one chromosome at `res`, version 8, float counts, KR vector of ones) holding the
+    synthetic chromosome with pixel (i, i + d) kept with probability min(1, keep / (d + 1)) -- generated slab by slab on the
+    GPU, written with the bulk writer of tests/hic_writer.py (test infrastructure; untimed).  Returns the record count."""
+    import torch
+    from mustache_amd.synth import band_counts, _uniform
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hic_writer import write_hic_bulk
+
+    def blocks():
+        d = torch.arange(dpx + 2, dtype=torch.int64, device=device)[:, None]
+        for bx in range(-(-n // block_bins)):
+            i0, i1 = bx * block_bins, min(n, (bx + 1) * block_bins)
+            i = torch.arange(i0, i1, dtype=torch.int64, device=device)[None, :]
+            val = band_counts(n, dpx, depth, nloops, seed, i0=i0, i1=i1, device=device)
+            # thinning grows with the distance (dense near the diagonal, sparse far out, like a real map at 1 kb): pixel
+            # (i, i + d) is kept with probability min(1, keep / (d + 1))
+            val = torch.where(_uniform(seed + 5, d, i, 9) * (d + 1).to(torch.float64) < keep, val, torch.zeros_like(val))
+            dd, cc = torch.nonzero(val > 0, as_tuple=True)
+            x = cc + i0
+            y = x + dd
+            v = val[dd, cc].to(torch.float32)
+            by = y // block_bins
+            order = torch.argsort((by << 42) | (y << 21) | x)
+            x, y, v, by = x[order].to(torch.int32).cpu().numpy(), y[order].to(torch.int32).cpu().numpy(), \
+                v[order].cpu().numpy(), by[order].cpu().numpy()
+            import numpy as np
+            cuts = np.flatnonzero(np.r_[True, by[1:] != by[:-1]]) if len(by) else np.zeros(0, np.int64)
+            cuts = np.append(cuts, len(by))
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                yield bx, int(by[a]), x[a:b], y[a:b], v[a:b]
+
+    return write_hic_bulk(path, "chr1", n * res, res, blocks(), block_bins, threads=min(32, os.cpu_count() or 4))
+
+
+def file_leg(w, device, keep=200.0):
+    """file -> loops for a config-4-shaped `.hic` (chr1 at 1 kb), stage by stage.  The records go from the
+    native reader's per-thread arenas into page-locked buffers (int32 bin, int32 distance, float32 value) and from there to
+    the device loader -- no int64 / float64 COO triple, no Python de-duplication between inflate and H2D."""
+    import tempfile
+    import torch
+    from mustache_amd.hicfile import HicFile, read_intra_packed
+    from mustache_amd.normalize import band_from_packed, normalize_band, pinned_packed_alloc
+    tmp = tempfile.mkdtemp(prefix="mst_bench_")
+    path = os.path.join(tmp, "chr1_1kb.hic")
+    try:
+        t0 = time.time()
+        nrec = write_synthetic_hic(path, w.n, w.dpx, w.res, 400.0, 8000, 1, keep, device)
+        t_write = time.time() - t0
+        size = os.path.getsize(path)
+        t0 = time.time()
+        h = HicFile(path)
+        t_open = time.time() - t0
+        passes = []
+        for rep in range(3):        # pass 1 pays for fresh pages (reader arenas, pinned buffers, allocator); 2 and 3 = steady state
+            torch.cuda.synchronize()
+            t = [time.time()]
+            pc = read_intra_packed(h, "chr1", w.res, "KR", w.dpx, 0, alloc=pinned_packed_alloc)
+            t.append(time.time())
+            band = band_from_packed(pc, w.dpx, device)
+            torch.cuda.synchronize()
+            t.append(time.time())
+            nb, _, _ = normalize_band(band, pc.n, w.dpx, w.res)
+            torch.cuda.synchronize()
+            t.append(time.time())
+            tm = {}
+            loops = w.pipe.run_band(nb, pc.n, w.dpx, 0.88, 0.1, timings=tm, distributed=False)
+            torch.cuda.synchronize()
+            t.append(time.time())
+            passes.append({"inflate_decode_pack_s": round(t[1] - t[0], 4), "upload_and_band_scatter_s": round(t[2] - t[1], 4),
+                           "normalize_s": round(t[3] - t[2], 4), "kernels_and_tail_s": round(t[4] - t[3], 4),
+                           "total_s": round(t[4] - t[0], 4), "loops": len(loops), "records": len(pc), "n": pc.n})
+            del pc, band, nb
+        h.close()
+        best = dict(min(passes[1:], key=lambda p: p["total_s"]))
+        best["open_index_s"] = round(t_open, 4)
+        best["reader_plus_upload_s"] = round(best["inflate_decode_pack_s"] + best["upload_and_band_scatter_s"], 4)
+        best["gpu_step_s"] = round(best["normalize_s"] + best["kernels_and_tail_s"], 4)
+        best["first_pass"] = passes[0]
+        best["file"] = {"format": ".hic v8, float counts, 1000-bin blocks, zlib level 1, KR vector of ones",
+                        "records_written": int(nrec), "bytes": int(size), "write_s_untimed": round(t_write, 1),
+                        "pixel_kept_with_probability": "min(1, %g / (d + 1))" % keep}
+        best["host_threads"] = os.cpu_count()
+        best["note"] = "synthetic chr1@1kb (thinned with the distance), from the open file to the final loop list on 1 GPU: " \
+                       "threaded inflate + record decode into per-thread arenas + copy into page-locked buffers " \
+                       "(libmustache_io.so), three uploads + mst_band_from_packed, mst_normalize_band, fused kernels + device " \
+                       "BH / selection / clustering + host tail (product mode).  Best of passes 2-3 (steady state of a " \
+                       "whole-genome run: arenas, pinned buffers and the device allocator warm); first_pass beside it"
+        return best
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _dense_raw_block(w, block_index):
     import numpy as np
     s = w.start[block_index]
@@ -216,14 +317,14 @@ def cpu_baseline(w, block_index):
     return _oracle_block((_dense_raw_block(w, block_index), w.dpx, True))
 
 
-def cpu_baseline_p4(w, block_indices):
-    """The reference's default parallelism (-p 4, mustache.py:146): 4 blocks in 4 processes at once."""
+def cpu_baseline_pool(w, block_indices, procs):
+    """`procs` worker processes over the given blocks (the reference's default parallelism is -p 4, mustache.py:146)."""
     import multiprocessing as mp
     blocks = [(_dense_raw_block(w, i), w.dpx, False) for i in block_indices]
     ctx = mp.get_context("spawn")
     t0 = time.time()
-    with ctx.Pool(len(blocks)) as pool:
-        res = pool.map(_oracle_block, blocks)
+    with ctx.Pool(procs) as pool:
+        res = pool.map(_oracle_block, blocks, chunksize=1)
     return time.time() - t0, res
 
 
@@ -299,6 +400,11 @@ def main():
     # roofline of the dominant kernel (rank 0's launches): algorithmic flops per launch / event-timed duration
     launches_per_step = max(1, len(kms) // args.steps)
     k_ms = sum(kms) / len(kms)
+    # every rank's own view on stderr, so that a partial failure of an N > 1 run can be told from the log
+    print("RANK_FRAGMENT " + json.dumps({"rank": rank, "world": world, "device": local, "backend": backend if grouped else None,
+                                         "blocks": len(w.mine), "own_ms_per_step": round(owns[rank if grouped else 0] / args.steps * 1e3, 3),
+                                         "kernel_ms_mean": round(k_ms, 3), "job_ms_per_step": round(ms_per_step, 3)}),
+          file=sys.stderr, flush=True)
     px_per_launch = len(w.mine) * w.CH * w.CH / launches_per_step
     achieved_tf = px_per_launch * FLOPS_PER_PIXEL / (k_ms * 1e-3) / 1e12
     achieved_gbs = px_per_launch * BYTES_PER_PIXEL / (k_ms * 1e-3) / 1e9
@@ -319,14 +425,19 @@ def main():
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac_of_model_roofline": round(achieved_gbs / HBM_PEAK_GBS, 4),
                           "note": "level-streaming model of BASELINE.md (every level written and re-read): the rate the "
                                   "kernel WOULD need if it followed that model -- it does not, see traffic"}}
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if os.path.exists(pmc):
+    import glob
+    import re
+    cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))
+                   if re.fullmatch(r"r\d+_pmc_traffic\.json", os.path.basename(f)))
+    pmc = cands[-1] if cands else ""                      # the latest round's profiling session
+    if pmc:
         try:
             pj = json.load(open(pmc))
             roof["traffic"] = round(pj["bytes_per_pixel"] * px_per_launch)        # PMC bytes/pixel x pixels/launch
-            roof["traffic_source"] = "profiles/r02_pmc_traffic.json: FETCH_SIZE (x2, gfx950) + WRITE_SIZE of the fused kernel " \
-                                     "in this round's rocprofv3 --pmc pass (%s), %.2f B/pixel" % (pj.get("command", "?"),
-                                                                                                pj["bytes_per_pixel"])
+            roof["traffic_source"] = "profiles/%s: FETCH_SIZE (x2, gfx950) + WRITE_SIZE of the fused kernel in that " \
+                                     "round's rocprofv3 --pmc pass (%s), %.2f B/pixel" % (os.path.basename(pmc),
+                                                                                          pj.get("command", "?"),
+                                                                                          pj["bytes_per_pixel"])
         except Exception:
             pass
 
@@ -365,6 +476,8 @@ def main():
                      "ms_per_step_min": round(min(owns) / args.steps * 1e3, 3),
                      "blocks_per_rank_max": -(-len(w.start) // world), "blocks_per_rank_min": len(w.start) // world,
                      "imbalance_bound": round(-(-len(w.start) // world) * world / len(w.start), 4),
+                     "efficiency_bound": round(len(w.start) / (world * -(-len(w.start) // world)), 4),
+                     "efficiency_bound_at": {str(k): round(len(w.start) / (k * -(-len(w.start) // k)), 4) for k in (1, 2, 4, 8)},
                      "note": "round-robin split of the blocks: the slowest rank carries ceil(blocks / ranks) blocks, so "
                              "the strong-scaling efficiency cannot exceed blocks / (ranks * ceil(blocks / ranks))"},
            "roofline": roof, "band_skip": band_skip, "fma_mode": fma_mode,
@@ -424,6 +537,7 @@ def main():
                                                       "is launch- and latency-bound, not FP64-bound -- see diff_genome_5kb"},
                                  "note": "two-sample caller, rows 3-7 for both samples + difference image + pair p-values"}
         del w5, band_b
+    if rank == 0 and world == 1 and not args.core:
         # BASELINE configs 3 and 5: a whole hg19-shaped genome at 5 kb (24 chromosomes, ~390 blocks of 2000 x 2000) with all
         # chromosomes side by side in one band (pipeline.GenomeLayout) -- every launch carries blocks of many chromosomes
         wg = GenomeWorkload("hg19-shaped genome @5kb synthetic", 5000, 400, 300.0, 1000, device, two_samples=True)
@@ -504,6 +618,49 @@ def main():
         out["end_to_end"] = {"rows_2_to_9_s": round(time.time() - t0, 3), "normalize_s": round(w.normalize_s, 3),
                              "tail_s": round(tm.get("tail_s", 0.0), 3), "loops": len(loops),
                              "note": "synthetic chr1@1kb from the normalised band to the final loop list, 1 GPU"}
+    if rank == 0 and world == 1 and not args.core:
+        # instantiations outside the headline configuration, so that their cost is on the line: the wide-radius tile that
+        # serves -sz / -oc (blur radius 15..28) and the normalisation kernel for windows beyond 8400 bins (< 238 bp)
+        from mustache_amd.pipeline import ChromosomePipeline, block_tiling
+        from mustache_amd.normalize import normalize_band
+        from mustache_amd.synth import band_counts
+        var = {}
+        nv = 4000 + 5 * 2000
+        bandv, _ = make_band(nv, 2000, 400.0, 500, 3, 1000, device, reps=1)
+        CHv, startv, _ = block_tiling(nv, 2000)
+        for label, octs in (("octaves_3.2_6.4", (3.2, 6.4)), ("octaves_1.6_3.2_6.4", (1.6, 3.2, 6.4))):
+            eng = ChromosomePipeline(octs, device=device).engine
+            r = {}
+            for mode, skip in (("dense", False), ("band_skip", True)):
+                tms = []
+                for it in range(3):
+                    tm = []
+                    eng.sigma_loop_band(bandv, nv, 2000, startv, CHv, skip_empty=skip, download=False, timing=tm)
+                    torch.cuda.synchronize()
+                    tms.append(tm[0][0].elapsed_time(tm[0][1]))
+                r[mode] = round(len(startv) * CHv * CHv / 1e6 / (sorted(tms)[1] * 1e-3), 1)
+            var[label] = dict(r, unit="Mpix/s", kernel="scale_space_kernel<Tile<32,32,28,4>, band>", blocks=len(startv),
+                              chunk=CHv, max_radius=int(max(eng.levels.radius)))
+            del eng
+        del bandv
+        nw, resw = 60000, 222                                   # window int(2e6 / 222) = 9009 bins
+        raww = band_counts(nw, 2000, 30.0, 100, 5, device=device)
+        tms = []
+        for it in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            normalize_band(raww, nw, 2000, resw)
+            e1.record()
+            torch.cuda.synchronize()
+            tms.append(e0.elapsed_time(e1))
+        var["normalize_window_9009"] = {"ms": round(sorted(tms)[1], 3), "samples": nw * 2002,
+                                        "GB/s_on_16B_per_sample": round(16.0 * nw * 2002 / (sorted(tms)[1] * 1e-3) / 1e9, 1),
+                                        "kernel": "normalize_walk_kernel<1024,16> (128-VGPR cap, spills: correctness-only "
+                                                  "path for resolutions below ~238 bp)"}
+        del raww
+        out["variants"] = var
+    if rank == 0 and world == 1 and not args.no_file:
+        out["end_to_end_from_file"] = file_leg(w, device)
     if rank == 0 and world == 1 and not args.no_cpu:
         bi = len(w.start) // 2
         import numpy as np
@@ -522,17 +679,22 @@ def main():
                                "found_set_pixels_levels_values_identical": bool(same), "pvalue_max_rel_err": p_err,
                                "cpu_model": _cpu_model(), "host_cores": os.cpu_count()}
         out["speedup_vs_cpu_1core"] = round(value / out["cpu_baseline"]["value"], 1)
-        wall4, _ = cpu_baseline_p4(w, [bi - 2, bi - 1, bi + 1, bi + 2])
-        out["cpu_baseline_p4"] = {"value": round(4 * w.CH * w.CH / 1e6 / wall4, 4), "unit": "Mpix/s", "cores": 4,
-                                  "kind": "port", "sample": "4 blocks of the same workload in 4 worker processes (the "
-                                  "reference's default -p 4), wall %.1f s incl. process start-up" % wall4}
+        # (b) the reference's default -p 4 over a stated subset of >= 8 blocks, scaled linearly
+        sub = [(bi + j) % len(w.start) for j in range(-4, 5) if j]
+        wall4, _ = cpu_baseline_pool(w, sub, 4)
+        out["cpu_baseline_p4"] = {"value": round(len(sub) * w.CH * w.CH / 1e6 / wall4, 4), "unit": "Mpix/s", "cores": 4,
+                                  "kind": "port", "sample": "%d of the workload's %d blocks (a stated subset, scaled linearly) "
+                                  "in 4 worker processes, two rounds (the reference's default -p 4), wall %.1f s incl. "
+                                  "process start-up" % (len(sub), len(w.start), wall4)}
         out["speedup_vs_cpu_p4"] = round(value / out["cpu_baseline_p4"]["value"], 1)
-        if args.cpu_procs > 0:
-            P = min(args.cpu_procs, len(w.start))
-            wallp, _ = cpu_baseline_p4(w, [(bi + j) % len(w.start) for j in range(P)])
+        # (c) one process per core, capped (--cpu-procs, default 16; 0 switches the leg off)
+        P = min(args.cpu_procs, len(w.start), os.cpu_count() or 1)
+        if P > 0:
+            wallp, _ = cpu_baseline_pool(w, [(bi + j) % len(w.start) for j in range(P)], P)
             out["cpu_baseline_node"] = {"value": round(P * w.CH * w.CH / 1e6 / wallp, 3), "unit": "Mpix/s", "cores": P,
-                                        "kind": "port", "sample": "%d blocks of the same workload in %d worker processes "
-                                        "at once, wall %.1f s incl. process start-up" % (P, P, wallp)}
+                                        "kind": "port", "host_cores": os.cpu_count(),
+                                        "sample": "%d blocks of the same workload in %d worker processes at once (capped; "
+                                        "--cpu-procs raises it), wall %.1f s incl. process start-up" % (P, P, wallp)}
             out["speedup_vs_cpu_node"] = round(value / out["cpu_baseline_node"]["value"], 1)
     if rank == 0:
         print(json.dumps(out))

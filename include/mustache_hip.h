@@ -196,9 +196,9 @@ int mst_band_to_coo(const double *band, const int64_t *x, const int64_t *y, int6
  *   local != 0 : branch A (:628-669), taken by the caller when (n - dpx) * res > 2e6; `window` = int(2e6 / res).
  *                (local == 1: the library picks the kernel -- the walking kernel (blocks of `window` samples along each
  *                diagonal, one scan per sample) for windows up to 4096, blocked sums up to ~8400, a slow spilling form
- *                of the walking kernel up to 16384, an error beyond; local == 2: the blocked-sum
- *                kernel whatever the window; local == 3: the segment kernel with prefix arrays in LDS (windows up to
- *                ~3000, blocked sums above).  Three formulations of the same sums, selectable so they can be cross-checked.)
+ *                of the walking kernel up to 16384, an error beyond.  PROFILE builds of the library additionally accept
+ *                local == 2 (blocked sums whatever the window) and local == 3 (round 1's segment kernel) as cross-checks;
+ *                the product library refuses them.)
  *                Per diagonal d <= dpx+1: vals = v + 0.001; counts / sum / sum of squares over the zero-padded
  *                window [i - window/2, i - window/2 + window - 1] (np.convolve 'same'); local variance and mean
  *                with the global fallback below 30 samples or when non-finite; z = (vals - mean)/sqrt(var),
@@ -239,6 +239,19 @@ int mst_diag_means_band(const double *band, int64_t n, int32_t dpx, int64_t star
 /* the same for diagonals of several blocks in ONE launch: starts: dev [nd], the block origin of each requested diagonal */
 int mst_diag_means_band_multi(const double *band, int64_t n, int32_t dpx, const int64_t *starts, int32_t CH,
                               const int32_t *diag_k, int32_t nd, double *mean_out, void *stream);
+
+/* mustache.py:830-848 for B blocks in one launch: 8-connected clustering of every surviving candidate with its 3 x 3 halo
+ * (scipy.ndimage.label numbering: components in raster order of their first pixel) and, per component, the FIRST arg-min of
+ * o in raster order over its member pixels.  Inputs (dev): per block b the SELECTED records (q < pt) sorted by pixel --
+ * sel_pix / sel_q [sel_off[b], sel_off[b+1]) -- and the positions of the candidates that survived the filters among them,
+ * ascending -- cand_pos [cand_off[b], cand_off[b+1]).  Output: rep_pos[cand_off[b] + k] = position (in block b's records) of
+ * the representative of its k-th component, rep_count[b] components.  workspace: mst_cluster_workspace_bytes(total
+ * candidates).  Only selected records can be an arg-min (o >= 1 elsewhere), which is why they suffice. */
+uint64_t mst_cluster_workspace_bytes(uint32_t n_candidates);
+int mst_cluster_representatives(const uint32_t *sel_pix, const double *sel_q, const uint32_t *sel_off,
+                                const uint32_t *cand_pos, const uint32_t *cand_off, int32_t B, int32_t CH,
+                                uint32_t n_candidates, uint32_t *rep_pos, uint32_t *rep_count, void *workspace,
+                                uint64_t workspace_bytes, void *stream);
 
 /* ---- two-sample (differential) caller, reference mustache/diff_mustache.py:260-569 ------------------------------------
  * The per-sample sigma loops are mst_scale_space on both samples' blocks.  The entry points below add what

@@ -81,6 +81,14 @@ int64_t mst_hic_read_intra_packed(mst_hic *h, const char *chrom, int32_t resolut
                                   int64_t chrom_size_bp, int32_t n_threads, int32_t **x, int32_t **dist, float **v,
                                   int64_t *n_bins);
 
+/* The two halves of mst_hic_read_intra_packed for callers that own the destination (a pinned staging buffer the GPU upload
+ * reads at full PCIe rate): decode returns the record count and *n_bins and keeps the records in grow-only per-thread arenas
+ * inside the handle (their capacity survives from chromosome to chromosome: no fresh pages after the largest one); fetch
+ * copies them, in file block order, into x / dist / v with room for `capacity` records.  One decode at a time per handle. */
+int64_t mst_hic_decode_intra_packed(mst_hic *h, const char *chrom, int32_t resolution, const char *norm,
+                                    int64_t max_dist_bins, int64_t chrom_size_bp, int32_t n_threads, int64_t *n_bins);
+int mst_hic_fetch_packed(mst_hic *h, int32_t *x, int32_t *dist, float *v, int64_t capacity, int32_t n_threads);
+
 /* ---- text contact maps ------------------------------------------------------------------------------------------------
  * The parse step of read_pd() (reference mustache/mustache.py:254-258): `pd.read_csv(f, sep=sep, header=None)` followed
  * by `df.dropna()`, for the two layouts the reference accepts -- 3 columns (pos1 pos2 count) or 5 columns (chr1 pos1 chr2

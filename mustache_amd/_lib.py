@@ -72,6 +72,8 @@ _SIGNATURES = {
     "mst_diag_means": (ctypes.c_int, [_p, _i32, _i32, _p, _i32, _p, _p]),
     "mst_diag_means_band": (ctypes.c_int, [_p, _i64, _i32, _i64, _i32, _p, _i32, _p, _p]),
     "mst_diag_means_band_multi": (ctypes.c_int, [_p, _i64, _i32, _p, _i32, _p, _i32, _p, _p]),
+    "mst_cluster_workspace_bytes": (_u64, [_u32]),
+    "mst_cluster_representatives": (ctypes.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _u32, _p, _p, _p, _u64, _p]),
     "mst_diff_image": (ctypes.c_int, [_p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p]),
     "mst_masked_normfit": (ctypes.c_int, [_p, _p, _p, _p, _i32, _i64, _p, _p, _u64, _p]),
     "mst_diff_dog_workspace_bytes": (_u64, [_i32, _i32, ctypes.POINTER(MstLevels)]),

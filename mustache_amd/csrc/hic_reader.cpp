@@ -126,6 +126,21 @@ struct mst_hic {
     size_t after_master = 0;                                          // file offset right behind the master index entries
     bool norm_index_read = false;
     std::map<std::string, NormRef> norm_index;                        // "TYPE|chrIdx|UNIT|binSize"
+    // records of the last mst_hic_decode_intra_packed call: one grow-only arena per worker thread (capacity survives
+    // from call to call, so a whole-genome run stops paying for fresh pages after its largest chromosome), and per
+    // block which arena holds its records and where
+    struct PackedArena {
+        std::vector<int32_t> x, d;
+        std::vector<float> v;
+    };
+    struct PackedSpan {
+        int arena;
+        size_t begin, count;
+    };
+    std::vector<PackedArena> arenas;
+    std::vector<std::vector<uint8_t>> inflate_bufs;                   // per worker thread, grow-only like the arenas
+    std::vector<PackedSpan> spans;
+    int64_t packed_total = -1;
 
     Cursor at(int64_t pos) const {
         if (pos < 0 || (uint64_t)pos > size) throw FormatError{"file position outside the file"};
@@ -298,6 +313,36 @@ struct Records {
     std::vector<double> v;
 };
 
+// packed sink: binX, binY - binX, float32 value appended to a worker's arena; y_limit = first bin past the caller's size
+struct PackedSink {
+    mst_hic::PackedArena *a;
+    int64_t y_limit, ymax;
+    void push(int64_t bx, int64_t by, float c) {
+        if (by >= y_limit) return;
+        a->x.push_back((int32_t)bx);
+        a->d.push_back((int32_t)(by - bx));
+        a->v.push_back(c);
+        ymax = by > ymax ? by : ymax;
+    }
+    void reserve(size_t) {}
+};
+
+inline void emit(PackedSink &out, int64_t bx, int64_t by, float counts, const std::vector<double> *norm, int64_t max_dist) {
+    if (bx > by) {
+        const int64_t t = bx;
+        bx = by;
+        by = t;
+    }
+    if (max_dist >= 0 && by - bx > max_dist) return;
+    float c = counts;
+    if (norm) {
+        if (bx < 0 || (size_t)by >= norm->size()) return;
+        c = (float)((double)counts / ((*norm)[(size_t)bx] * (*norm)[(size_t)by]));
+    }
+    if (std::isnan(c) || !(c > 0.0f)) return;
+    out.push(bx, by, c);
+}
+
 inline void emit(Records &out, int64_t bx, int64_t by, float counts, const std::vector<double> *norm, int64_t max_dist) {
     if (bx > by) {                                                         // intra blocks store binX <= binY; be lenient
         const int64_t t = bx;
@@ -316,7 +361,15 @@ inline void emit(Records &out, int64_t bx, int64_t by, float counts, const std::
     out.v.push_back((double)c);
 }
 
-void decode_block(int32_t version, const uint8_t *comp, size_t comp_size, std::vector<uint8_t> &buf, Records &out,
+inline void sink_reserve(Records &out, size_t room) {
+    out.x.reserve(room);
+    out.y.reserve(room);
+    out.v.reserve(room);
+}
+inline void sink_reserve(PackedSink &, size_t) {}
+
+template <class Sink>
+void decode_block(int32_t version, const uint8_t *comp, size_t comp_size, std::vector<uint8_t> &buf, Sink &out,
                   const std::vector<double> *norm, int64_t max_dist) {
     // inflate (the uncompressed size is not stored: grow until it fits)
     if (buf.size() < comp_size * 8 + 1024) buf.resize(comp_size * 8 + 1024);
@@ -343,9 +396,7 @@ void decode_block(int32_t version, const uint8_t *comp, size_t comp_size, std::v
     const int32_t n_rec = c.get<int32_t>();
     if (n_rec < 0) throw FormatError{"negative record count in a block"};
     const size_t room = (size_t)n_rec < n_out ? (size_t)n_rec : n_out;      // a record takes at least one byte
-    out.x.reserve(room);
-    out.y.reserve(room);
-    out.v.reserve(room);
+    sink_reserve(out, room);
     if (version < 7) {
         for (int32_t i = 0; i < n_rec; ++i) {
             const int32_t bx = c.get<int32_t>();
@@ -590,74 +641,154 @@ extern "C" int64_t mst_hic_read_intra(mst_hic *h, const char *chrom, int32_t res
     }
 }
 
-extern "C" int64_t mst_hic_read_intra_packed(mst_hic *h, const char *chrom, int32_t resolution, const char *norm,
-                                             int64_t max_dist_bins, int64_t chrom_size_bp, int32_t n_threads,
-                                             int32_t **x, int32_t **dist, float **v, int64_t *n_bins) {
-    if (!h || !chrom || !x || !dist || !v || !n_bins || resolution <= 0)
-        return fail(MST_IO_E_ARG, "mst_hic_read_intra_packed: bad argument");
-    *x = *dist = nullptr;
-    *v = nullptr;
+// block list + normalisation vector of one chromosome's intra matrix (shared by the record readers)
+static int intra_todo(mst_hic *h, const char *chrom, int32_t resolution, const char *norm, int64_t max_dist_bins,
+                      std::vector<const BlockRef *> &todo, ZoomData &z, std::vector<double> &norm_vec, bool *use_norm) {
+    const int ci = find_chromosome(h, chrom);
+    if (ci < 0) return fail(MST_IO_E_NOTFOUND, "chromosome %s is not in the file", chrom);
+    const std::string key = std::to_string(ci) + "_" + std::to_string(ci);
+    auto it = h->matrices.find(key);
+    if (it == h->matrices.end()) return fail(MST_IO_E_NOTFOUND, "no intra-chromosomal matrix for %s", chrom);
+    z = read_zoom(h, it->second.first, resolution);
+    if (!z.found) return fail(MST_IO_E_NOTFOUND, "resolution %d is not in the file", resolution);
+    *use_norm = norm && *norm && strcmp(norm, "NONE") != 0;
+    if (*use_norm) {
+        read_norm_index(h);
+        auto nit = h->norm_index.find(norm_key(norm, ci, "BP", resolution));
+        if (nit == h->norm_index.end())
+            return fail(MST_IO_E_NOTFOUND, "no %s normalisation vector for %s at %d bp", norm, chrom, resolution);
+        norm_vec = read_norm_vector(h, nit->second);
+    }
+    for (const BlockRef &b : z.blocks) {
+        if (b.size <= 0) continue;
+        if (b.pos < 0 || (uint64_t)b.pos + (uint64_t)b.size > h->size) throw FormatError{"block outside the file"};
+        if (block_near_diagonal(h->version, b.number, z.block_bin_count, z.block_column_count, max_dist_bins))
+            todo.push_back(&b);
+    }
+    return MST_IO_OK;
+}
+
+extern "C" int64_t mst_hic_decode_intra_packed(mst_hic *h, const char *chrom, int32_t resolution, const char *norm,
+                                               int64_t max_dist_bins, int64_t chrom_size_bp, int32_t n_threads,
+                                               int64_t *n_bins) {
+    if (!h || !chrom || !n_bins || resolution <= 0) return fail(MST_IO_E_ARG, "mst_hic_decode_intra_packed: bad argument");
     *n_bins = 0;
+    h->packed_total = -1;
     try {
-        std::vector<Records> part;
-        int nt = 1;
-        const int rc = read_intra_parts(h, chrom, resolution, norm, max_dist_bins, n_threads, part, &nt);
+        std::vector<const BlockRef *> todo;
+        ZoomData z;
+        std::vector<double> norm_vec;
+        bool use_norm = false;
+        const int rc = intra_todo(h, chrom, resolution, norm, max_dist_bins, todo, z, norm_vec, &use_norm);
         if (rc != MST_IO_OK) return rc;
+        int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+        if (nt < 1) nt = 1;
+        if ((size_t)nt > todo.size()) nt = todo.empty() ? 1 : (int)todo.size();
+        if (h->arenas.size() < (size_t)nt) h->arenas.resize((size_t)nt);
+        if (h->inflate_bufs.size() < (size_t)nt) h->inflate_bufs.resize((size_t)nt);
+        for (auto &a : h->arenas) {
+            a.x.clear();
+            a.d.clear();
+            a.v.clear();
+        }
+        h->spans.assign(todo.size(), mst_hic::PackedSpan{0, 0, 0});
         // straw's window end (mustache.py:320-333): no position at or past the chromosome size the caller gave
         const int64_t y_limit = chrom_size_bp > 0 ? (chrom_size_bp + resolution - 1) / resolution : INT64_MAX;
-        std::vector<size_t> keep(part.size(), 0);
-        std::vector<int64_t> ymax(part.size(), -1);
-        parallel_for(part.size(), nt, [&](size_t i) {
-            const Records &r = part[i];
-            size_t k = 0;
-            int64_t m = -1;
-            for (size_t e = 0; e < r.v.size(); ++e)
-                if (r.y[e] < y_limit) {
-                    ++k;
-                    m = r.y[e] > m ? r.y[e] : m;
+        std::atomic<size_t> next(0);
+        std::atomic<int> bad(0);
+        const char *bad_what = nullptr;
+        std::vector<int64_t> ymax((size_t)nt, -1);
+        auto work = [&](int t) {
+            std::vector<uint8_t> &buf = h->inflate_bufs[(size_t)t];
+            PackedSink sink{&h->arenas[(size_t)t], y_limit, -1};
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= todo.size() || bad.load()) break;
+                const size_t before = sink.a->v.size();
+                try {
+                    decode_block(h->version, h->map + todo[i]->pos, (size_t)todo[i]->size, buf, sink,
+                                 use_norm ? &norm_vec : nullptr, max_dist_bins);
+                } catch (const FormatError &e) {
+                    bad_what = e.what;
+                    bad.store(1);
+                    break;
+                } catch (...) {
+                    bad_what = "out of memory";
+                    bad.store(1);
+                    break;
                 }
-            keep[i] = k;
-            ymax[i] = m;
-        });
-        std::vector<size_t> offs(part.size() + 1, 0);
-        int64_t top = -1;
-        for (size_t i = 0; i < part.size(); ++i) {
-            offs[i + 1] = offs[i] + keep[i];
-            top = ymax[i] > top ? ymax[i] : top;
-        }
+                h->spans[i] = mst_hic::PackedSpan{t, before, sink.a->v.size() - before};
+            }
+            ymax[(size_t)t] = sink.ymax;
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto &t : pool) t.join();
+        if (bad.load()) return fail(MST_IO_E_ZLIB, "block decode failed: %s", bad_what ? bad_what : "?");
+        int64_t total = 0, top = -1;
+        for (const auto &sp : h->spans) total += (int64_t)sp.count;
+        for (int64_t m : ymax) top = m > top ? m : top;
         if (top >= INT32_MAX) return fail(MST_IO_E_FORMAT, "bin index %lld does not fit 32 bits", (long long)top);
-        const size_t total = offs[part.size()];
-        int32_t *ox = (int32_t *)malloc((total ? total : 1) * sizeof(int32_t));
-        int32_t *od = (int32_t *)malloc((total ? total : 1) * sizeof(int32_t));
-        float *ov = (float *)malloc((total ? total : 1) * sizeof(float));
-        if (!ox || !od || !ov) {
-            free(ox);
-            free(od);
-            free(ov);
-            return fail(MST_IO_E_FILE, "out of memory for %zu records", total);
-        }
-        parallel_for(part.size(), nt, [&](size_t i) {
-            Records &r = part[i];
-            size_t o = offs[i];
-            for (size_t e = 0; e < r.v.size(); ++e)
-                if (r.y[e] < y_limit) {
-                    ox[o] = (int32_t)r.x[e];
-                    od[o] = (int32_t)(r.y[e] - r.x[e]);
-                    ov[o] = (float)r.v[e];             // exact: the values are straw's float32 results held in doubles
-                    ++o;
-                }
-            std::vector<int64_t>().swap(r.x);
-            std::vector<int64_t>().swap(r.y);
-            std::vector<double>().swap(r.v);
-        });
-        *x = ox;
-        *dist = od;
-        *v = ov;
+        h->packed_total = total;
         *n_bins = top + 1;
-        return (int64_t)total;
+        return total;
     } catch (const FormatError &e) {
         return fail(MST_IO_E_FORMAT, "%s", e.what);
     } catch (...) {
         return fail(MST_IO_E_FORMAT, "unreadable file (out of memory?)");
     }
+}
+
+extern "C" int mst_hic_fetch_packed(mst_hic *h, int32_t *x, int32_t *dist, float *v, int64_t capacity, int32_t n_threads) {
+    if (!h || h->packed_total < 0) return fail(MST_IO_E_ARG, "mst_hic_fetch_packed: no decoded records (call mst_hic_decode_intra_packed)");
+    if (capacity < h->packed_total || (h->packed_total > 0 && (!x || !dist || !v)))
+        return fail(MST_IO_E_ARG, "mst_hic_fetch_packed: room for %lld records, %lld decoded", (long long)capacity,
+                    (long long)h->packed_total);
+    std::vector<size_t> offs(h->spans.size() + 1, 0);
+    for (size_t i = 0; i < h->spans.size(); ++i) offs[i + 1] = offs[i] + h->spans[i].count;
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if ((size_t)nt > h->spans.size()) nt = h->spans.empty() ? 1 : (int)h->spans.size();
+    // file block order (deterministic whatever thread decoded a block), the copies spread over the worker threads
+    parallel_for(h->spans.size(), nt, [&](size_t i) {
+        const mst_hic::PackedSpan &sp = h->spans[i];
+        if (!sp.count) return;
+        const mst_hic::PackedArena &a = h->arenas[(size_t)sp.arena];
+        memcpy(x + offs[i], a.x.data() + sp.begin, sp.count * sizeof(int32_t));
+        memcpy(dist + offs[i], a.d.data() + sp.begin, sp.count * sizeof(int32_t));
+        memcpy(v + offs[i], a.v.data() + sp.begin, sp.count * sizeof(float));
+    });
+    return MST_IO_OK;
+}
+
+extern "C" int64_t mst_hic_read_intra_packed(mst_hic *h, const char *chrom, int32_t resolution, const char *norm,
+                                             int64_t max_dist_bins, int64_t chrom_size_bp, int32_t n_threads,
+                                             int32_t **x, int32_t **dist, float **v, int64_t *n_bins) {
+    if (!x || !dist || !v) return fail(MST_IO_E_ARG, "mst_hic_read_intra_packed: bad argument");
+    *x = *dist = nullptr;
+    *v = nullptr;
+    const int64_t total = mst_hic_decode_intra_packed(h, chrom, resolution, norm, max_dist_bins, chrom_size_bp, n_threads,
+                                                      n_bins);
+    if (total < 0) return total;
+    int32_t *ox = (int32_t *)malloc((size_t)(total ? total : 1) * sizeof(int32_t));
+    int32_t *od = (int32_t *)malloc((size_t)(total ? total : 1) * sizeof(int32_t));
+    float *ov = (float *)malloc((size_t)(total ? total : 1) * sizeof(float));
+    if (!ox || !od || !ov) {
+        free(ox);
+        free(od);
+        free(ov);
+        return fail(MST_IO_E_FILE, "out of memory for %lld records", (long long)total);
+    }
+    const int rc = mst_hic_fetch_packed(h, ox, od, ov, total, n_threads);
+    if (rc != MST_IO_OK) {
+        free(ox);
+        free(od);
+        free(ov);
+        return rc;
+    }
+    *x = ox;
+    *dist = od;
+    *v = ov;
+    return total;
 }

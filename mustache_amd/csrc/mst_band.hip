@@ -80,8 +80,8 @@ __device__ __forceinline__ void block_reduce2(double &a, double &b, double *sa, 
 // One workgroup per diagonal: count, mean and population std of the raw entries (np.mean / np.std at
 // mustache.py:638-643, :677-682; NaN -> mean 0, std 1), and the weight 1 + log30(1 + mean) (:667).
 // diag_stats[d] = {mean, std, weight, count}
-// The row is read ONCE: np.std's two passes (mean, then squared deviations) become shifted sums around a pivot K taken
-// from the row's head (the mean of the non-zero entries among its first 256 samples):
+// The row is read ONCE: np.std's two passes (mean, then squared deviations) become shifted sums around a pivot K = the
+// mean of the non-zero entries among 256 samples spread evenly over the row:
 //     mean = K + sum(v - K) / n,      var = (sum((v - K)^2) - sum(v - K)^2 / n) / n.
 // With K within a few standard deviations of the mean the cancellation in `var` costs a few ulp (relative error
 // ~ eps * (1 + (mean - K)^2 / var)); the band is 4 GB for chr1 at 1 kb, so the second pass was as expensive as the first.
@@ -92,8 +92,10 @@ diag_stats_kernel(const double *__restrict__ band, int64_t n, double *__restrict
     const int64_t L = n - d;
     const double *row = band + (int64_t)d * n;
     double hc = 0.0, hs = 0.0;
-    if ((int64_t)threadIdx.x < L) {
-        const double v = row[threadIdx.x];
+    if (L > 0) {
+        // 256 samples spread evenly over the whole diagonal, not its head: acrocentric chromosomes and telomeric gaps begin
+        // with megabases of empty bins, and a pivot of 0 would turn the formula into the naive sum(x^2) - sum(x)^2 / n
+        const double v = row[(int64_t)threadIdx.x * L / kThreads];
         if (v != 0.0 && isfinite(v)) {
             hc = 1.0;
             hs = v;
@@ -267,7 +269,7 @@ normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ 
     }
 }
 
-// Branch A, prefix-sum form (the default): one workgroup = kPSeg consecutive positions of one diagonal.  The kPSeg + W
+// Branch A, prefix-sum form (round 1's kernel; compiled in PROFILE builds only): one workgroup = kPSeg consecutive positions of one diagonal.  The kPSeg + W
 // samples it needs are read ONCE and turned into three exclusive prefix arrays in LDS -- count of non-zero samples
 // (exact, int32), sum of (v + 0.001), sum of squares -- so every window is two LDS reads per quantity instead of
 // ~W/16 block sums: the kernel becomes a streaming pass over the band (8 B read + 8 B written per sample).
@@ -275,7 +277,9 @@ normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ 
 // terms), i.e. a relative error of a few 1e-16 on the window sums -- the same order as the difference between BLAS
 // builds of the reference's np.convolve; parity with the reference fixtures is held at 1e-9 (tests).  The summation
 // order is fixed by (diagonal, segment), so results are deterministic.
+#ifdef MST_PROFILE
 constexpr int kPSeg = 1024;
+#endif
 
 // ---- wave-level inclusive scan with DPP moves (no LDS crossbar): Hillis-Steele inside the four 16-lane rows (row_shr 1, 2,
 // 4, 8; lanes without a source read 0), then row_bcast15 / row_bcast31 add the totals of the rows below.
@@ -309,9 +313,12 @@ __device__ __forceinline__ void wave_scan3(double &a, double &b, int &c) {
 __device__ __forceinline__ double lane_before(double x) { return dpp_d<0x138, 0xf>(x); }
 __device__ __forceinline__ int lane_before_i(int x) { return dpp_i<0x138, 0xf>(x); }
 
+#ifdef MST_PROFILE
 constexpr int kPThreads = 256;                         // (1024-thread workgroups were measured: 20 % slower)
 constexpr int kPMaxChunk = 17;                         // samples per thread a tile may need (W <= 3072); always odd
+#endif
 
+#ifdef MST_PROFILE   /* the round-1 segment / prefix-array form: PROFILE builds only (cross-check, scripts/norm_*.py) */
 // raw samples of one item's tile into registers: r[u] = element t = tid + u * kPThreads (0 outside the diagonal)
 template <int CHUNK>
 __device__ __forceinline__ void normalize_prefix_fetch(const double *__restrict__ band_in, int64_t n, int W,
@@ -462,6 +469,7 @@ normalize_prefix_kernel(const double *__restrict__ band_in, double *__restrict__
         __syncthreads();                               // the LDS arrays are reused by the next item
     }
 }
+#endif  // MST_PROFILE
 
 // ---- Branch A, walking form (the default) ------------------------------------------------------------------------------
 // A workgroup walks along ONE diagonal in blocks of W samples, W = the window length.  With sample blocks
@@ -835,6 +843,11 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
                                   int32_t local, double *diag_stats, void *stream) {
     if (!band_in || !band_out || !diag_stats || band_in == band_out || n <= 0 || dpx < 0 || dpx + 2 > 65535)
         return mst::fail(MST_E_ARG, "mst_normalize_band: bad argument (out of place, dpx + 2 <= 65535)");
+#ifndef MST_PROFILE
+    if (local != 0 && local != 1)
+        return mst::fail(MST_E_ARG, "mst_normalize_band: local = %d selects a cross-check kernel that only PROFILE builds "
+                         "carry (make PROFILE=1 -> libmustache_hip_profile.so); the product library takes 0 or 1", local);
+#endif
     hipStream_t s = mst::as_stream(stream);
     const int nd = dpx + 2;
     diag_stats_kernel<<<nd, kThreads, 0, s>>>(band_in, n, diag_stats);
@@ -868,6 +881,7 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
         MST_LAUNCH_CHECK();
         return MST_OK;
     }
+#ifdef MST_PROFILE
     if (local && window >= 2) {
         // local == 3: the segment / prefix-array kernel (2 doubles + 1 int per sample in LDS), kept selectable for cross-checks
         const int tile = kPSeg + window - 1;
@@ -896,6 +910,7 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
             return MST_OK;
         }
     }
+#endif
     if (local) {
         // wide windows: blocked-sum kernel.  LDS: 2 doubles per staged sample + 2 doubles and an int per 16-sample block,
         // for up to SEG + W + 2*16 samples
@@ -930,7 +945,7 @@ extern "C" int mst_blocks_from_band(const double *band, int64_t n, int32_t dpx, 
     hipStream_t s = mst::as_stream(stream);
     int64_t *d_starts = nullptr;
     MST_HIP(hipMallocAsync((void **)&d_starts, sizeof(int64_t) * B, s));
-    MST_HIP(hipMemcpyAsync(d_starts, starts, sizeof(int64_t) * B, hipMemcpyHostToDevice, s));
+    MST_HIP(mst::upload_small(d_starts, starts, sizeof(int64_t) * B, s));
     MST_HIP(hipMemsetAsync(nz_count, 0, sizeof(uint32_t) * B, s));
     blocks_from_band_kernel<<<dim3((CH + kTC - 1) / kTC, (CH + kTR * kStrips - 1) / (kTR * kStrips), B), kThreads, 0, s>>>(
         band, n, dpx, d_starts, CH, c, nz, nz_count);

@@ -92,7 +92,7 @@ extern "C" int mst_scatter_blocks(const int64_t *x, const int64_t *y, const doub
     if (nnz == 0) return MST_OK;
     int64_t *d_starts = nullptr;
     MST_HIP(hipMallocAsync((void **)&d_starts, sizeof(int64_t) * B, s));
-    MST_HIP(hipMemcpyAsync(d_starts, starts, sizeof(int64_t) * B, hipMemcpyHostToDevice, s));
+    MST_HIP(mst::upload_small(d_starts, starts, sizeof(int64_t) * B, s));
     int64_t want = (nnz + kThreads - 1) / kThreads;
     int grid = (int)(want < 65536 ? want : 65536);
     scatter_kernel<<<grid, kThreads, 0, s>>>(x, y, v, nnz, d_starts, B, CH, c);

@@ -35,4 +35,11 @@ inline hipError_t allow_dynamic_lds(const void *kernel, int bytes, unsigned long
     return e;
 }
 
+// Host -> device upload of a small table (level table, block starts, tile lists) whose source may be reused or freed as
+// soon as the call returns (a stack object, a thread_local vector, a ctypes array the Python caller drops): the bytes are
+// copied into a PINNED staging slot first and the asynchronous copy reads from there, so its correctness does not rest on
+// the runtime staging pageable sources before hipMemcpyAsync returns.  A ring of slots per host thread; a slot is reused
+// only after the event recorded behind its copy has completed (normally long ago).
+hipError_t upload_small(void *dst, const void *src, size_t bytes, hipStream_t s);
+
 }  // namespace mst

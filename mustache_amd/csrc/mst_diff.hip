@@ -376,7 +376,7 @@ pair_pvalue_dog_kernel(const mst_found *__restrict__ found, uint32_t found_cap, 
 
 using DiffTile8 = Tile<32, 64, 8>;        // the reference's default octaves: G_2 / G_3 radii 4, 4 and 7, 8
 using DiffTile14 = Tile<32, 64, 14>;
-using DiffTile28 = Tile<32, 32, 28>;
+using DiffTile28 = Tile<32, 32, 28, 4, 1>;   // 256 threads x 4 pixels, like the sigma loop's wide tile
 
 template <class T>
 size_t diff_lds_bytes() { return sizeof(double) * (size_t)(T::CT_ELEMS + T::VB_ELEMS + 2 * T::NT); }
@@ -449,8 +449,8 @@ extern "C" int mst_diff_dog_band(const double *band1, const double *band2, int64
     int64_t *d_starts = reinterpret_cast<int64_t *>(w);
     w += diff_align(sizeof(int64_t) * (size_t)B);
     double *partial = reinterpret_cast<double *>(w);
-    MST_HIP(hipMemcpyAsync(d_lv, &h, sizeof(h), hipMemcpyHostToDevice, s));
-    MST_HIP(hipMemcpyAsync(d_starts, starts, sizeof(int64_t) * B, hipMemcpyHostToDevice, s));
+    MST_HIP(mst::upload_small(d_lv, &h, sizeof(h), s));
+    MST_HIP(mst::upload_small(d_starts, starts, sizeof(int64_t) * B, s));
     MST_HIP(hipMemsetAsync(mask_count, 0, sizeof(uint32_t) * B, s));
     if (mr <= DiffTile8::RMAX)
         return diff_dog_launch<DiffTile8>(band1, band2, n, dpx, d_starts, CH, B, d_lv, h.n_octaves, dog, partial,

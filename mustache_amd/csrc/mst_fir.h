@@ -128,7 +128,7 @@ __device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const do
     constexpr int QC0 = (R + OFF) >> 1, QC1 = (R + KC - 1 + OFF) >> 1;   // pairs holding the centre run
     const double2 *p2 = reinterpret_cast<const double2 *>(p);
     double x[2 * NP];
-#if defined(MST_ABL_NOLDS)   /* timing ablation: no LDS window loads (values opaque to the optimiser) */
+#if defined(MST_PROFILE) && defined(MST_ABL_NOLDS)   /* timing ablation (PROFILE builds): no LDS window loads */
 #define MST_LD(q_)                                        \
     {                                                     \
         double a_ = w[0], b_ = w[R];                      \
@@ -159,7 +159,7 @@ __device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const do
         }
         lq_hi = lq1 > lq_hi ? lq1 : lq_hi;
         rq_lo = rq0 < rq_lo ? rq0 : rq_lo;
-#if defined(MST_ABL_NOMATH)  /* timing ablation: loads only, one add per loaded pair */
+#if defined(MST_PROFILE) && defined(MST_ABL_NOMATH)  /* timing ablation (PROFILE builds): loads only */
         if (j & 1) t[j % KC] = t[j % KC] + (x[R - j + OFF] + x[R + KC - 1 + j + OFF]);
 #else
         double s[KC];

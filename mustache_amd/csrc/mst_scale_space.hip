@@ -589,19 +589,9 @@ int check_levels(const mst_levels *lv, int *max_radius, int *n_tested) {
     return MST_OK;
 }
 
-#ifndef MST_TILE_K
-#define MST_TILE_K 8
-#endif
-#ifndef MST_TILE_W
-#define MST_TILE_W 64
-#endif
-#if MST_TILE_K == 4
-using TileDefault = Tile<32, 64, 14, 4, 4>;   // 512 threads x 4 pixels, 128 VGPRs -> 4 waves per SIMD
-#else
-using TileDefault = Tile<32, MST_TILE_W, 14>;   // the reference's default octaves (radius <= 14)
-#endif
-using TileWide = Tile<32, 32, 28>;      // -sz / -oc variants up to radius 28: smaller tile, same code
-using TileDefaultFma = Tile<32, MST_TILE_W, 14, 8, 1, true>;   // opt-in relaxed arithmetic (MST_FLAG_FMA), default radii only
+using TileDefault = Tile<32, 64, 14>;   // the reference's default octaves (radius <= 14)
+using TileWide = Tile<32, 32, 28, 4, 1>;   // -sz / -oc variants up to radius 28: 256 threads x 4 pixels (K = 8 spilled SGPRs and left half the SIMDs idle)
+using TileDefaultFma = Tile<32, 64, 14, 8, 1, true>;   // opt-in relaxed arithmetic (MST_FLAG_FMA), default radii only
 
 template <class T>
 int tiles_x(int CH) { return (CH + T::ITC - 1) / T::ITC; }
@@ -725,7 +715,7 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
                          (unsigned long long)workspace_bytes, (unsigned long long)need);
     hipStream_t s = mst::as_stream(stream);
 
-    // level table -> device (pageable source: the runtime stages it before returning, so `h` may die)
+    // level table -> device (through a pinned staging slot, mst::upload_small: `h` may die as soon as this returns)
     DevLevels h;
     memset(&h, 0, sizeof(h));
     h.n_octaves = lv->n_octaves;
@@ -758,10 +748,10 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
     int32_t *d_tiles = reinterpret_cast<int32_t *>(w);
     w += align_up(sizeof(int32_t) * 2 * (size_t)nt_tiles_max(CH), 256);
     double *partial = reinterpret_cast<double *>(w);
-    MST_HIP(hipMemcpyAsync(d_lv, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    MST_HIP(mst::upload_small(d_lv, &h, sizeof(h), s));
     MST_HIP(hipMemsetAsync(found_count, 0, sizeof(uint32_t) * B, s));
     if (BAND) {
-        MST_HIP(hipMemcpyAsync(d_starts, starts_host, sizeof(int64_t) * B, hipMemcpyHostToDevice, s));
+        MST_HIP(mst::upload_small(d_starts, starts_host, sizeof(int64_t) * B, s));
         MST_HIP(hipMemsetAsync(src.nz_count, 0, sizeof(uint32_t) * B, s));
         src.starts = d_starts;
     }
@@ -804,8 +794,7 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
             MST_LAUNCH_CHECK();
             return MST_OK;
         }
-        MST_HIP(hipMemcpyAsync(d_tiles, host_list.data(), sizeof(int32_t) * 2 * (size_t)ntiles_all, hipMemcpyHostToDevice,
-                               s));
+        MST_HIP(mst::upload_small(d_tiles, host_list.data(), sizeof(int32_t) * 2 * (size_t)ntiles_all, s));
         tile_list = d_tiles;
         slot_of_tile = d_tiles + ntiles_all;
     }

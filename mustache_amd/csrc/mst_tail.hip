@@ -371,3 +371,166 @@ extern "C" int mst_gather_diagonals(const double *c, int32_t CH, int32_t b, cons
     MST_LAUNCH_CHECK();
     return MST_OK;
 }
+
+// ---- clustering of the surviving candidates (mustache.py:830-848) --------------------------------------------------------
+// The reference paints every candidate and its 8 neighbours into a label matrix, labels the 8-connected components
+// (scipy.ndimage.label, numbered in raster order of their first pixel) and reports, per component, the FIRST arg-min of o in
+// raster order over all member pixels (o = q at found pixels, >= 1 elsewhere).  On the record lists that is:
+//   * two candidates share a component iff a chain of candidates links them with Chebyshev steps <= 3 (their 3 x 3 halos
+//     touch or overlap);
+//   * the raster-first pixel of a component is the top-left halo pixel of its raster-first candidate, so the components
+//     are numbered in the order of their first candidates;
+//   * a member pixel can only be the arg-min if its o is below 1, i.e. if it is a SELECTED record (q < pt, candidate or
+//     not: the sparsity / diagonal-mean filters drop candidates, not their q) within Chebyshev distance 1 of a candidate.
+// One workgroup per block.  Inputs per block: its selected records sorted by pixel (sel_pix, sel_q) and the positions of the
+// surviving candidates among them (cand_pos, ascending).  Scratch per candidate: label, min q (bit pattern), min pixel.
+namespace {
+
+constexpr int kClThreads = 256;
+
+__device__ __forceinline__ int cl_lower_bound(const uint32_t *__restrict__ pix, const uint32_t *__restrict__ pos, int n,
+                                               uint32_t key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (pix[pos[mid]] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// first candidate (index into the block's candidate list) within Chebyshev distance R of (x, y), or -1; with ALL != 0 the
+// minimum label over all of them is returned instead (labels: lab[])
+template <int R, bool MIN_LABEL>
+__device__ __forceinline__ int cl_probe(const uint32_t *__restrict__ spix, const uint32_t *__restrict__ cpos, int nc, int CH,
+                                        int x, int y, const uint32_t *__restrict__ lab, int init) {
+    int best = init;
+    const int y_lo = y - R > 0 ? y - R : 0, y_hi = y + R < CH - 1 ? y + R : CH - 1;
+    for (int r = x - R; r <= x + R; ++r) {
+        if (r < 0 || r >= CH) continue;
+        const uint32_t k_lo = (uint32_t)r * (uint32_t)CH + (uint32_t)y_lo, k_hi = (uint32_t)r * (uint32_t)CH + (uint32_t)y_hi;
+        for (int j = cl_lower_bound(spix, cpos, nc, k_lo); j < nc && spix[cpos[j]] <= k_hi; ++j) {
+            if (!MIN_LABEL) return j;
+            const int l = (int)lab[j];
+            best = l < best ? l : best;
+        }
+    }
+    return best;
+}
+
+__global__ void __launch_bounds__(kClThreads)
+cluster_kernel(const uint32_t *__restrict__ sel_pix, const double *__restrict__ sel_q, const uint32_t *__restrict__ sel_off,
+               const uint32_t *__restrict__ cand_pos, const uint32_t *__restrict__ cand_off, int CH, uint32_t *__restrict__ lab_all,
+               unsigned long long *__restrict__ minq_all, uint32_t *__restrict__ minpix_all, uint32_t *__restrict__ rep_pos,
+               uint32_t *__restrict__ rep_count) {
+    __shared__ int changed;
+    __shared__ uint32_t scan[kClThreads];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t s0 = sel_off[b], c0 = cand_off[b];
+    const int ns = (int)(sel_off[b + 1] - s0), nc = (int)(cand_off[b + 1] - c0);
+    if (nc == 0) {
+        if (tid == 0) rep_count[b] = 0;
+        return;
+    }
+    const uint32_t *spix = sel_pix + s0;
+    const double *sq = sel_q + s0;
+    const uint32_t *cpos = cand_pos + c0;
+    uint32_t *lab = lab_all + c0;
+    unsigned long long *minq = minq_all + c0;
+    uint32_t *minpix = minpix_all + c0;
+    for (int i = tid; i < nc; i += kClThreads) {
+        lab[i] = (uint32_t)i;
+        minq[i] = ~0ull;
+        minpix[i] = ~0u;
+    }
+    __syncthreads();
+    // components: minimum-label propagation over the Chebyshev <= 3 links, with pointer jumping; a component's label
+    // converges to the index of its raster-first candidate
+    for (;;) {
+        if (tid == 0) changed = 0;
+        __syncthreads();
+        for (int i = tid; i < nc; i += kClThreads) {
+            const uint32_t p = spix[cpos[i]];
+            const int cur = (int)lab[i];
+            const int m = cl_probe<3, true>(spix, cpos, nc, CH, (int)(p / (uint32_t)CH), (int)(p % (uint32_t)CH), lab, cur);
+            if (m < cur) {
+                atomicMin(&lab[i], (uint32_t)m);
+                atomicMin(&lab[cur], (uint32_t)m);          // hook the old root as well
+                changed = 1;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nc; i += kClThreads) {         // pointer jumping
+            uint32_t l = lab[i];
+            while (lab[l] != l) l = lab[l];
+            lab[i] = l;
+        }
+        __syncthreads();
+        if (!changed) break;
+        __syncthreads();
+    }
+    // per component: min q over the selected records inside its halo, then the raster-first record among the ties
+    for (int s = tid; s < ns; s += kClThreads) {
+        const uint32_t p = spix[s];
+        const int j = cl_probe<1, false>(spix, cpos, nc, CH, (int)(p / (uint32_t)CH), (int)(p % (uint32_t)CH), nullptr, -1);
+        if (j >= 0) atomicMin(&minq[lab[j]], (unsigned long long)__double_as_longlong(sq[s]));
+    }
+    __syncthreads();
+    for (int s = tid; s < ns; s += kClThreads) {
+        const uint32_t p = spix[s];
+        const int j = cl_probe<1, false>(spix, cpos, nc, CH, (int)(p / (uint32_t)CH), (int)(p % (uint32_t)CH), nullptr, -1);
+        if (j >= 0 && (unsigned long long)__double_as_longlong(sq[s]) == minq[lab[j]]) atomicMin(&minpix[lab[j]], p);
+    }
+    __syncthreads();
+    // representatives in component order (= ascending root index): position of the winning record among the block's records
+    const int per = (nc + kClThreads - 1) / kClThreads;
+    const int i0 = tid * per, i1 = i0 + per < nc ? i0 + per : nc;
+    uint32_t mine = 0;
+    for (int i = i0; i < i1; ++i) mine += lab[i] == (uint32_t)i ? 1u : 0u;
+    scan[tid] = mine;
+    __syncthreads();
+    for (int o = 1; o < kClThreads; o <<= 1) {
+        const uint32_t v = tid >= o ? scan[tid - o] : 0u;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    uint32_t k = scan[tid] - mine;
+    for (int i = i0; i < i1; ++i) {
+        if (lab[i] != (uint32_t)i) continue;
+        const uint32_t want = minpix[i];
+        int lo = 0, hi = ns;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (spix[mid] < want) lo = mid + 1;
+            else hi = mid;
+        }
+        rep_pos[c0 + k] = (uint32_t)lo;
+        ++k;
+    }
+    if (tid == kClThreads - 1) rep_count[b] = scan[tid];
+}
+
+}  // namespace
+
+extern "C" uint64_t mst_cluster_workspace_bytes(uint32_t n_candidates) { return 16ull * (uint64_t)(n_candidates ? n_candidates : 1); }
+
+extern "C" int mst_cluster_representatives(const uint32_t *sel_pix, const double *sel_q, const uint32_t *sel_off,
+                                           const uint32_t *cand_pos, const uint32_t *cand_off, int32_t B, int32_t CH,
+                                           uint32_t n_candidates, uint32_t *rep_pos, uint32_t *rep_count, void *workspace,
+                                           uint64_t workspace_bytes, void *stream) {
+    if (B <= 0) return MST_OK;
+    if (!sel_pix || !sel_q || !sel_off || !cand_pos || !cand_off || !rep_pos || !rep_count || !workspace || CH <= 0 ||
+        (int64_t)CH * CH > 0xFFFFFFFFLL)
+        return mst::fail(MST_E_ARG, "mst_cluster_representatives: bad argument");
+    if (workspace_bytes < mst_cluster_workspace_bytes(n_candidates))
+        return mst::fail(MST_E_ARG, "mst_cluster_representatives: workspace too small");
+    char *w = reinterpret_cast<char *>(workspace);
+    unsigned long long *minq = reinterpret_cast<unsigned long long *>(w);
+    uint32_t *lab = reinterpret_cast<uint32_t *>(w + 8ull * (n_candidates ? n_candidates : 1));
+    uint32_t *minpix = lab + (n_candidates ? n_candidates : 1);
+    cluster_kernel<<<B, kClThreads, 0, mst::as_stream(stream)>>>(sel_pix, sel_q, sel_off, cand_pos, cand_off, CH, lab, minq,
+                                                                  minpix, rep_pos, rep_count);
+    MST_LAUNCH_CHECK();
+    return MST_OK;
+}

@@ -45,8 +45,10 @@ def _pair_tail(batch, b1, b2, start, pt, pt2, st, intra):
         if i2.size == 0:
             return empty
     out = []
-    for (b, q, idx, bo) in ((b1, q1, i1, b2), (b2, q2, i2, b1)):
-        reps = cluster_representatives(batch, b, q, idx)                   # (:531-561)
+    multi = getattr(batch, "cluster_representatives_multi", None)       # both samples' blocks in one launch (:531-561)
+    reps_both = multi([b1, b2], [q1, q2], [i1, i2], pt) if multi is not None else \
+        [cluster_representatives(batch, b1, q1, i1), cluster_representatives(batch, b2, q2, i2)]
+    for (b, q, idx, bo), reps in zip(((b1, q1, i1, b2), (b2, q2, i2, b1)), reps_both):
         loops = loops_from_reps(batch, b, q, reps, start)
         rec, other = batch.found[b], batch.found[bo]
         # differential subset (:567-568): pair < pt2 and v_self > v_other, where v = 1 off-nz, vAll on nz (0 if not found)

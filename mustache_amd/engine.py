@@ -111,6 +111,51 @@ class _MultiGather:
     def _diag_means_one_launch(self, bs, sizes, d_k, out):
         return False                        # overridden where all blocks share one source buffer
 
+    def cluster_representatives_multi(self, bs, qs, idxs, pt):
+        """Clustering of the surviving candidates of several blocks (mustache.py:830-848) in ONE launch
+        (mst_cluster_representatives): per block the record indices of the components' representatives, in the
+        reference's label order.  qs[i]: q per record of block bs[i]; idxs[i]: ascending record indices of its candidates.
+        Only records with q < pt can be a component's arg-min (o >= 1 everywhere else), so those are what is uploaded."""
+        out = [[] for _ in bs]
+        sel_pix, sel_q, sel_off, cand_pos, cand_off, back = [], [], [0], [], [0], []
+        for b, q, idx in zip(bs, qs, idxs):
+            rec = self.found[b]
+            idx = np.asarray(idx, dtype=np.int64)
+            below = np.nonzero(q < pt)[0]
+            if len(idx) and not np.all(q[idx] < pt):
+                raise ValueError("cluster_representatives_multi: a candidate with q >= pt")
+            sel_pix.append(rec["pixel"][below].astype(np.uint32))
+            sel_q.append(np.ascontiguousarray(q[below], dtype=np.float64))
+            sel_off.append(sel_off[-1] + len(below))
+            cand_pos.append(np.searchsorted(below, idx).astype(np.uint32))
+            cand_off.append(cand_off[-1] + len(idx))
+            back.append(below)
+        total_c = cand_off[-1]
+        if total_c == 0:
+            return out
+        dev = self._device()
+        lib = self.engine.lib
+        up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)
+        d_pix = up(np.concatenate(sel_pix) if sel_off[-1] else np.zeros(1, np.uint32), np.int32)
+        d_q = up(np.concatenate(sel_q) if sel_off[-1] else np.zeros(1), np.float64)
+        d_soff = up(np.asarray(sel_off, dtype=np.uint32), np.int32)
+        d_cpos = up(np.concatenate(cand_pos), np.int32)
+        d_coff = up(np.asarray(cand_off, dtype=np.uint32), np.int32)
+        d_rep = torch.empty(total_c, dtype=torch.int32, device=dev)
+        d_cnt = torch.empty(len(bs), dtype=torch.int32, device=dev)
+        ws_bytes = int(lib.mst_cluster_workspace_bytes(total_c))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.mst_cluster_representatives(_ptr(d_pix), _ptr(d_q), _ptr(d_soff), _ptr(d_cpos), _ptr(d_coff),
+                                                       len(bs), int(self.CH), total_c, _ptr(d_rep), _ptr(d_cnt), _ptr(ws),
+                                                       ws_bytes, _stream()))
+        rep = d_rep.cpu().numpy().view(np.uint32)
+        cnt = d_cnt.cpu().numpy().view(np.uint32)
+        for i in range(len(bs)):
+            r = rep[cand_off[i]:cand_off[i] + int(cnt[i])]
+            out[i] = [int(v) for v in back[i][r]]
+        return out
+
     def candidate_features(self, b, pixel, half):
         """(cnt1, cnt2, cval) for candidate pixels of block b (reference mustache.py:800-807, :824)."""
         return self.candidate_features_multi([b], [pixel], [half])[0]

@@ -23,15 +23,18 @@ def band_from_host_coo(x, y, v, n, dpx, device):
     """Host COO (the readers' output) -> band on `device`, with the reference's rule for repeated pixels.  The reference
     writes the entries of a diagonal in input order (`vals[x[indices]] = v[indices]`, mustache.py:633-635; `cc[xc, yc] = vc`,
     :921-924): the LAST entry of a repeated (x, y) wins.  The device scatter is a plain racing store, so repeated pixels are
-    looked for first (one count on the device) and, only if there are any, removed on the host keeping the last one.
+    looked for first (every entry reads its pixel back from the band: a mismatch means two entries with different values
+    share a pixel) and, only if there are any, removed on the host keeping the last one.
     (The reference's per-diagonal mean / std run over ALL entries, repeats included, :636-639; after the de-duplication a
     repeated pixel counts once here -- stated in DESIGN.md; a contact list with repeats is malformed input for both.)"""
     import warnings
     xd, yd, vd = (torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in (x, y, v))
     band = band_from_coo(xd, yd, vd, n, dpx)
-    lo, hi = torch.minimum(xd, yd), torch.maximum(xd, yd)
-    in_band = ((hi - lo) <= dpx + 1) & (lo >= 0) & (hi < n) & (vd != 0)
-    if int((band != 0).sum().item()) != int(in_band.sum().item()):
+    # every entry reads its pixel back: a pixel written by two entries with DIFFERENT values (zero included) shows up as a
+    # mismatch for one of them whichever store won the race; repeats of equal value change nothing.  nnz-sized, exact.
+    back = vd.clone()
+    band_to_coo(band, xd, yd, back, n, dpx)
+    if bool((back != vd).any().item()):
         xs, ys, vs = np.asarray(x, dtype=np.int64), np.asarray(y, dtype=np.int64), np.asarray(v, dtype=np.float64)
         key = np.minimum(xs, ys) * np.int64(n) + np.maximum(xs, ys)
         order = np.argsort(key, kind="stable")
@@ -46,13 +49,24 @@ def band_from_host_coo(x, y, v, n, dpx, device):
     return band
 
 
+def pinned_packed_alloc(count):
+    """Allocator for hicfile.read_intra_packed: three page-locked torch tensors (PyTorch's caching host allocator recycles
+    them from chromosome to chromosome) and NumPy views of them for the reader to fill."""
+    ts = (torch.empty(count, dtype=torch.int32, pin_memory=True), torch.empty(count, dtype=torch.int32, pin_memory=True),
+          torch.empty(count, dtype=torch.float32, pin_memory=True))
+    return ts[0].numpy(), ts[1].numpy(), ts[2].numpy(), ts
+
+
 def band_from_packed(pc, dpx, device):
-    """hicfile.PackedContacts (host views of the native reader's buffers) -> raw band [dpx+2, n] on `device`: three
-    pageable uploads of 4 bytes per record each and one scatter (mst_band_from_packed).  A `.hic` matrix holds every pixel
+    """hicfile.PackedContacts -> raw band [dpx+2, n] on `device`: three uploads of 4 bytes per record each (from page-locked
+    memory when the records were read into it) and one scatter (mst_band_from_packed).  A `.hic` matrix holds every pixel
     once, so there is no repeated-pixel check here (band_from_host_coo has one for free-form text input)."""
     lib = require_gpu()
     n = int(pc.n)
-    xd, dd, vd = (torch.from_numpy(a).to(device) for a in (pc.x, pc.dist, pc.v))
+    if pc.pinned is not None:
+        xd, dd, vd = (t.to(device, non_blocking=True) for t in pc.pinned)
+    else:
+        xd, dd, vd = (torch.from_numpy(a).to(device) for a in (pc.x, pc.dist, pc.v))
     band = torch.empty((dpx + 2, n), dtype=torch.float64, device=device)
     with torch.cuda.device(device):
         _lib.check(lib.mst_band_from_packed(_ptr(xd), _ptr(dd), _ptr(vd), int(pc.count), n, int(dpx), _ptr(band), _stream()))
@@ -72,9 +86,9 @@ _KERNELS = {"auto": 1, "blocked": 2, "segment": 3}
 
 def normalize_band(band, n, dpx, resolution, blocked=False, kernel=None):
     """Returns (normalised band, diag_stats [dpx+2, 4] = mean, std, weight, count).  Branch selection and window
-    size follow mustache.py:628, :631.  `kernel` picks the implementation of branch A (mst_normalize_band's `local`):
-    "auto" (default: the walking kernel, blocked sums for windows beyond 4096), "blocked", "segment" -- three independent
-    formulations of the same window sums that the tests cross-check.  `blocked=True` is short for kernel="blocked"."""
+    size follow mustache.py:628, :631.  `kernel` ("blocked" / "segment"; `blocked=True` is short for the former) asks for one
+    of the two cross-check formulations of branch A's window sums -- only a PROFILE build of the library carries them
+    (make PROFILE=1, MUSTACHE_HIP_LIB=.../libmustache_hip_profile.so); the product library picks its kernel itself."""
     lib = require_gpu()
     local = (n - dpx) * resolution > 2000000
     window = int(2000000 / resolution)

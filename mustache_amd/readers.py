@@ -136,13 +136,34 @@ def read_hic_file(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, chr2, res):
     return _finish(x, y, v, distance_in_bp, res, chr1 == chr2, chr1)
 
 
+_HIC_HANDLE = [None, None]           # (path, HicFile): the packed reader's arenas live in the handle -- keep the last one open
+
+
+def _hic_handle(f):
+    from .hicfile import HicFile
+    path = os.path.abspath(str(f))
+    if _HIC_HANDLE[0] != path:
+        if _HIC_HANDLE[1] is not None:
+            _HIC_HANDLE[1].close()
+        _HIC_HANDLE[0], _HIC_HANDLE[1] = path, HicFile(path)
+    return _HIC_HANDLE[1]
+
+
 def read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, res):
     """read_hic_file's records for an intra-chromosomal run as hicfile.PackedContacts (int32 bin, int32 distance, float32
     value: what the GPU loader mst_band_from_packed takes) -- same record set as read_hic_file through the native reader,
     without the int64 / float64 COO triple; None when the chromosome has no contact.  Native backend only."""
-    from .hicfile import HicFile, read_intra_packed
+    from .hicfile import read_intra_packed
     norm = "KR" if not norm_method else str(norm_method)
-    with HicFile(f) as h:
+    alloc = None
+    try:
+        import torch
+        if torch.cuda.is_available():
+            from .normalize import pinned_packed_alloc as alloc
+    except ImportError:
+        pass
+    h = _hic_handle(f)
+    if True:
         if not CHRM_SIZE:
             sizes = {"chr" + name.replace("chr", ''): length for name, length in h.chromosomes()[1:]}
             key = "chr" + str(chr1).replace("chr", '')
@@ -151,7 +172,7 @@ def read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, res):
             CHRM_SIZE = sizes[key]
         print("reading %s through the native .hic reader, packed records (MUSTACHE_HIC_BACKEND=auto|native|hicstraw)"
               % os.path.basename(str(f)))
-        pc = read_intra_packed(h, chr1, res, norm, int(distance_in_bp // res), int(CHRM_SIZE))
+        pc = read_intra_packed(h, chr1, res, norm, int(distance_in_bp // res), int(CHRM_SIZE), alloc=alloc)
     if len(pc) == 0:
         print(f'There is no contact in chrmosome {chr1} to work on.')
         return None

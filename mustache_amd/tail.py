@@ -199,8 +199,12 @@ def batch_tail(batch, bs, starts, pt, st, intra=True):
     if intra and keep:                                                       # (:822-828)
         idxs = diag_mean_filter_multi(batch, [bs[j] for j, _, _, _ in keep], [k[2] for k in keep], [k[3] for k in keep])
         keep = [(j, q, idx, None) for (j, q, _, _), idx in zip(keep, idxs) if idx.size]
-    for j, q, idx, _ in keep:
-        reps = cluster_representatives(batch, bs[j], q, idx)
+    multi = getattr(batch, "cluster_representatives_multi", None)
+    if multi is not None and keep:              # device clustering, all blocks in one launch (mst_cluster_representatives)
+        reps_all = multi([bs[j] for j, _, _, _ in keep], [k[1] for k in keep], [k[2] for k in keep], pt)
+    else:                                       # host form (test doubles without a device; the cross-check of the kernel)
+        reps_all = [cluster_representatives(batch, bs[j], q, idx) for j, q, idx, _ in keep]
+    for (j, q, idx, _), reps in zip(keep, reps_all):
         out[j] = loops_from_reps(batch, bs[j], q, reps, starts[j])
     return out
 

@@ -9,7 +9,7 @@ flags="$*"
 make -j8 >/dev/null
 mkdir -p ../../scratch_libs build_var_$name
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function \
-    -fno-honor-nans -mno-amdgpu-ieee -DMST_TILE_K=8 -DMST_TILE_W=64 $flags -c mst_scale_space.hip -o build_var_$name/ss.o
+    -fno-honor-nans -mno-amdgpu-ieee $flags -c mst_scale_space.hip -o build_var_$name/ss.o
 objs=$(ls build/*.o | grep -v mst_scale_space)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch_libs/$name.so $objs build_var_$name/ss.o
 python ../../scripts/kernel_resources.py ../../scratch_libs/$name.so "scale_space_kernel" | grep "Tile<32, 64, 14, 8, 1, false>" 

@@ -10,12 +10,12 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$REPO
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu > $OUT/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu --no-file > $OUT/bench_trace.log 2>&1
 # PMC: one launch for all 12 blocks of the --small workload (MST_BENCH_OVERLAP=1), so a dispatch's counters cover a known
 # pixel count; the same runs also hold the normalisation kernels (n = 26,000 bins) and the two-sample kernels (chr21 shape)
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
   N=$(echo $C | cut -d' ' -f1)
-  MST_BENCH_OVERLAP=1 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$N -o pmc --output-format csv -- python $REPO/bench.py --small --steps 1 --warmup 0 --no-cpu > $OUT/bench_pmc_$N.log 2>&1
+  MST_BENCH_OVERLAP=1 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$N -o pmc --output-format csv -- python $REPO/bench.py --small --steps 1 --warmup 0 --core > $OUT/bench_pmc_$N.log 2>&1
 done
 cd $REPO && python scripts/summarize_profile.py $TAG $OUT > $OUT/summarize.log 2>&1
 tail -5 $OUT/summarize.log

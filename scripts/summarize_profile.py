@@ -15,9 +15,9 @@ out_md = os.path.join(src, tag + "_summary.md")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 lines = ["# rocprofv3 summary `%s`" % tag, "",
-         "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu` "
+         "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu --no-file` "
          "(scripts/profile_bench.sh); PMC passes: `rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --small "
-         "--steps 1 --warmup 0 --no-cpu` with `MST_BENCH_OVERLAP=1` (12 blocks of 4000x4000 in ONE launch), one pass per counter "
+         "--steps 1 --warmup 0 --core` with `MST_BENCH_OVERLAP=1` (12 blocks of 4000x4000 in ONE launch), one pass per counter "
          "group, all in the same session as the trace.  The traced run uses bench.py's default of 4 launches per step on alternating streams.", ""]
 
 # ---- kernel stats ------------------------------------------------------------------------------------------------

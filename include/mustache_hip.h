@@ -283,6 +283,8 @@ int mst_pair_pvalues(const mst_found *found, uint32_t found_cap, const uint32_t 
  * (SciPy tap order, no FMA) and only  dog[oct][b] = G_2 - G_3  (dev [n_octaves][B][CH][CH]) is written, together with
  * fit[oct][b] = {loc, scale} of norm.fit over the doubly tested pixels (dev [n_octaves][B][2]; scale from one pass,
  * sqrt(mean(x^2) - loc^2)) and mask_count[b] = their number.  No dense block, difference image or blurred level reaches HBM.
+ * dog is written only in the tiles whose pixels can reach the tested band 4 <= col - row <= dpx + 1 (every found pixel lies
+ * in one; the others hold no pixel of the fit either) -- the rest of the buffer is left as it was.
  * lv: the SAME level table as the sigma loop (levels 2 and 3 of each octave are used).  starts: host [B]. */
 uint64_t mst_diff_dog_workspace_bytes(int32_t B, int32_t CH, const mst_levels *lv);
 int mst_diff_dog_band(const double *band1, const double *band2, int64_t n, int32_t dpx, const int64_t *starts, int32_t B,

@@ -16,6 +16,7 @@
 // D_2 per octave plus the masked sums of norm.fit: no dense blocks, no difference image, no G_2 / G_3 in HBM.
 #include <cmath>
 #include <cstring>
+#include <vector>
 #include "mst_common.h"
 #include "mst_fir.h"
 
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(T::NT)
 diff_dog_kernel(const double *__restrict__ band1, const double *__restrict__ band2, int64_t n, int dpx,
                 const int64_t *__restrict__ starts, int CH, int B, const DiffLevels *__restrict__ lv,
                 double *__restrict__ dog, double *__restrict__ partial, uint32_t *__restrict__ mask_count, int tiles_x,
-                int ntiles) {
+                int n_slots, const int32_t *__restrict__ tile_list) {
     constexpr int K = T::K, RGR = T::RGR, RGC = T::RGC, RMAX = T::RMAX;
     extern __shared__ __align__(16) double lds[];
     double *ct = lds;
@@ -172,8 +173,11 @@ diff_dog_kernel(const double *__restrict__ band1, const double *__restrict__ ban
     double *red = vb + T::VB_ELEMS;                     // 2 * NT doubles: the masked sums' reduction
     const int tid = threadIdx.x, b = blockIdx.y;
     const int per_xcd = gridDim.x >> 3;                 // XCD-aware order, as in the fused kernel
-    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= ntiles) return;
+    // a slot is an entry of the host's list of tiles whose pixels can reach the doubly tested band 4 <= col - row <= dpx + 1:
+    // the others hold no pixel of either mask (their sums are zero) and no found pixel ever reads their DoG values
+    const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (slot >= n_slots) return;
+    const int tile = tile_list[slot];
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int y0 = ty * RGR, x0 = tx * RGC;
     const int rr = tid % RGR, cg = tid / RGR;
@@ -277,7 +281,7 @@ diff_dog_kernel(const double *__restrict__ band1, const double *__restrict__ ban
     const double *vsrc = ct + v_col * T::CTP + v_rgp * K;
     double *vdst = vb + (v_rgp * K) * T::VP + v_col;
     const double *hsrc = vb + rr * T::VP + cg * K;
-    double *part = partial + (((size_t)b * ntiles + tile) * lv->n_octaves) * 2;
+    double *part = partial + (((size_t)b * n_slots + slot) * lv->n_octaves) * 2;
     for (int o = 0; o < lv->n_octaves; ++o) {
         double g2[K], g3[K];
         {
@@ -325,14 +329,17 @@ diff_dog_kernel(const double *__restrict__ band1, const double *__restrict__ ban
 // loc = mean, scale = sqrt(mean(x^2) - loc^2).  (One pass: the DoG of a difference image has |mean| << std, so the
 // subtraction costs no accuracy; the reference's two-pass value is reproduced to ~1e-15 relative.)
 __global__ void __launch_bounds__(256)
-diff_fit_kernel(const double *__restrict__ partial, int ntiles, int n_oct, int B, const uint32_t *__restrict__ mask_count,
-                double *__restrict__ fit) {
+diff_fit_kernel(const double *__restrict__ partial, int ntiles, int n_slots, const int32_t *__restrict__ slot_of_tile,
+                int n_oct, int B, const uint32_t *__restrict__ mask_count, double *__restrict__ fit) {
     __shared__ double sa[256], sb[256];
     const int o = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     double a = 0.0, q = 0.0;
+    // summation order fixed by the TILE numbering: a tile that was not launched would have contributed {0, 0}
     for (int i = tid; i < ntiles; i += 256) {
-        a = a + partial[(((size_t)b * ntiles + i) * n_oct + o) * 2];
-        q = q + partial[(((size_t)b * ntiles + i) * n_oct + o) * 2 + 1];
+        const int sl = slot_of_tile[i];
+        if (sl < 0) continue;
+        a = a + partial[(((size_t)b * n_slots + sl) * n_oct + o) * 2];
+        q = q + partial[(((size_t)b * n_slots + sl) * n_oct + o) * 2 + 1];
     }
     sa[tid] = a;
     sb[tid] = q;
@@ -407,16 +414,32 @@ int diff_levels(const mst_levels *lv, DiffLevels *out, int *max_radius) {
 
 template <class T>
 int diff_dog_launch(const double *band1, const double *band2, int64_t n, int dpx, const int64_t *d_starts, int CH, int B,
-                    const DiffLevels *d_lv, int n_oct, double *dog, double *partial, uint32_t *mask_count, double *fit,
-                    hipStream_t s) {
+                    const DiffLevels *d_lv, int n_oct, double *dog, double *partial, int32_t *d_tiles, uint32_t *mask_count,
+                    double *fit, hipStream_t s) {
     static unsigned long long lds_allowed = 0;
     MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&diff_dog_kernel<T>), (int)diff_lds_bytes<T>(),
                                    &lds_allowed));
     const int tx = (CH + T::RGC - 1) / T::RGC, nt = diff_tiles<T>(CH);
-    diff_dog_kernel<T><<<dim3((nt + 7) / 8 * 8, B), T::NT, diff_lds_bytes<T>(), s>>>(band1, band2, n, dpx, d_starts, CH, B,
-                                                                                   d_lv, dog, partial, mask_count, tx, nt);
-    MST_LAUNCH_CHECK();
-    diff_fit_kernel<<<dim3(n_oct, B), 256, 0, s>>>(partial, nt, n_oct, B, mask_count, fit);
+    // tiles (no ring here: a tile owns all its RGR x RGC pixels) that can reach the band, row-major; and the inverse map
+    std::vector<int32_t> list(2 * (size_t)nt, -1);
+    int m = 0;
+    for (int t = 0; t < nt; ++t) {
+        const int y0 = (t / tx) * T::RGR, x0 = (t % tx) * T::RGC;
+        const int r_hi = y0 + T::RGR - 1 < CH - 1 ? y0 + T::RGR - 1 : CH - 1;
+        const int c_hi = x0 + T::RGC - 1 < CH - 1 ? x0 + T::RGC - 1 : CH - 1;
+        if (c_hi - y0 >= 4 && x0 - r_hi <= dpx + 1) {
+            list[(size_t)nt + t] = m;
+            list[(size_t)m++] = t;
+        }
+    }
+    MST_HIP(mst::upload_small(d_tiles, list.data(), sizeof(int32_t) * 2 * (size_t)nt, s));
+    if (m > 0) {
+        diff_dog_kernel<T><<<dim3((m + 7) / 8 * 8, B), T::NT, diff_lds_bytes<T>(), s>>>(band1, band2, n, dpx, d_starts, CH, B,
+                                                                                      d_lv, dog, partial, mask_count, tx, m,
+                                                                                      d_tiles);
+        MST_LAUNCH_CHECK();
+    }
+    diff_fit_kernel<<<dim3(n_oct, B), 256, 0, s>>>(partial, nt, m, d_tiles + nt, n_oct, B, mask_count, fit);
     MST_LAUNCH_CHECK();
     return MST_OK;
 }
@@ -427,7 +450,7 @@ extern "C" uint64_t mst_diff_dog_workspace_bytes(int32_t B, int32_t CH, const ms
     if (B <= 0 || CH <= 0 || !lv || lv->n_octaves < 1 || lv->n_octaves > 16) return 0;
     const int nt = diff_tiles<DiffTile28>(CH);          // the smallest tile has the most tiles
     return diff_align(sizeof(DiffLevels)) + diff_align(sizeof(int64_t) * (size_t)B) +
-           sizeof(double) * 2 * (size_t)B * nt * lv->n_octaves;
+           diff_align(sizeof(int32_t) * 2 * (size_t)nt) + sizeof(double) * 2 * (size_t)B * nt * lv->n_octaves;
 }
 
 extern "C" int mst_diff_dog_band(const double *band1, const double *band2, int64_t n, int32_t dpx, const int64_t *starts,
@@ -448,17 +471,19 @@ extern "C" int mst_diff_dog_band(const double *band1, const double *band2, int64
     w += diff_align(sizeof(DiffLevels));
     int64_t *d_starts = reinterpret_cast<int64_t *>(w);
     w += diff_align(sizeof(int64_t) * (size_t)B);
+    int32_t *d_tiles = reinterpret_cast<int32_t *>(w);
+    w += diff_align(sizeof(int32_t) * 2 * (size_t)diff_tiles<DiffTile28>(CH));
     double *partial = reinterpret_cast<double *>(w);
     MST_HIP(mst::upload_small(d_lv, &h, sizeof(h), s));
     MST_HIP(mst::upload_small(d_starts, starts, sizeof(int64_t) * B, s));
     MST_HIP(hipMemsetAsync(mask_count, 0, sizeof(uint32_t) * B, s));
     if (mr <= DiffTile8::RMAX)
-        return diff_dog_launch<DiffTile8>(band1, band2, n, dpx, d_starts, CH, B, d_lv, h.n_octaves, dog, partial,
+        return diff_dog_launch<DiffTile8>(band1, band2, n, dpx, d_starts, CH, B, d_lv, h.n_octaves, dog, partial, d_tiles,
                                           mask_count, fit, s);
     if (mr <= DiffTile14::RMAX)
-        return diff_dog_launch<DiffTile14>(band1, band2, n, dpx, d_starts, CH, B, d_lv, h.n_octaves, dog, partial,
+        return diff_dog_launch<DiffTile14>(band1, band2, n, dpx, d_starts, CH, B, d_lv, h.n_octaves, dog, partial, d_tiles,
                                            mask_count, fit, s);
-    return diff_dog_launch<DiffTile28>(band1, band2, n, dpx, d_starts, CH, B, d_lv, h.n_octaves, dog, partial,
+    return diff_dog_launch<DiffTile28>(band1, band2, n, dpx, d_starts, CH, B, d_lv, h.n_octaves, dog, partial, d_tiles,
                                        mask_count, fit, s);
 }
 

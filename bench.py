@@ -596,9 +596,18 @@ def main():
             eng.run_band_pairs([wg.band, wg.band2], wg.n, wg.dpx, wg.start, wg.CH, select_below=0.1)
         torch.cuda.synchronize()
         gp_s = wg.total_mpix * 1e6 / ((time.time() - t0) / gsteps)
+        from mustache_amd.diff_mustache import run_pair_layout
+        run_pair_layout(wg.pipe, wg.layout, [wg.band, wg.band2], 0.88, 0.1, 0.1)
+        t0 = time.time()
+        rows = run_pair_layout(wg.pipe, wg.layout, [wg.band, wg.band2], 0.88, 0.1, 0.1)
+        gp_e2e = time.time() - t0
         gp_flops = 2 * FLOPS_PER_PIXEL * g_frac + 146.0
         out["diff_genome_5kb"] = {"value": round(gp_s / 1e6, 1), "unit": "Mpix-pairs/s", "block_pairs": len(wg.start),
                                   "chunk": wg.CH, "chromosomes": len(HG19),
+                                  "end_to_end": {"rows_2_to_9_both_samples_s": round(gp_e2e, 3),
+                                                 "tagged_rows": sum(len(o) for o in rows),
+                                                 "note": "run_pair_layout: the device part above + the batched host tail "
+                                                         "(filters, device clustering, differential test, overlap masks)"},
                                   "roofline": {"bound": "fp64_valu", "flops_per_pixel_pair_launched": round(gp_flops, 1),
                                                "launched_tile_fraction": round(g_frac, 4),
                                                "achieved": round(gp_s * gp_flops / 1e12, 3), "peak": peak_tf,

@@ -23,56 +23,84 @@ import time
 import numpy as np
 
 from .mustache import (_engine, block_tiling, block_mask_size, parseBP, read_pd)
-from .tail import fdr_candidates, diag_mean_filter, cluster_representatives, loops_from_reps
+from .tail import (fdr_candidates_multi, diag_mean_filter_multi, cluster_representatives, loops_from_reps,
+                   _features_multi)
+
+
+def _pair_tails(batch, pairs, pt, pt2, st, intra):
+    """diff_mustache.py:428-569 for several block pairs at once: pairs = [(b1, b2, start)] (block of sample 1, block of
+    sample 2, coordinate offset).  Every stage -- BH candidates + sparsity windows, diagonal means, clustering, the
+    tested-in-the-other-sample look-up -- is ONE device round trip for all the pairs instead of one per block.  Returns one
+    (loops1, diff_loops1, loops2, diff_loops2) tuple per pair, identical to the pair-by-pair evaluation."""
+    empty = ([], [], [], [])
+    out = [empty for _ in pairs]
+    live = [k for k, (b1, b2, _) in enumerate(pairs)
+            if batch.nz_count[b1] >= 50 and batch.nz_count[b2] >= 50                      # (:266)
+            and batch.nz_count[b1] >= 10000 and batch.nz_count[b2] >= 10000]              # (:430)
+    if not live:
+        return out
+    blocks = [b for k in live for b in pairs[k][:2]]
+    cand = fdr_candidates_multi(batch, blocks, pt, st)                                     # (:432-505)
+    state = {}
+    for j, k in enumerate(live):
+        (q1, i1, c1), (q2, i2, c2) = cand[2 * j], cand[2 * j + 1]
+        if i1.size and i2.size:                                                            # (:507)
+            state[k] = [q1, i1, c1, q2, i2, c2]
+    if intra and state:                                                                    # (:516-529)
+        ks = list(state)
+        # the reference filters sample 1 first and returns if nothing is left, then sample 2: evaluating both is the same
+        flt = diag_mean_filter_multi(batch, [b for k in ks for b in pairs[k][:2]],
+                                     [state[k][i] for k in ks for i in (1, 4)], [state[k][i] for k in ks for i in (2, 5)])
+        for j, k in enumerate(ks):
+            state[k][1], state[k][4] = flt[2 * j], flt[2 * j + 1]
+            if state[k][1].size == 0 or state[k][4].size == 0:
+                del state[k]
+    if not state:
+        return out
+    ks = list(state)
+    cl_blocks = [b for k in ks for b in pairs[k][:2]]
+    cl_q = [state[k][i] for k in ks for i in (0, 3)]
+    cl_idx = [state[k][i] for k in ks for i in (1, 4)]
+    multi = getattr(batch, "cluster_representatives_multi", None)                          # (:531-561)
+    reps_all = multi(cl_blocks, cl_q, cl_idx, pt) if multi is not None else \
+        [cluster_representatives(batch, b, q, idx) for b, q, idx in zip(cl_blocks, cl_q, cl_idx)]
+    # is the representative's pixel tested in the OTHER sample?  one gather for all pairs
+    other_blocks = [pairs[k][1 - s_] for k in ks for s_ in (0, 1)]
+    rep_pix = [batch.found[b]["pixel"][reps] if reps else np.zeros(0, np.uint32) for b, reps in zip(cl_blocks, reps_all)]
+    feats = _features_multi(batch, other_blocks, rep_pix, [np.zeros(len(p), np.int64) for p in rep_pix])
+    for j, k in enumerate(ks):
+        b1, b2, start = pairs[k]
+        res4 = []
+        for s_, (b, bo) in enumerate(((b1, b2), (b2, b1))):
+            q, reps, pix, nz_other = cl_q[2 * j + s_], reps_all[2 * j + s_], rep_pix[2 * j + s_], feats[2 * j + s_][0]
+            loops = loops_from_reps(batch, b, q, reps, start)
+            rec, other = batch.found[b], batch.found[bo]
+            # differential subset (:567-568): pair < pt2 and v_self > v_other, where v = 1 off-nz, vAll on nz (0 if not found)
+            looked_up = "v_other" in rec       # selected-only records (engine.run_band_pairs(select_below=pt)): device look-up
+            opix = None if looked_up else other["pixel"].astype(np.int64)
+            diff = []
+            for i, r in enumerate(reps):
+                p_ = int(pix[i])
+                if looked_up:
+                    v_other = rec["v_other"][r]
+                    if np.isnan(v_other):                                  # the other sample did not find this pixel
+                        v_other = 0.0 if nz_other[i] else 1.0
+                else:
+                    kk = int(np.searchsorted(opix, p_))
+                    if kk < len(opix) and opix[kk] == p_:
+                        v_other = other["value"][kk]
+                    else:
+                        v_other = 0.0 if nz_other[i] else 1.0
+                if rec["pair"][r] < pt2 and rec["value"][r] > v_other:
+                    diff.append(loops[i])
+            res4.extend([loops, diff])
+        out[k] = tuple(res4)
+    return out
 
 
 def _pair_tail(batch, b1, b2, start, pt, pt2, st, intra):
     """diff_mustache.py:428-569 on the records of blocks b1 (sample 1) and b2 (sample 2)."""
-    empty = ([], [], [], [])
-    if batch.nz_count[b1] < 50 or batch.nz_count[b2] < 50:                 # (:266)
-        return empty
-    if batch.nz_count[b1] < 10000 or batch.nz_count[b2] < 10000:           # (:430)
-        return empty
-    q1, i1 = fdr_candidates(batch, b1, pt, st)                             # (:432-505)
-    q2, i2 = fdr_candidates(batch, b2, pt, st)
-    if i1.size == 0 or i2.size == 0:                                       # (:507)
-        return empty
-    if intra:                                                              # (:516-529)
-        i1 = diag_mean_filter(batch, b1, i1)
-        if i1.size == 0:
-            return empty
-        i2 = diag_mean_filter(batch, b2, i2)
-        if i2.size == 0:
-            return empty
-    out = []
-    multi = getattr(batch, "cluster_representatives_multi", None)       # both samples' blocks in one launch (:531-561)
-    reps_both = multi([b1, b2], [q1, q2], [i1, i2], pt) if multi is not None else \
-        [cluster_representatives(batch, b1, q1, i1), cluster_representatives(batch, b2, q2, i2)]
-    for (b, q, idx, bo), reps in zip(((b1, q1, i1, b2), (b2, q2, i2, b1)), reps_both):
-        loops = loops_from_reps(batch, b, q, reps, start)
-        rec, other = batch.found[b], batch.found[bo]
-        # differential subset (:567-568): pair < pt2 and v_self > v_other, where v = 1 off-nz, vAll on nz (0 if not found)
-        pix = rec["pixel"][reps] if reps else np.zeros(0, np.uint32)
-        nz_other, _, _ = batch.candidate_features(bo, pix, np.zeros(len(pix), np.int64))
-        looked_up = "v_other" in rec           # selected-only records (engine.run_band_pairs(select_below=pt)): device look-up
-        opix = None if looked_up else other["pixel"].astype(np.int64)
-        diff = []
-        for j, r in enumerate(reps):
-            p = int(pix[j])
-            if looked_up:
-                v_other = rec["v_other"][r]
-                if np.isnan(v_other):                                      # the other sample did not find this pixel
-                    v_other = 0.0 if nz_other[j] else 1.0
-            else:
-                k = int(np.searchsorted(opix, p))
-                if k < len(opix) and opix[k] == p:
-                    v_other = other["value"][k]
-                else:
-                    v_other = 0.0 if nz_other[j] else 1.0
-            if rec["pair"][r] < pt2 and rec["value"][r] > v_other:
-                diff.append(loops[j])
-        out.extend([loops, diff])
-    return tuple(out)
+    return _pair_tails(batch, [(b1, b2, start)], pt, pt2, st, intra)[0]
 
 
 def diff_mustache(c1, c2, chromosome, chromosome2, res, start, end, mask_size, distance_in_px, octave_values, st, pt,
@@ -142,10 +170,15 @@ def run_pair_genome(pipe, pairs, distance_in_px, st, pt, pt2):
     pairs is one engine.run_band_pairs call.  Returns the tagged rows [x, y, fdr, sigma, tag] per chromosome, identical to
     call_diff_loops_coo on each chromosome alone."""
     from .pipeline import GenomeLayout
-    eng = pipe.engine
     lay = GenomeLayout([n for _, n in pairs], distance_in_px)
-    CH = lay.CH
     gbands = [lay.band([d[s_] for d, _ in pairs], pipe.device) for s_ in (0, 1)]
+    return run_pair_layout(pipe, lay, gbands, st, pt, pt2)
+
+
+def run_pair_layout(pipe, lay, gbands, st, pt, pt2):
+    """run_pair_genome's body on a prepared layout + the two samples' genome bands."""
+    eng = pipe.engine
+    CH, distance_in_px, pairs = lay.CH, lay.dpx, lay.ns
     # per block pair in HBM: D_2 of the difference image for every octave + the two samples' record buffers
     per_pair = len(eng.levels.octave_values) * CH * CH * 8 + 2 * max(4096, CH * CH // 32) * 48
     bs = max(1, int(pipe.max_batch_bytes // per_pair))
@@ -154,10 +187,11 @@ def run_pair_genome(pipe, pairs, distance_in_px, st, pt, pt2):
         grp = lay.blocks[g0:g0 + bs]
         batch = eng.run_band_pairs(gbands, lay.N, distance_in_px, [g[3] for g in grp], CH, select_below=pt)
         P = len(grp)
+        tails = _pair_tails(batch, [(j, P + j, g[2]) for j, g in enumerate(grp)], pt, pt2, st, True)
         for j, (c, i, s_loc, _) in enumerate(grp):
             _, start, end = lay.tiling[c]
             mask = block_mask_size(i, start, end, distance_in_px)
-            _append_tagged(out[c], _pair_tail(batch, j, P + j, s_loc, pt, pt2, st, True), s_loc, mask)
+            _append_tagged(out[c], tails[j], s_loc, mask)
         del batch
     return out
 

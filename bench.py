@@ -10,7 +10,7 @@ pass of rows 2-7 of SURVEY.md section 8a over ALL blocks of the chromosome:
     normalised band resident in HBM -> fused kernel (dense blocks cut out of the band, filled and masked while the tile is
     staged; sigma-stack / DoG / 3x3 max / sieve / level statistics) -> p-values of the found pixels -> compacted found
     records on the host.
-With N ranks the 124 blocks are dealt round-robin (strong scaling, no data-path collective); the step time is the
+With N ranks the 124 blocks are split into N contiguous ranges (strong scaling, no data-path collective); the step time is the
 MAX over ranks between two barriers.  `value` = 1,984 Mpix / step time, whole job.
 
 Also reported on the same JSON line:
@@ -64,6 +64,27 @@ def band_tile_fraction(CH, dpx):
     if m < 0 or total.value <= 0:
         raise RuntimeError("mst_scale_space_band_tiles failed")
     return m / float(total.value)
+
+
+def work_items(w, skip_empty, share=True):
+    """(workgroups launched, tiles the blocks would run one by one, tiles computed once for two blocks) summed over the
+    launches of one step of workload w -- asked of the library (mst_scale_space_band_items)."""
+    import ctypes
+    from mustache_amd import _lib
+    lib = _lib.load()
+    lv = ctypes.byref(w.pipe.engine._lv_struct)
+    flags = (1 if skip_empty else 0) | (0 if share else 4)
+    tot = [0, 0, 0]
+    for g in w.groups:
+        st = (ctypes.c_int64 * len(g))(*[int(w.start[i]) for i in g])
+        tiles, shared = ctypes.c_int64(), ctypes.c_int64()
+        m = lib.mst_scale_space_band_items(st, len(g), int(w.CH), int(w.dpx), lv, flags, ctypes.byref(tiles), ctypes.byref(shared))
+        if m < 0:
+            raise RuntimeError("mst_scale_space_band_items failed")
+        tot[0] += m
+        tot[1] += tiles.value
+        tot[2] += shared.value
+    return tuple(tot)
 
 
 def parse():
@@ -401,7 +422,7 @@ def main():
     launches_per_step = max(1, len(kms) // args.steps)
     k_ms = sum(kms) / len(kms)
     # every rank's own view on stderr, so that a partial failure of an N > 1 run can be told from the log
-    print("RANK_FRAGMENT " + json.dumps({"rank": rank, "world": world, "device": local, "backend": backend if grouped else None,
+    print("\nRANK_FRAGMENT " + json.dumps({"rank": rank, "world": world, "device": local, "backend": backend if grouped else None,
                                          "blocks": len(w.mine), "own_ms_per_step": round(owns[rank if grouped else 0] / args.steps * 1e3, 3),
                                          "kernel_ms_mean": round(k_ms, 3), "job_ms_per_step": round(ms_per_step, 3)}),
           file=sys.stderr, flush=True)
@@ -429,6 +450,14 @@ def main():
     import re
     cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))
                    if re.fullmatch(r"r\d+_pmc_traffic\.json", os.path.basename(f)))
+    wi = work_items(w, False)
+    roof.update({"work_items": wi[0], "tiles": wi[1], "shared_tiles": wi[2],
+                 "executed_frac": round(px_per_launch * exec_fpp * wi[0] / wi[1] / (k_ms * 1e-3) / 1e12 / peak_tf, 4),
+                 "sharing_note": "consecutive blocks overlap by half their edge (mustache.py:899-908); a tile that lies inside two "
+                                 "blocks of a launch with its whole blur halo is computed once and its records / statistics are "
+                                 "delivered to both (identical bits, tests): `achieved` counts the algorithmic flops of every "
+                                 "block pixel as the metric does, `executed_frac` only the workgroups really run -- the figure "
+                                 "comparable with rounds 1-2 is no_share.roofline"})
     pmc = cands[-1] if cands else ""                      # the latest round's profiling session
     if pmc:
         try:
@@ -456,6 +485,29 @@ def main():
                          "block pixels (the headline value / roofline are always the dense run); band_skip.roofline prices the "
                          "launched tiles alone"}
     band_skip["roofline"]["frac"] = round(band_skip["roofline"]["achieved"] / peak_tf, 4)
+    wis = work_items(w, True)
+    band_skip["roofline"].update({"work_items": wis[0], "tiles": wis[1], "shared_tiles": wis[2],
+                                  "executed_frac_on_run_workgroups": round(band_skip["roofline"]["frac"] * wis[0] / wis[1], 4)})
+
+    # the same two steps with every tile computed once PER BLOCK on the block's own lattice (MST_FLAG_NO_SHARE, the form of
+    # rounds 1 and 2): identical records; this is the figure that measures the kernel itself
+    w.pipe.engine.share_tiles = False
+    dt_n, kms_n, _, _ = timed(False, max(1, args.steps // 2), 1)
+    dt_ns, kms_ns, _, _ = timed(True, max(1, args.steps // 2), 1)
+    w.pipe.engine.share_tiles = True
+    hs = max(1, args.steps // 2)
+    kn, kns = sum(kms_n) / hs, sum(kms_ns) / hs
+    tf_n = len(w.mine) * w.CH * w.CH * FLOPS_PER_PIXEL / (kn * 1e-3) / 1e12
+    tf_ns = len(w.mine) * w.CH * w.CH * band_tile_fraction(w.CH, w.dpx) * FLOPS_PER_PIXEL / (kns * 1e-3) / 1e12
+    no_share = {"value": round(w.total_mpix / (dt_n / hs), 1), "unit": "Mpix/s", "kernel_ms_per_step": round(kn, 3),
+                "roofline": {"bound": "fp64_valu", "achieved": round(tf_n, 3), "peak": peak_tf, "unit": "TFLOP/s",
+                             "frac": round(tf_n / peak_tf, 4)},
+                "band_skip": {"value": round(w.total_mpix / (dt_ns / hs), 1), "unit": "Mpix/s",
+                              "kernel_ms_per_step": round(kns, 3),
+                              "roofline": {"bound": "fp64_valu", "achieved": round(tf_ns, 3), "peak": peak_tf,
+                                           "unit": "TFLOP/s", "frac": round(tf_ns / peak_tf, 4)}},
+                "note": "MST_FLAG_NO_SHARE: every workgroup's flops are algorithmic flops of one block -- the kernel's own "
+                        "efficiency, comparable with the roofline figures of rounds 1 and 2"}
 
     # opt-in relaxed arithmetic (fused multiply-add per tap pair): DoG no longer bit-identical (~1e-16 relative, north_star
     # allows 1e-5), found set unchanged on every case tested.  Reported separately; `value` is always the exact mode.
@@ -468,7 +520,7 @@ def main():
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": w.name, "blocks": len(w.start), "chunk": w.CH, "distance_px": w.dpx,
-                      "megapixels_per_step": round(w.total_mpix, 1), "sharding": "blocks round-robin over %d rank(s)" % world,
+                      "megapixels_per_step": round(w.total_mpix, 1), "sharding": "blocks in contiguous ranges over %d rank(s)" % world,
                       "timed_region": "normalised band in HBM -> fused kernel (blocks cut, filled and masked in-kernel; "
                                       "sigma loop, sieve, level statistics) -> p-values -> found records on host; "
                                       "%d launches per step, the download of one under the kernel of the next" % OVERLAP},
@@ -478,9 +530,9 @@ def main():
                      "imbalance_bound": round(-(-len(w.start) // world) * world / len(w.start), 4),
                      "efficiency_bound": round(len(w.start) / (world * -(-len(w.start) // world)), 4),
                      "efficiency_bound_at": {str(k): round(len(w.start) / (k * -(-len(w.start) // k)), 4) for k in (1, 2, 4, 8)},
-                     "note": "round-robin split of the blocks: the slowest rank carries ceil(blocks / ranks) blocks, so "
+                     "note": "contiguous split of the blocks: the slowest rank carries ceil(blocks / ranks) blocks, so "
                              "the strong-scaling efficiency cannot exceed blocks / (ranks * ceil(blocks / ranks))"},
-           "roofline": roof, "band_skip": band_skip, "fma_mode": fma_mode,
+           "roofline": roof, "band_skip": band_skip, "no_share": no_share, "fma_mode": fma_mode,
            "normalize_ms_untimed": round(w.normalize_s * 1e3, 2),
            # row 1 of SURVEY 8a next to it: 16 B per band sample (8 read + 8 written) over mst_normalize_band (median of 3,
            # HIP events: the per-diagonal statistics pass + the window pass; the statistics pass reads the band once more)

@@ -38,6 +38,9 @@ extern "C" {
 
 /* mst_scale_space flags */
 #define MST_FLAG_SKIP_EMPTY 1 /* tiles that contain no nz pixel are not computed (identical outputs, less work) */
+#define MST_FLAG_NO_SHARE 4   /* band source only: compute every tile once PER BLOCK on the block's own tile lattice (the form
+                               * of rounds 1 and 2).  Default: a tile that lies inside two consecutive blocks with its whole
+                               * blur halo is computed once and delivered to both (identical records; see mst_scale_space_band) */
 #define MST_FLAG_FMA 2        /* OPT-IN relaxed arithmetic: fuse the multiply-add of each tap pair.  DoG values then differ
                                  from the reference's by ~1e-16 relative (instead of being bit-identical); default off */
 
@@ -224,9 +227,15 @@ int mst_scale_space_band(const double *band, int64_t n, int32_t dpx, const int64
                          double *level_stats, uint32_t *nz_count, int32_t flags, void *workspace,
                          uint64_t workspace_bytes, void *stream);
 /* How many of a block's tiles mst_scale_space_band launches with MST_FLAG_SKIP_EMPTY (those whose pixels can reach the tested
- * band 4 <= col - row <= dpx + 1), and, through tiles_total, how many without it.  Depends on (CH, dpx, lv) only; < 0 on a
- * bad argument.  For measurement: the share of the dense work the skipping mode really does. */
+ * band 4 <= col - row <= dpx + 1), on the block's own tile lattice; *tiles_total = all tiles of the block.  Host only. */
 int mst_scale_space_band_tiles(int32_t CH, int32_t dpx, const mst_levels *lv, int32_t *tiles_total);
+/* The work list mst_scale_space_band would build for these blocks and flags (host only): returns the number of workgroups it
+ * launches; *tiles = the tiles the blocks would run one by one (workgroups + shared), *shared = tiles computed once for two
+ * consecutive blocks.  Consecutive blocks of a chromosome overlap by half their edge (mustache.py:899-908); a tile that lies
+ * inside both with its whole blur halo sees the same pixels in either, so its records and statistics are computed once and
+ * delivered to both -- unless MST_FLAG_NO_SHARE is set. */
+int mst_scale_space_band_items(const int64_t *starts, int32_t B, int32_t CH, int32_t dpx, const mst_levels *lv, int32_t flags,
+                               int64_t *tiles, int64_t *shared);
 
 /* mst_candidate_features / mst_gather_diagonals / mst_diag_means for the block that starts at bin `start` of the band. */
 int mst_candidate_features_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,

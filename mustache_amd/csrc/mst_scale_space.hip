@@ -34,6 +34,7 @@
 // Build flags for this file add -fno-honor-nans -mno-amdgpu-ieee: inputs are finite (checked through the level
 // statistics), and with IEEE mode off v_max_f64 needs no canonicalising pre-pass; no value-changing fast-math
 // flag (reassociation, contraction, reciprocal) is enabled.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -136,13 +137,23 @@ struct BandSrc {
     uint32_t *nz_count;        // dev [B]: out, number of tested pixels per block
 };
 
+// One workgroup's job: the tile whose region (interior + ring) starts at (y0, x0) of block b.  Consecutive blocks of a
+// chromosome overlap by half their edge (mustache.py:899-908), and a Gaussian level at a pixel depends on c within its blur
+// radius only: a tile that lies inside BOTH blocks, halo included, sees the same c values, fills and tested pixels in either
+// -- its DoG values, maxima, sieve decisions and statistics are the same bits.  Such a tile is computed ONCE (for block b) and
+// its found records, tested-pixel count and level statistics are delivered to block b2 as well (pixel indices shifted by
+// delta2 = start_b - start_b2 along both axes); b2 < 0: the tile belongs to one block only.  The host builds the list
+// (build_items): tiles sit on a lattice anchored at chromosome coordinate 0, so that overlapping blocks cut the same tiles.
+struct WorkItem {
+    int32_t y0, x0, b, delta2;      // delta2 != 0: also delivered to block b + 1 (delta2 = start_b - start_{b+1} < 0)
+};
+
 template <class T, bool BAND>
 __global__ void __launch_bounds__(T::NT, T::MINW)
 scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz, BandSrc src, int CH,
                    const DevLevels *__restrict__ lv, mst_found *__restrict__ found, uint32_t found_cap,
-                   uint32_t *__restrict__ found_count, double *__restrict__ partial, int tiles_x, int tiles_y,
-                   int n_tested, int skip_empty, const int32_t *__restrict__ tile_list, int n_slots, int variant,
-                   unsigned long long *__restrict__ trace) {
+                   uint32_t *__restrict__ found_count, double *__restrict__ partial, const WorkItem *__restrict__ items,
+                   int n_items, int n_tested, int skip_empty, int variant, unsigned long long *__restrict__ trace) {
     constexpr int K = T::K, RGR = T::RGR, RGC = T::RGC, RMAX = T::RMAX;
     extern __shared__ __align__(16) double lds[];
     double *ct = lds;
@@ -151,25 +162,22 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
     double *st = de + T::DE_ELEMS;
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.y;
     // XCD-aware order: hardware places workgroup i on XCD i % 8 (gridDim.x is a multiple of 8), so give each XCD a
-    // contiguous run of slots -- neighbouring tiles share their halo through that XCD's L2.  A slot is a tile, or, when
-    // the host passes the list of tiles that can reach the tested band (skip_empty on the band source), an entry of
-    // that list: every XCD then gets the same number of tiles WITH work (with all tiles in the grid the dispatcher, which
-    // hands out workgroups in order, waits for the XCD that holds the widest part of the band while the others idle).
+    // contiguous run of the item list -- neighbouring tiles share their halo through that XCD's L2.  The host orders the list
+    // so that every XCD's run holds the same mix of work (build_items).
     const int per_xcd = gridDim.x >> 3;
     const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (slot >= n_slots) return;
-    const int tile = tile_list ? tile_list[slot] : slot;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int y0 = ty * T::ITR - 1, x0 = tx * T::ITC - 1;  // block coordinates of region (0, 0)
+    if (slot >= n_items) return;
+    const WorkItem item = items[slot];
+    const int b = item.b, b2 = item.delta2 != 0 ? item.b + 1 : -1;
+    const int y0 = item.y0, x0 = item.x0;  // block coordinates of region (0, 0)
 
     const int rr = tid % RGR;  // region row owned in the H pass; consecutive lanes = consecutive rows
     const int cg = tid / RGR;  // column group
     const int gy = y0 + rr;
     const bool row_in = gy >= 0 && gy < CH;
     const bool row_own = row_in && rr >= 1 && rr <= T::ITR;
-    double *part = partial + ((size_t)b * n_slots + slot) * n_tested * 2;
+    double *part = partial + (size_t)slot * n_tested * 2;
 
     uint32_t in_mask = 0, nz_mask = 0;  // per-k bits: column inside the block / tested pixel owned by this thread
 #pragma unroll
@@ -218,17 +226,6 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
         const int64_t start = src.starts[b];
         const int64_t n = src.n;
         const int dpx = src.dpx;
-        // cheap geometric rejection first: can the owned pixels of this tile reach the tested band 4 <= off <= dpx+1 ?
-        const int r_lo = y0 + 1 > 0 ? y0 + 1 : 0, r_hi = y0 + T::ITR < CH - 1 ? y0 + T::ITR : CH - 1;
-        const int c_lo = x0 + 1 > 0 ? x0 + 1 : 0, c_hi = x0 + T::ITC < CH - 1 ? x0 + T::ITC : CH - 1;
-        const bool reaches_band = (c_hi - r_lo >= 4) && (c_lo - r_hi <= dpx + 1);
-        if (!reaches_band && skip_empty) {
-            for (int t = tid; t < n_tested; t += T::NT) {
-                part[2 * t] = INFINITY;
-                part[2 * t + 1] = 0.0;
-            }
-            return;
-        }
         uint8_t *nzb = reinterpret_cast<uint8_t *>(vb);      // [RGR][RGC] tested flags of the region; vb is free until the V pass
         const int Y0 = y0 - RMAX, X0 = x0 - RMAX;
         const bool inner = Y0 >= 0 && X0 >= 0 && Y0 + T::CTR <= CH && X0 + T::CTC <= CH;   // no reflection in this tile
@@ -317,7 +314,10 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
         mine = __builtin_popcount(nz_mask);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
-        if ((tid & 63) == 0 && mine) atomicAdd(src.nz_count + b, mine);       // integer: exact in any order
+        if ((tid & 63) == 0 && mine) {                                         // integer: exact in any order
+            atomicAdd(src.nz_count + b, mine);
+            if (b2 >= 0) atomicAdd(src.nz_count + b2, mine);
+        }
         const int any_nz = __syncthreads_or(nz_mask != 0);                  // also fences nzb reads before vb is reused
         if (!any_nz && skip_empty) {
             for (int t = tid; t < n_tested; t += T::NT) {
@@ -359,10 +359,10 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
     unsigned long long *tr = nullptr;
 #ifdef MST_PROFILE
     // timeline sample: MST_TRACE_WGS consecutive slots of block 0, starting at 3/8 of the grid (tiles inside the band)
-    if (trace && b == 0 && slot >= 3 * (n_slots >> 3) && slot < 3 * (n_slots >> 3) + MST_TRACE_WGS) {
-        tr = trace + ((size_t)(slot - 3 * (n_slots >> 3)) * T::NW + (tid >> 6)) * (MST_MAX_LEVELS + 1) * MST_TRACE_STAMPS;
+    if (trace && slot >= 3 * (per_xcd >> 3) && slot < 3 * (per_xcd >> 3) + MST_TRACE_WGS) {
+        tr = trace + ((size_t)(slot - 3 * (per_xcd >> 3)) * T::NW + (tid >> 6)) * (MST_MAX_LEVELS + 1) * MST_TRACE_STAMPS;
         MST_STAMP(tr, MST_MAX_LEVELS * MST_TRACE_STAMPS + 1)        // end of staging
-        if ((tid & 63) == 0) tr[MST_MAX_LEVELS * MST_TRACE_STAMPS + 2] = (unsigned long long)tile | ((unsigned long long)(nz_mask != 0) << 40);
+        if ((tid & 63) == 0) tr[MST_MAX_LEVELS * MST_TRACE_STAMPS + 2] = (unsigned long long)slot | ((unsigned long long)(nz_mask != 0) << 40);
     }
 #endif
     for (int o = 0; o < n_oct; ++o) {
@@ -506,19 +506,23 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
             tot += n;
         }
         cnt_lds[T::NW] = tot ? atomicAdd(found_count + b, tot) : 0u;
+        cnt_lds[T::NW + 1] = (tot && b2 >= 0) ? atomicAdd(found_count + b2, tot) : 0u;
     }
     __syncthreads();
     const uint32_t wave_base = cnt_lds[T::NW] + cnt_lds[wave];
+    const uint32_t wave_base2 = cnt_lds[T::NW + 1] + cnt_lds[wave];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (lvl[k]) {
-            const uint32_t pos = wave_base + kbase[k] + before[k];
-            if (pos < found_cap) {
-                mst_found rec;
-                rec.pixel = (uint32_t)gy * (uint32_t)CH + (uint32_t)(x0 + cg * K + k);
-                rec.level = lvl[k];
-                rec.value = best[k];
-                found[(size_t)b * found_cap + pos] = rec;
+            const uint32_t off = kbase[k] + before[k];
+            mst_found rec;
+            rec.pixel = (uint32_t)gy * (uint32_t)CH + (uint32_t)(x0 + cg * K + k);
+            rec.level = lvl[k];
+            rec.value = best[k];
+            if (wave_base + off < found_cap) found[(size_t)b * found_cap + wave_base + off] = rec;
+            if (b2 >= 0 && wave_base2 + off < found_cap) {          // the same pixel in the neighbouring block's coordinates
+                rec.pixel = (uint32_t)(gy + item.delta2) * (uint32_t)CH + (uint32_t)(x0 + cg * K + k + item.delta2);
+                found[(size_t)b2 * found_cap + wave_base2 + off] = rec;
             }
         }
     }
@@ -535,23 +539,25 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
     }
 }
 
-// partial[b][slot][t][2] -> level_stats[b][t][2].  The summation order is fixed by the TILE numbering (thread i takes tiles
-// i, i + 256, ... in ascending order, then a fixed tree), whether or not only a list of tiles was launched: a tile that
-// is not in the list (slot_of_tile < 0) would have contributed {inf, 0}, which changes neither the minimum nor the sum,
-// so a block's statistics do not depend on MST_FLAG_SKIP_EMPTY down to the last bit.
+// partial[item][t][2] -> level_stats[b][t][2].  A block's tiles are numbered by their position in ITS tile grid (row-major);
+// slot_of_pos[b][pos] is the work item that computed that tile -- one of the block's own, or a shared one that the previous
+// block's list carries -- or -1.  The summation order is fixed by the POSITION numbering (thread i takes positions i, i + 256,
+// ... in ascending order, then a fixed tree), whichever items were launched: a tile that is not in the list would have
+// contributed {inf, 0}, which changes neither the minimum nor the sum, so a block's statistics do not depend on
+// MST_FLAG_SKIP_EMPTY down to the last bit.
 __global__ void __launch_bounds__(256)
-stats_reduce_kernel(const double *__restrict__ partial, int ntiles, int n_slots, const int32_t *__restrict__ slot_of_tile,
-                    int n_tested, double *__restrict__ level_stats) {
+stats_reduce_kernel(const double *__restrict__ partial, int npos, const int32_t *__restrict__ slot_of_pos, int n_tested,
+                    double *__restrict__ level_stats) {
     __shared__ double smin[256], ssum[256];
     const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const double *p = partial + (size_t)b * n_slots * n_tested * 2;
+    const int32_t *sop = slot_of_pos + (size_t)b * npos;
     double mn = INFINITY, sm = 0.0;
-    for (int i = tid; i < ntiles; i += 256) {
-        const int slot = slot_of_tile ? slot_of_tile[i] : i;
+    for (int i = tid; i < npos; i += 256) {
+        const int slot = sop[i];
         if (slot < 0) continue;
-        const double a = p[((size_t)slot * n_tested + t) * 2];
+        const double a = partial[((size_t)slot * n_tested + t) * 2];
         mn = a < mn ? a : mn;
-        sm = sm + p[((size_t)slot * n_tested + t) * 2 + 1];
+        sm = sm + partial[((size_t)slot * n_tested + t) * 2 + 1];
     }
     smin[tid] = mn;
     ssum[tid] = sm;
@@ -593,17 +599,114 @@ using TileDefault = Tile<32, 64, 14>;   // the reference's default octaves (radi
 using TileWide = Tile<32, 32, 28, 4, 1>;   // -sz / -oc variants up to radius 28: 256 threads x 4 pixels (K = 8 spilled SGPRs and left half the SIMDs idle)
 using TileDefaultFma = Tile<32, 64, 14, 8, 1, true>;   // opt-in relaxed arithmetic (MST_FLAG_FMA), default radii only
 
+// A block's tile grid has at most this many rows / columns of tiles, whatever the lattice phase of its origin
 template <class T>
-int tiles_x(int CH) { return (CH + T::ITC - 1) / T::ITC; }
+int grid_rows(int CH) { return (CH + T::ITR - 1) / T::ITR + 1; }
 template <class T>
-int tiles_y(int CH) { return (CH + T::ITR - 1) / T::ITR; }
+int grid_cols(int CH) { return (CH + T::ITC - 1) / T::ITC + 1; }
 template <class T>
-int tiles_total(int CH) { return tiles_x<T>(CH) * tiles_y<T>(CH); }
+int grid_positions(int CH) { return grid_rows<T>(CH) * grid_cols<T>(CH); }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-int nt_tiles_max(int CH) {
-    const int a = tiles_total<TileDefault>(CH), b = tiles_total<TileWide>(CH);
+int positions_max(int CH) {
+    const int a = grid_positions<TileDefault>(CH), b = grid_positions<TileWide>(CH);
     return a > b ? a : b;
+}
+
+int64_t floor_div(int64_t a, int64_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+// The work list of one launch (see WorkItem).  Tiles sit on a lattice of ITR x ITC interiors; with `share` (band source: the
+// blocks' origins in chromosome coordinates are known) the lattice is anchored at chromosome coordinate 0, so overlapping
+// blocks cut the same tiles, and a tile that lies inside block b AND block b + 1 with its whole halo is listed once, for
+// block b, with b2 = b + 1.  Without it (dense blocks from the caller, or MST_FLAG_NO_SHARE) every block has its own lattice
+// anchored at its origin -- the grid of rounds 1 and 2.
+//   band_only : list only the tiles whose owned pixels can reach the tested band 4 <= col - row <= dpx + 1 (skip_empty on the
+//               band source: the others would return at once)
+//   slot_of_pos[b * npos + pos] = index of the item that computes the tile at grid position pos of block b, or -1
+// Order: a block's items row-major; without band_only the tile ROWS are dealt to eight buckets in turn (the kernel gives each
+// XCD a contiguous eighth of the list): the upper rows of a block hold the wide part of the band, whose tiles cost more than
+// the constant ones, and the dispatcher hands out workgroups in order, so an XCD that got only upper rows would set the pace.
+template <class T>
+void build_items(const int64_t *starts, int B, int CH, int dpx, bool share, bool band_only, std::vector<WorkItem> &items,
+                 std::vector<int32_t> &slot_of_pos, int *tiles_total_out) {
+    const int npos = grid_positions<T>(CH), gcols = grid_cols<T>(CH);
+    slot_of_pos.assign((size_t)B * npos, -1);
+    std::vector<WorkItem> list;
+    std::vector<int> row_of;                      // running tile-row counter of each item (for the dealing)
+    std::vector<int32_t> pos_of, pos2_of;
+    std::vector<char> given((size_t)npos, 0), given_next((size_t)npos, 0);   // tiles of block b that block b - 1 delivers
+    int rows_seen = 0, tiles_total = 0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t s0 = share ? starts[b] : 0;
+        const int64_t a_lo = floor_div(s0, T::ITR), c_lo = floor_div(s0, T::ITC);
+        // lattice cell a owns chromosome rows [a ITR, a ITR + ITR); region row 0 is the ring row above it
+        const int64_t a_hi = floor_div(s0 + CH - 1, T::ITR), c_hi = floor_div(s0 + CH - 1, T::ITC);
+        const bool next_ok = share && b + 1 < B && starts[b + 1] > starts[b] && starts[b + 1] - starts[b] < CH;
+        const int64_t s1 = next_ok ? starts[b + 1] : 0;
+        std::fill(given_next.begin(), given_next.end(), 0);
+        for (int64_t a = a_lo; a <= a_hi; ++a) {
+            bool row_has = false;
+            for (int64_t cc = c_lo; cc <= c_hi; ++cc) {
+                const int y0 = (int)(a * T::ITR - s0) - 1, x0 = (int)(cc * T::ITC - s0) - 1;
+                const int pos = (int)(a - a_lo) * gcols + (int)(cc - c_lo);
+                ++tiles_total;
+                // owned pixels inside the block
+                const int r_lo = y0 + 1 > 0 ? y0 + 1 : 0, r_hi = y0 + T::ITR < CH - 1 ? y0 + T::ITR : CH - 1;
+                const int q_lo = x0 + 1 > 0 ? x0 + 1 : 0, q_hi = x0 + T::ITC < CH - 1 ? x0 + T::ITC : CH - 1;
+                if (r_lo > r_hi || q_lo > q_hi) continue;                       // the cell only grazes the block with its ring
+                if (band_only && !((q_hi - r_lo >= 4) && (q_lo - r_hi <= dpx + 1))) continue;
+                if (given[(size_t)pos]) continue;                               // block b - 1's list computes it for both
+                WorkItem it;
+                it.b = b;
+                it.y0 = y0;
+                it.x0 = x0;
+                it.delta2 = 0;
+                int pos2 = -1;
+                if (next_ok) {
+                    // staged window (region + blur halo) inside both blocks: no reflection, no zero padding, no pixel outside
+                    const int Y0 = y0 - T::RMAX, X0 = x0 - T::RMAX;
+                    const int d = (int)(s0 - s1);                               // block b + 1 coordinate = block b coordinate + d
+                    const bool in_b = Y0 >= 0 && X0 >= 0 && Y0 + T::CTR <= CH && X0 + T::CTC <= CH;
+                    const bool in_n = Y0 + d >= 0 && X0 + d >= 0 && Y0 + d + T::CTR <= CH && X0 + d + T::CTC <= CH;
+                    if (in_b && in_n) {
+                        const int64_t a1_lo = floor_div(s1, T::ITR), c1_lo = floor_div(s1, T::ITC);
+                        pos2 = (int)(a - a1_lo) * gcols + (int)(cc - c1_lo);
+                        it.delta2 = d;
+                        given_next[(size_t)pos2] = 1;
+                    }
+                }
+                list.push_back(it);
+                row_of.push_back(rows_seen);
+                pos_of.push_back(pos);
+                pos2_of.push_back(pos2);
+                row_has = true;
+            }
+            if (row_has) ++rows_seen;
+        }
+        given.swap(given_next);
+    }
+    // final order + the position maps
+    const size_t n = list.size();
+    items.clear();
+    items.reserve(n);
+    std::vector<size_t> order;
+    order.reserve(n);
+    if (band_only) {
+        for (size_t i = 0; i < n; ++i) order.push_back(i);
+    } else {
+        size_t at[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t i = 0; i < n; ++i) ++at[row_of[i] % 8 + 1];
+        for (int x = 0; x < 8; ++x) at[x + 1] += at[x];
+        order.assign(n, 0);
+        for (size_t i = 0; i < n; ++i) order[at[row_of[i] % 8]++] = i;
+    }
+    for (size_t k = 0; k < n; ++k) {
+        const size_t i = order[k];
+        items.push_back(list[i]);
+        slot_of_pos[(size_t)list[i].b * npos + pos_of[i]] = (int32_t)k;
+        if (list[i].delta2 != 0) slot_of_pos[(size_t)(list[i].b + 1) * npos + pos2_of[i]] = (int32_t)k;
+    }
+    if (tiles_total_out) *tiles_total_out = tiles_total;
 }
 
 // level_stats of blocks without any tested tile: {min, sum} = {inf, 0}, what the reduction of zero tiles yields
@@ -620,20 +723,20 @@ __global__ void fill_stats_kernel(double *level_stats, int n) {
 extern "C" uint64_t mst_scale_space_workspace_bytes(int32_t B, int32_t CH, const mst_levels *lv) {
     int mr = 0, nt = 0;
     if (B <= 0 || CH <= 0 || check_levels(lv, &mr, &nt) != MST_OK) return 0;
-    const int nt_tiles = mr <= TileDefault::RMAX ? tiles_total<TileDefault>(CH) : tiles_total<TileWide>(CH);
+    const size_t npos = (size_t)positions_max(CH);
     return align_up(sizeof(DevLevels), 256) + align_up(sizeof(int64_t) * (size_t)B, 256) +
-           align_up(sizeof(int32_t) * 2 * (size_t)nt_tiles_max(CH), 256) + sizeof(double) * 2 * (size_t)B * nt_tiles * nt;
+           align_up(sizeof(WorkItem) * (size_t)B * npos, 256) + align_up(sizeof(int32_t) * (size_t)B * npos, 256) +
+           sizeof(double) * 2 * (size_t)B * npos * nt;
 }
 
 template <class T, bool BAND>
-static int launch_scale_space(const double *c, const uint8_t *nz, BandSrc src, int B, int CH, const DevLevels *d_lv,
+static int launch_scale_space(const double *c, const uint8_t *nz, BandSrc src, int CH, const DevLevels *d_lv,
                               mst_found *found, uint32_t found_cap, uint32_t *found_count, double *partial,
-                              int n_tested, int skip_empty, const int32_t *tile_list, int n_slots, hipStream_t s) {
+                              int n_tested, int skip_empty, const WorkItem *d_items, int n_items, hipStream_t s) {
     static unsigned long long lds_allowed = 0;      // per device (mst_common.h)
     MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&scale_space_kernel<T, BAND>), (int)T::LDS_BYTES,
                                    &lds_allowed));
-    const int tx = tiles_x<T>(CH), ty = tiles_y<T>(CH);
-    const int gx = (n_slots + 7) / 8 * 8;
+    const int gx = (n_items + 7) / 8 * 8;
     int variant = 0;
     unsigned long long *trace = nullptr;
 #ifdef MST_PROFILE
@@ -646,9 +749,8 @@ static int launch_scale_space(const double *c, const uint8_t *nz, BandSrc src, i
         MST_HIP(hipMemsetAsync(trace, 0, tbytes, s));
     }
 #endif
-    scale_space_kernel<T, BAND><<<dim3(gx, B), T::NT, T::LDS_BYTES, s>>>(c, nz, src, CH, d_lv, found, found_cap,
-                                                                       found_count, partial, tx, ty, n_tested,
-                                                                       skip_empty, tile_list, n_slots, variant, trace);
+    scale_space_kernel<T, BAND><<<gx, T::NT, T::LDS_BYTES, s>>>(c, nz, src, CH, d_lv, found, found_cap, found_count, partial,
+                                                              d_items, n_items, n_tested, skip_empty, variant, trace);
     MST_LAUNCH_CHECK();
 #ifdef MST_PROFILE
     if (trace) {
@@ -667,32 +769,35 @@ static int launch_scale_space(const double *c, const uint8_t *nz, BandSrc src, i
     return MST_OK;
 }
 
-// Tiles whose owned pixels can reach the tested band 4 <= col - row <= dpx + 1 (the kernel's own geometric test), in
-// row-major order.  The same list serves every block of a launch: the test depends on (CH, dpx) only.
-template <class T>
-static int band_tile_list(int CH, int dpx, int32_t *out) {
-    const int tx = tiles_x<T>(CH), ty = tiles_y<T>(CH);
-    int m = 0;
-    for (int j = 0; j < ty; ++j) {
-        const int y0 = j * T::ITR - 1;
-        const int r_lo = y0 + 1 > 0 ? y0 + 1 : 0, r_hi = y0 + T::ITR < CH - 1 ? y0 + T::ITR : CH - 1;
-        for (int i = 0; i < tx; ++i) {
-            const int x0 = i * T::ITC - 1;
-            const int c_lo = x0 + 1 > 0 ? x0 + 1 : 0, c_hi = x0 + T::ITC < CH - 1 ? x0 + T::ITC : CH - 1;
-            if ((c_hi - r_lo >= 4) && (c_lo - r_hi <= dpx + 1)) out[m++] = j * tx + i;
-        }
-    }
-    return m;
-}
-
 extern "C" int mst_scale_space_band_tiles(int32_t CH, int32_t dpx, const mst_levels *lv, int32_t *tiles_total_out) {
     int mr = 0, nt = 0;
     if (CH <= 0 || dpx < 0 || check_levels(lv, &mr, &nt) != MST_OK) return -1;
     const bool wide = mr > TileDefault::RMAX;
-    const int total = wide ? tiles_total<TileWide>(CH) : tiles_total<TileDefault>(CH);
-    std::vector<int32_t> list((size_t)total);
+    std::vector<WorkItem> items;
+    std::vector<int32_t> sop;
+    const int64_t start = 0;
+    int total = 0;
+    if (wide) build_items<TileWide>(&start, 1, CH, dpx, false, true, items, sop, &total);
+    else build_items<TileDefault>(&start, 1, CH, dpx, false, true, items, sop, &total);
     if (tiles_total_out) *tiles_total_out = total;
-    return wide ? band_tile_list<TileWide>(CH, dpx, list.data()) : band_tile_list<TileDefault>(CH, dpx, list.data());
+    return (int)items.size();
+}
+
+extern "C" int mst_scale_space_band_items(const int64_t *starts, int32_t B, int32_t CH, int32_t dpx, const mst_levels *lv,
+                                          int32_t flags, int64_t *tiles_out, int64_t *shared_out) {
+    int mr = 0, nt = 0;
+    if (!starts || B <= 0 || CH <= 0 || dpx < 0 || check_levels(lv, &mr, &nt) != MST_OK) return -1;
+    const bool wide = mr > TileDefault::RMAX, share = !(flags & MST_FLAG_NO_SHARE), band_only = (flags & MST_FLAG_SKIP_EMPTY) != 0;
+    std::vector<WorkItem> items;
+    std::vector<int32_t> sop;
+    int total = 0;
+    if (wide) build_items<TileWide>(starts, B, CH, dpx, share, band_only, items, sop, &total);
+    else build_items<TileDefault>(starts, B, CH, dpx, share, band_only, items, sop, &total);
+    int64_t shared = 0;
+    for (const WorkItem &it : items) shared += it.delta2 != 0;
+    if (tiles_out) *tiles_out = (int64_t)items.size() + shared;      // tiles the blocks would run one by one
+    if (shared_out) *shared_out = shared;
+    return (int)items.size();
 }
 
 // shared body of mst_scale_space (dense blocks) and mst_scale_space_band (blocks cut out of the band on the fly)
@@ -740,13 +845,21 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
         }
         if (same) h.first_level[o] = 3;
     }
+    if (fma && mr > TileDefault::RMAX)
+        return mst::fail(MST_E_ARG, "%s: MST_FLAG_FMA is only built for blur radii <= %d", who, TileDefault::RMAX);
+    const bool wide = mr > TileDefault::RMAX;
+    const size_t npos_max = (size_t)positions_max(CH);
+    const int npos = wide ? grid_positions<TileWide>(CH) : grid_positions<TileDefault>(CH);
+
     char *w = reinterpret_cast<char *>(workspace);
     DevLevels *d_lv = reinterpret_cast<DevLevels *>(w);
     w += align_up(sizeof(DevLevels), 256);
     int64_t *d_starts = reinterpret_cast<int64_t *>(w);
     w += align_up(sizeof(int64_t) * (size_t)B, 256);
-    int32_t *d_tiles = reinterpret_cast<int32_t *>(w);
-    w += align_up(sizeof(int32_t) * 2 * (size_t)nt_tiles_max(CH), 256);
+    WorkItem *d_items = reinterpret_cast<WorkItem *>(w);
+    w += align_up(sizeof(WorkItem) * (size_t)B * npos_max, 256);
+    int32_t *d_sop = reinterpret_cast<int32_t *>(w);
+    w += align_up(sizeof(int32_t) * (size_t)B * npos_max, 256);
     double *partial = reinterpret_cast<double *>(w);
     MST_HIP(mst::upload_small(d_lv, &h, sizeof(h), s));
     MST_HIP(hipMemsetAsync(found_count, 0, sizeof(uint32_t) * B, s));
@@ -756,59 +869,62 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
         src.starts = d_starts;
     }
 
-    if (fma && mr > TileDefault::RMAX)
-        return mst::fail(MST_E_ARG, "%s: MST_FLAG_FMA is only built for blur radii <= %d", who, TileDefault::RMAX);
-    const bool wide = mr > TileDefault::RMAX;
-    const int ntiles_all = wide ? tiles_total<TileWide>(CH) : tiles_total<TileDefault>(CH);
-    int ntiles = ntiles_all;
-    const int32_t *tile_list = nullptr, *slot_of_tile = nullptr;
-    {
-        // slot -> tile list.  skip_empty on the band source: only the tiles that can reach the tested band (identical results:
-        // the others would return at once), in row-major order.  Otherwise: all tiles, with the tile ROWS dealt to the XCDs in
-        // turn (XCD x runs rows x, x + 8, ... -- the kernel gives each XCD a contiguous run of the list): the upper rows of a
-        // block hold the wide part of the band, whose tiles cost more than the constant ones (sieve, statistics, real
-        // staging loads), and the dispatcher hands out workgroups in order, so an XCD that got only upper rows would set
-        // the pace for the other seven (measured: -1.3 % kernel time).
-        static thread_local std::vector<int32_t> host_list;      // [0, ntiles): slot -> tile; [ntiles_all, 2 ntiles_all): tile -> slot
-        static thread_local std::vector<int32_t> rowmajor;
-        host_list.assign(2 * (size_t)ntiles_all, -1);
-        rowmajor.resize((size_t)ntiles_all);
-        const int txn = wide ? tiles_x<TileWide>(CH) : tiles_x<TileDefault>(CH);
-        if (BAND && skip_empty) {
-            ntiles = wide ? band_tile_list<TileWide>(CH, src.dpx, rowmajor.data())
-                          : band_tile_list<TileDefault>(CH, src.dpx, rowmajor.data());
-        } else {
-            for (int i = 0; i < ntiles_all; ++i) rowmajor[(size_t)i] = i;
+    // the launch's work list: band source -> tiles on the chromosome's lattice, tiles inside two consecutive blocks computed
+    // once (MST_FLAG_NO_SHARE: every block on its own lattice, every tile once per block: the cross-check form)
+    // (a few recent lists are kept per host thread: a caller that runs the same blocks again -- a benchmark loop, the second
+    // sample of a two-sample run -- does not pay the ~1 ms of host time per 100 k items again)
+    struct Cached {
+        std::vector<int64_t> key;
+        std::vector<WorkItem> items;
+        std::vector<int32_t> sop;
+    };
+    static thread_local Cached cache[4];
+    static thread_local unsigned cache_turn = 0;
+    const bool share = BAND && !(flags & MST_FLAG_NO_SHARE);
+    const bool band_only = BAND && skip_empty;
+    std::vector<int64_t> key;
+    key.reserve((size_t)B + 6);
+    key.push_back(B);
+    key.push_back(CH);
+    key.push_back(BAND ? src.dpx : -1);
+    key.push_back((share ? 1 : 0) | (band_only ? 2 : 0) | (wide ? 4 : 0));
+    if (share) key.insert(key.end(), starts_host, starts_host + B);     // without sharing the list does not depend on the origins
+    Cached *hit = nullptr;
+    for (Cached &cd : cache)
+        if (cd.key == key) hit = &cd;
+    if (!hit) {
+        hit = &cache[cache_turn++ % 4];
+        hit->key = key;
+        std::vector<int64_t> zeros;
+        const int64_t *st = starts_host;
+        if (!share) {
+            zeros.assign((size_t)B, 0);
+            st = zeros.data();
         }
-        if (BAND && skip_empty) {               // every listed tile is a band tile: equal work, row-major order keeps the halo in L2
-            for (int i = 0; i < ntiles; ++i) host_list[(size_t)i] = rowmajor[(size_t)i];
-        } else {
-            int m = 0;
-            for (int x = 0; x < 8; ++x)
-                for (int i = 0; i < ntiles; ++i)
-                    if ((rowmajor[(size_t)i] / txn) % 8 == x) host_list[(size_t)m++] = rowmajor[(size_t)i];
-        }
-        for (int sl = 0; sl < ntiles; ++sl) host_list[(size_t)ntiles_all + host_list[sl]] = sl;
-        if (ntiles == 0) {          // no tile reaches the band: nothing is tested, nothing is found
-            fill_stats_kernel<<<(B * MST_MAX_TESTED + 255) / 256, 256, 0, s>>>(level_stats, B * MST_MAX_TESTED);
-            MST_LAUNCH_CHECK();
-            return MST_OK;
-        }
-        MST_HIP(mst::upload_small(d_tiles, host_list.data(), sizeof(int32_t) * 2 * (size_t)ntiles_all, s));
-        tile_list = d_tiles;
-        slot_of_tile = d_tiles + ntiles_all;
+        if (wide) build_items<TileWide>(st, B, CH, BAND ? src.dpx : 0, share, band_only, hit->items, hit->sop, nullptr);
+        else build_items<TileDefault>(st, B, CH, BAND ? src.dpx : 0, share, band_only, hit->items, hit->sop, nullptr);
     }
+    const std::vector<WorkItem> &items = hit->items;
+    const std::vector<int32_t> &sop = hit->sop;
+    const int n_items = (int)items.size();
+    if (n_items == 0) {          // no tile reaches the band: nothing is tested, nothing is found
+        fill_stats_kernel<<<(B * MST_MAX_TESTED + 255) / 256, 256, 0, s>>>(level_stats, B * MST_MAX_TESTED);
+        MST_LAUNCH_CHECK();
+        return MST_OK;
+    }
+    MST_HIP(mst::upload_small(d_items, items.data(), sizeof(WorkItem) * (size_t)n_items, s));
+    MST_HIP(mst::upload_small(d_sop, sop.data(), sizeof(int32_t) * (size_t)B * npos, s));
     if (fma)
-        rc = launch_scale_space<TileDefaultFma, BAND>(c, nz, src, B, CH, d_lv, found, found_cap, found_count, partial,
-                                                      nt, skip_empty, tile_list, ntiles, s);
+        rc = launch_scale_space<TileDefaultFma, BAND>(c, nz, src, CH, d_lv, found, found_cap, found_count, partial, nt,
+                                                      skip_empty, d_items, n_items, s);
     else if (!wide)
-        rc = launch_scale_space<TileDefault, BAND>(c, nz, src, B, CH, d_lv, found, found_cap, found_count, partial, nt,
-                                                   skip_empty, tile_list, ntiles, s);
+        rc = launch_scale_space<TileDefault, BAND>(c, nz, src, CH, d_lv, found, found_cap, found_count, partial, nt,
+                                                   skip_empty, d_items, n_items, s);
     else
-        rc = launch_scale_space<TileWide, BAND>(c, nz, src, B, CH, d_lv, found, found_cap, found_count, partial, nt,
-                                                skip_empty, tile_list, ntiles, s);
+        rc = launch_scale_space<TileWide, BAND>(c, nz, src, CH, d_lv, found, found_cap, found_count, partial, nt,
+                                                skip_empty, d_items, n_items, s);
     if (rc != MST_OK) return rc;
-    stats_reduce_kernel<<<dim3(nt, B), 256, 0, s>>>(partial, ntiles_all, ntiles, slot_of_tile, nt, level_stats);
+    stats_reduce_kernel<<<dim3(nt, B), 256, 0, s>>>(partial, npos, d_sop, nt, level_stats);
     MST_LAUNCH_CHECK();
     return MST_OK;
 }

@@ -258,6 +258,7 @@ class ScaleSpaceEngine:
 
     def __init__(self, octave_values=(1.6, 3.2), s=10, device=None):
         self.lib = require_gpu()
+        self.share_tiles = True      # band source: compute the tiles two consecutive blocks have in common once (identical records)
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.levels = LevelTable(octave_values, s)
         self._select_cap = 4096
@@ -342,7 +343,8 @@ class ScaleSpaceEngine:
             if timing is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            flags = (1 if skip_empty else 0) | (2 if fma else 0)
+            # MST_FLAG_NO_SHARE (4): every tile once per block; default: tiles inside two consecutive blocks computed once
+            flags = (1 if skip_empty else 0) | (2 if fma else 0) | (0 if self.share_tiles else 4)
             if band_src is not None:
                 _lib.check(self.lib.mst_scale_space_band(_ptr(band), bn, bdpx, st_arr, B, CH, lv, _ptr(found),
                                                          found_cap, _ptr(count), _ptr(stats), _ptr(nz_count), flags,

@@ -1,4 +1,4 @@
-"""Multi-GPU sharding of the per-chromosome run: one process per GPU, blocks dealt round-robin, ONE gather of the
+"""Multi-GPU sharding of the per-chromosome run: one process per GPU, a contiguous range of blocks each, ONE gather of the
 candidate-loop records at the end (reference: one multiprocessing.Process per block + a Manager().list(),
 mustache/mustache.py:913-937).  Blocks share nothing, so there is no data-path collective; the gather payload is a
 few hundred records per rank.  Backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests."""
@@ -14,9 +14,12 @@ def world():
 
 
 def shard_blocks(nblocks, rank, world_size):
-    """Indices of the blocks rank `rank` owns: i = rank, rank + world, ... (neighbouring blocks differ in nz count
-    only slowly along the chromosome, so round-robin balances the load)."""
-    return list(range(rank, nblocks, world_size))
+    """Indices of the blocks rank `rank` owns: a contiguous range, sizes differing by at most one.  Contiguous, not
+    round-robin, because consecutive blocks overlap by half their edge and the fused kernel computes the tiles two
+    consecutive blocks of a launch have in common only once (mst_scale_space_band): a rank's neighbours must be its own."""
+    q, rem = divmod(int(nblocks), int(world_size))
+    lo = rank * q + min(rank, rem)
+    return list(range(lo, lo + q + (1 if rank < rem else 0)))
 
 
 def assign_chromosomes(weights, world_size):

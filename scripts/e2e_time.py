@@ -25,6 +25,9 @@ def main():
     n, dpx, res, depth = (int(a[0]), int(a[1]), int(a[2]), float(a[3])) if len(a) >= 4 else (9630, 400, 5000, 300.0)
     dev = torch.device("cuda:0")
     pipe = ChromosomePipeline((1.6, 3.2), device=dev)
+    pipe.engine.share_tiles = os.environ.get("E2E_SHARE", "1") != "0"      # E2E_SHARE=0: MST_FLAG_NO_SHARE
+    if os.environ.get("E2E_BLOCKS"):
+        pipe.overlap_blocks = int(os.environ["E2E_BLOCKS"])                # blocks per fused-kernel launch
     raw = band_counts(n, dpx, depth, max(10, n // 32), 0, device=dev)
     torch.cuda.synchronize()
     rows = []

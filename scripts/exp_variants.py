@@ -35,6 +35,7 @@ def one(reps=5, blocks=12):
     pipe = ChromosomePipeline(octs, device=dev)
     CH, start, end = block_tiling(n, dpx)
     eng = pipe.engine
+    eng.share_tiles = os.environ.get("EXP_SHARE", "1") != "0"       # EXP_SHARE=0: MST_FLAG_NO_SHARE (every tile once per block)
     out = {"lib": os.environ.get("MUSTACHE_HIP_LIB", "default"), "blocks": len(start), "octaves": list(octs)}
     modes = os.environ.get("EXP_MODES", "dense,skip").split(",")
     for mode, skip in (("dense", False), ("skip", True)):

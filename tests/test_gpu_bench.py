@@ -19,6 +19,12 @@ def _last_json(out):
     return json.loads(lines[-1])
 
 
+def _fragments(err):
+    """the RANK_FRAGMENT JSON objects on stderr (two ranks may write to the same line)"""
+    import re
+    return [json.loads(m.group(1)) for m in re.finditer(r"RANK_FRAGMENT (\{[^{}]*\})", err)]
+
+
 def _check_line(j, n_gpus, steps, warmup):
     assert j["metric"].startswith("scale-space Mpix/s") and j["unit"] == "Mpix/s" and j["higher_is_better"] is True
     assert j["n_gpus"] == n_gpus and j["steps"] == steps and j["warmup"] == warmup
@@ -60,7 +66,7 @@ def test_bench_two_ranks_gloo_one_device():
     j = _last_json(r.stdout)
     _check_line(j, 2, 2, 1)
     assert j["ranks"]["blocks_per_rank_max"] == 6 and "2 rank" in j["config"]["sharding"]
-    frags = [json.loads(l.split("RANK_FRAGMENT ", 1)[1]) for l in r.stderr.splitlines() if "RANK_FRAGMENT " in l]
+    frags = _fragments(r.stderr)
     assert sorted(f["rank"] for f in frags) == [0, 1] and all(f["backend"] == "gloo" for f in frags)
     assert "cpu_baseline" not in j and "chr21_5kb" not in j        # rank-0-at-N=1-only legs stay out of the N > 1 line
 
@@ -86,7 +92,7 @@ def test_bench_two_ranks_rccl_one_device_if_rccl_allows_it():
         raise AssertionError(tail)
     j = _last_json(r.stdout)
     _check_line(j, 2, 2, 1)
-    frags = [json.loads(l.split("RANK_FRAGMENT ", 1)[1]) for l in r.stderr.splitlines() if "RANK_FRAGMENT " in l]
+    frags = _fragments(r.stderr)
     assert sorted(f["rank"] for f in frags) == [0, 1] and all(f["backend"] == "nccl" and f["blocks"] == 6 for f in frags)
 
 

@@ -125,7 +125,7 @@ def test_skip_empty_and_dense_agree_on_chromosome():
 
 
 def test_rank_shards_union_equals_single_rank():
-    """Multi-GPU correctness by construction: the union of what ranks 0..N-1 find on their round-robin block shares is
+    """Multi-GPU correctness by construction: the union of what ranks 0..N-1 find on their block shares (contiguous ranges) is
     exactly the single-rank result (blocks are independent; the overlap mask de-duplicates per block)."""
     import torch
     from mustache_amd.normalize import band_from_coo, normalize_band
@@ -168,14 +168,21 @@ def test_band_direct_kernel_equals_dense_path(n, dpx, res):
         fb, fitb, cntb = pipe.engine.sigma_loop_band(band, n, dpx, start, CH, skip_empty=skip)
         assert torch.equal(cnt, cntb)
         for a, b in zip(fa, fb):
-            for k in ("pixel", "level", "value", "pval", "q"):
+            for k in ("pixel", "level", "value"):
                 assert np.array_equal(a[k], b[k]), k
+            # the band source cuts its tiles on the chromosome's lattice (shared between overlapping blocks), the dense source
+            # on each block's own: the level sums are grouped by different tiles, so scale -- and with it p and q -- may
+            # differ in the last bits
+            for k in ("pval", "q"):
+                np.testing.assert_allclose(a[k], b[k], rtol=1e-11, err_msg=k)
         for (la, sa), (lb, sb) in zip(fita, fitb):
-            assert np.array_equal(la, lb) and np.array_equal(sa, sb)
-    key = lambda r: (int(r[0]), int(r[1]), float(r[2]), float(r[3]))
-    dense = [key(r) for r in pipe.run_band(band, n, dpx, 0.8, 0.2, distributed=False, dense=True)]
-    direct = [key(r) for r in pipe.run_band(band, n, dpx, 0.8, 0.2, distributed=False)]
-    assert dense == direct and (len(dense) > 0 or n < 2000)
+            assert np.array_equal(la, lb)
+            np.testing.assert_allclose(sa, sb, rtol=1e-12)
+    key = lambda r: (int(r[0]), int(r[1]), float(r[3]))
+    dense = pipe.run_band(band, n, dpx, 0.8, 0.2, distributed=False, dense=True)
+    direct = pipe.run_band(band, n, dpx, 0.8, 0.2, distributed=False)
+    assert [key(r) for r in dense] == [key(r) for r in direct] and (len(dense) > 0 or n < 2000)
+    np.testing.assert_allclose([float(r[2]) for r in dense], [float(r[2]) for r in direct], rtol=1e-9)
 
 
 def test_chr21_5kb_shape_end_to_end_vs_oracle():
@@ -642,3 +649,57 @@ def test_genome_batched_cli_equals_per_chromosome_cli(tmp_path):
         del os.environ["MUSTACHE_GENOME_BATCH_GB"]
     a, b = open(one).read(), open(two).read()
     assert a == b and a.count("\n") > 30
+
+
+@pytest.mark.parametrize("n,dpx,res", [(9630, 400, 5000), (14321, 2000, 1000), (5230, 150, 10000)])
+def test_shared_tiles_equal_tiles_computed_per_block(n, dpx, res):
+    """Default: tiles sit on a lattice anchored at chromosome coordinate 0 and a tile that lies inside two consecutive blocks
+    with its whole blur halo is computed ONCE and delivered to both (mst_scale_space_band, WorkItem).  MST_FLAG_NO_SHARE:
+    every block on its own lattice, every tile once per block (the form of rounds 1 and 2).  Both, with and without empty
+    tiles skipped, must give every block the same found set (pixels, levels, DoG values bit for bit), the same number of tested
+    pixels, loc exactly and scale to 1e-12 (the partial sums are grouped by different tiles), hence the same loops."""
+    import ctypes
+    from mustache_amd import _lib
+    from mustache_amd.pipeline import ChromosomePipeline, block_tiling
+    from mustache_amd.normalize import band_from_host_coo, normalize_band
+    from mustache_amd.synth import synth_coo
+    x, y, v = synth_coo(n, dpx, depth=150.0, seed=17)
+    pipe = ChromosomePipeline(OCT)
+    eng = pipe.engine
+    band, _, _ = normalize_band(band_from_host_coo(x, y, v, n, dpx, pipe.device), n, dpx, res)
+    CH, start, end = block_tiling(n, dpx)
+    assert len(start) >= 3
+    out = {}
+    for share in (True, False):
+        for skip in (True, False):
+            eng.share_tiles = share
+            recs, fits, nzc = eng.sigma_loop_band(band, n, dpx, start, CH, skip_empty=skip, with_q=False)
+            out[(share, skip)] = (recs, fits, nzc.cpu().numpy())
+    eng.share_tiles = True
+    ref = out[(False, False)]
+    total = 0
+    for key, (recs, fits, nzc) in out.items():
+        assert np.array_equal(nzc, ref[2]), key
+        for b in range(len(start)):
+            for f in ("pixel", "level", "value"):
+                assert np.array_equal(recs[b][f], ref[0][b][f]), (key, b, f)
+            np.testing.assert_array_equal(fits[b][0], ref[1][b][0])                    # loc: a minimum, exact
+            np.testing.assert_allclose(fits[b][1], ref[1][b][1], rtol=1e-12)           # scale: a mean, grouped differently
+            np.testing.assert_allclose(recs[b]["pval"], ref[0][b]["pval"], rtol=1e-9)
+            total += len(recs[b]["pixel"])
+    assert total > 1000
+    # the library's own account of the work list: sharing saves workgroups, and only between consecutive blocks
+    lv = ctypes.byref(eng._lv_struct)
+    st = (ctypes.c_int64 * len(start))(*start)
+    tiles, shared = ctypes.c_int64(), ctypes.c_int64()
+    items = eng.lib.mst_scale_space_band_items(st, len(start), CH, dpx, lv, 1, ctypes.byref(tiles), ctypes.byref(shared))
+    assert items + shared.value == tiles.value and shared.value > (0.2 if CH == 2 * dpx else 0.02) * tiles.value
+    items_ns = eng.lib.mst_scale_space_band_items(st, len(start), CH, dpx, lv, 1 | 4, ctypes.byref(tiles), ctypes.byref(shared))
+    assert shared.value == 0 and items_ns == tiles.value and items < items_ns
+    loops_shared = pipe.run_band(band, n, dpx, 0.8, 0.2, distributed=False)
+    eng.share_tiles = False
+    loops_plain = pipe.run_band(band, n, dpx, 0.8, 0.2, distributed=False)
+    eng.share_tiles = True
+    key = lambda r: (int(r[0]), int(r[1]))
+    assert [(int(a), int(b), s_) for a, b, _, s_ in sorted(loops_shared, key=key)] == \
+           [(int(a), int(b), s_) for a, b, _, s_ in sorted(loops_plain, key=key)]

@@ -26,6 +26,9 @@
 // 77 KB of LDS per workgroup -> two independent workgroups per CU, so one's LDS window loads overlap the other's
 // FP64 work instead of every wave of the CU alternating between the two in barrier lock-step.
 // The kernel is FP64-VALU bound (~1150 non-fusable flops per pixel for the blurs alone), not HBM bound.
+// Tiles sit on a lattice anchored at the chromosome's origin, and a tile that lies inside two consecutive (overlapping) blocks of
+// a launch with its whole blur halo is computed once for both (struct WorkItem, build_items): the reference's blocks overlap by
+// up to half their edge (mustache.py:899-908) and recompute those pixels block by block.
 //
 // Bit-exactness: the tap order is SciPy's C correlate1d on a symmetric kernel,
 //     t = x[c]*w0;  for j = r..1:  t += (x[c-j] + x[c+j]) * w[j]

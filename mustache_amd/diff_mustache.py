@@ -77,22 +77,20 @@ def _pair_tails(batch, pairs, pt, pt2, st, intra):
             rec, other = batch.found[b], batch.found[bo]
             # differential subset (:567-568): pair < pt2 and v_self > v_other, where v = 1 off-nz, vAll on nz (0 if not found)
             looked_up = "v_other" in rec       # selected-only records (engine.run_band_pairs(select_below=pt)): device look-up
-            opix = None if looked_up else other["pixel"].astype(np.int64)
-            diff = []
-            for i, r in enumerate(reps):
-                p_ = int(pix[i])
-                if looked_up:
-                    v_other = rec["v_other"][r]
-                    if np.isnan(v_other):                                  # the other sample did not find this pixel
-                        v_other = 0.0 if nz_other[i] else 1.0
-                else:
-                    kk = int(np.searchsorted(opix, p_))
-                    if kk < len(opix) and opix[kk] == p_:
-                        v_other = other["value"][kk]
-                    else:
-                        v_other = 0.0 if nz_other[i] else 1.0
-                if rec["pair"][r] < pt2 and rec["value"][r] > v_other:
-                    diff.append(loops[i])
+            ridx = np.asarray(reps, dtype=np.int64)
+            if looked_up:
+                v_other = rec["v_other"][ridx].astype(np.float64)
+                missing = np.isnan(v_other)                                # the other sample did not find this pixel
+            else:
+                opix = other["pixel"].astype(np.int64)
+                pos = np.searchsorted(opix, pix.astype(np.int64))
+                pos_c = np.minimum(pos, max(len(opix) - 1, 0))
+                hit = (pos < len(opix)) & (opix[pos_c] == pix.astype(np.int64)) if len(opix) else np.zeros(len(pix), bool)
+                v_other = np.where(hit, other["value"][pos_c] if len(opix) else 0.0, 0.0).astype(np.float64)
+                missing = ~hit
+            v_other = np.where(missing, np.where(np.asarray(nz_other) != 0, 0.0, 1.0), v_other)
+            keep = (rec["pair"][ridx] < pt2) & (rec["value"][ridx] > v_other) if len(ridx) else np.zeros(0, bool)
+            diff = [loops[i] for i in np.nonzero(keep)[0]]
             res4.extend([loops, diff])
         out[k] = tuple(res4)
     return out

@@ -175,15 +175,20 @@ def cluster_representatives(batch, b, q, idx):
 
 
 def loops_from_reps(batch, b, q, reps, start):
+    """The reference's output rows [x + start, y + start, fdr, sigma] (np.int64, np.int64, np.float64, np.float64;
+    mustache.py:848) for the representatives `reps` (record indices) of block b."""
+    if len(reps) == 0:
+        return []
     CH = batch.CH
     rec = batch.found[b]
-    sigma_t = np.asarray(batch.engine.levels.tested_sigma)
-    out = []
-    for r in reps:
-        px = int(rec["pixel"][r])
-        out.append([np.int64(px // CH + start), np.int64(px % CH + start), np.float64(q[r]),
-                    np.float64(sigma_t[int(rec["level"][r]) - 1])])
-    return out
+    r = np.asarray(reps, dtype=np.int64)
+    px = rec["pixel"][r].astype(np.int64)
+    sigma_t = np.asarray(batch.engine.levels.tested_sigma, dtype=np.float64)
+    xs = px // CH + np.int64(start)
+    ys = px % CH + np.int64(start)
+    qs = np.asarray(q, dtype=np.float64)[r]
+    sg = sigma_t[rec["level"][r].astype(np.int64) - 1]
+    return [[a, b_, c, d] for a, b_, c, d in zip(xs, ys, qs, sg)]
 
 
 def batch_tail(batch, bs, starts, pt, st, intra=True):

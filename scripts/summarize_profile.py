@@ -30,32 +30,58 @@ for r in st[:12]:
                                                      float(r["AverageNs"]) / 1e6, r["Percentage"]))
 tr = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_trace.csv"))))
 ss = [r for r in tr if "scale_space_kernel" in r["Kernel_Name"] and ", true>," not in r["Kernel_Name"]]   # exact mode only
+# the fused kernel's launches are 1-D grids of work items (tiles; a tile shared by two blocks is one item): label them with
+# the per-launch item counts bench.py prints on its JSON line (same run: bench_trace.log)
+bench_line = {}
+try:
+    for l in open(os.path.join(src, "bench_trace.log")):
+        if l.startswith("{"):
+            bench_line = json.loads(l)
+except Exception:
+    pass
+labels = {}
+def _lab(counts, name):
+    for c in counts or []:
+        labels.setdefault((int(c) + 7) // 8 * 8, []).append(name)
+rf = bench_line.get("roofline", {})
+_lab(rf.get("work_items_per_launch"), "chr1@1kb dense step (tiles shared)")
+_lab(bench_line.get("band_skip", {}).get("roofline", {}).get("work_items_per_launch"), "chr1@1kb tile-list step (tiles shared)")
+ns = bench_line.get("no_share", {}).get("work_items_per_launch", {})
+_lab(ns.get("dense"), "chr1@1kb dense step, MST_FLAG_NO_SHARE")
+_lab(ns.get("band_skip"), "chr1@1kb tile-list step, MST_FLAG_NO_SHARE")
 groups = collections.defaultdict(list)
 for r in ss:
-    groups[(int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]))].append(
-        (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-lines += ["", "## Fused kernel `scale_space_kernel<Tile<32,64,14>, band>` (exact arithmetic) per launch shape", "",
-          "| tiles/block (padded) | blocks | launches | durations ms |", "|---|---|---|---|"]
-for (gx, gy), d in sorted(groups.items(), reverse=True):
-    lines.append("| %d | %d | %d | %s |" % (gx, gy, len(d), ", ".join("%.3f" % x for x in d[:8])))
-big = max(groups, key=lambda k: k[0] * k[1])
-dense = [x for x in groups[big] if x > 0.8 * max(groups[big])]
-lines += ["", "Dense %d-block launches: mean **%.3f ms** over %d launches; the shorter launches of the same shape are the "
-          "`band_skip` runs." % (big[1], sum(dense) / len(dense), len(dense))]
-# bench.py splits a step into several launches of unequal size (the last one smallest); roofline.kernel_ms is the mean
-# over ALL dense launches of the timed steps = (sum over the shapes of the workload's tile count) / (number of launches)
-gx_big = big[0]
-all_dense, blocks_dense = [], 0
-for (gx, gy), d in groups.items():
-    if gx == gx_big and gy * 3 >= big[1]:        # the step's launches; smaller ones are other workloads / ablations
-        dd = [x for x in d if x > 0.8 * max(d)]
-        all_dense += dd
-        blocks_dense += gy * len(dd)
-if all_dense:
-    lines += ["", "All dense launches of the workload's tile shape (%d launches, %d blocks in total): mean **%.3f ms per launch** "
-              "(what `roofline.kernel_ms` averages), **%.4f ms per block** -> %.1f ms per 124-block step."
-              % (len(all_dense), blocks_dense, sum(all_dense) / len(all_dense), sum(all_dense) / blocks_dense,
-                 124 * sum(all_dense) / blocks_dense)]
+    groups[int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+lines += ["", "## Fused kernel `scale_space_kernel<Tile<32,64,14>, band>` (exact arithmetic) per launch size", "",
+          "| workgroups (work items, padded to 8) | launches | mean ms | first durations ms | what (from the bench line of the same run) |",
+          "|---|---|---|---|---|"]
+for gx, d in sorted(groups.items(), reverse=True):
+    lines.append("| %d | %d | %.3f | %s | %s |" % (gx, len(d), sum(d) / len(d), ", ".join("%.3f" % x for x in d[:6]),
+                                                  "; ".join(sorted(set(labels.get(gx, ["other workload (chr21, genome, variants, end to end)"]))))))
+def _step(counts):
+    """kernel ms of one step = sum over its launches of the mean duration of that launch size; None if a size is missing"""
+    tot = 0.0
+    for c in counts or []:
+        d = groups.get((int(c) + 7) // 8 * 8)
+        if not d:
+            return None
+        tot += sum(d) / len(d)
+    return tot if counts else None
+px_step = 124 * 4000 * 4000
+lines += ["", "Kernel time of one chr1 @ 1 kb step (124 blocks, 1984 Mpix) from the trace, and what it is in the no-FMA FP64 roofline "
+          "(1152 algorithmic flops per pixel, 39.3 TFLOP/s):", ""]
+frac_band = bench_line.get("band_skip", {}).get("launched_tile_fraction")
+for name, counts, px in (("dense, tiles shared (`value`)", rf.get("work_items_per_launch"), px_step),
+                         ("tile list, tiles shared (`band_skip`, the product mode)",
+                          bench_line.get("band_skip", {}).get("roofline", {}).get("work_items_per_launch"),
+                          px_step * frac_band if frac_band else None),
+                         ("dense, MST_FLAG_NO_SHARE (`no_share`, the kernel's own figure)", ns.get("dense"), px_step),
+                         ("tile list, MST_FLAG_NO_SHARE", ns.get("band_skip"), px_step * frac_band if frac_band else None)):
+    ms = _step(counts)
+    if ms and px:
+        tf = px * 1152.0 / (ms * 1e-3) / 1e12
+        lines.append("* %s: **%.2f ms** -> %.2f TFLOP/s = **%.3f**%s" % (name, ms, tf, tf / 39.3,
+                     " (flops of the %.1f %% of the tiles that can reach the band)" % (100 * frac_band) if px != px_step else ""))
 r0 = ss[0]
 try:
     import kernel_resources
@@ -88,7 +114,8 @@ def pmc(dirname, kernel_sub):
     return per
 
 traffic = {}
-lines += ["## PMC, first dense launch of the fused kernel on 12 blocks (192 Mpix)", ""]
+lines += ["## PMC, the largest dispatch of the fused kernel on 12 blocks (192 Mpix): the dense launch with MST_FLAG_NO_SHARE "
+          "(every tile once per block, 104 520 workgroups) -- the form comparable with rounds 1 and 2", ""]
 allc = {}
 for d in sorted(os.listdir(src)):
     if d.startswith("pmc_"):

@@ -254,5 +254,9 @@ def test_large_distance_limit_blocks_of_10000():
     b = sorted(key(r) for r in pipe.run_band(band, n, dpx, 0.3, 0.3, distributed=False, skip_empty=False))
     c = sorted(key(r) for r in pipe.run_band(band, n, dpx, 0.3, 0.3, distributed=False, dense=True))
     d = sorted(key(r) for r in pipe.run_band(band, n, dpx, 0.3, 0.3, distributed=False))
-    assert a == b == c == d and len(a) > 50
+    assert a == b == d and len(a) > 50                      # with / without the tile list, and run to run: bit for bit
+    # the dense-block route cuts its tiles on each block's own lattice, the band route on the chromosome's (shared between
+    # overlapping blocks): the level sums are grouped differently, q may differ in its last bits
+    assert [(r[0], r[1], r[3]) for r in a] == [(r[0], r[1], r[3]) for r in c]
+    np.testing.assert_allclose([r[2] for r in a], [r[2] for r in c], rtol=1e-9)
     assert all(0 <= r[1] - r[0] <= dpx for r in a)

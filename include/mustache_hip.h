@@ -241,6 +241,10 @@ int mst_scale_space_band_items(const int64_t *starts, int32_t B, int32_t CH, int
 int mst_candidate_features_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,
                                 const uint32_t *pixel, const int32_t *half, int32_t ncand, uint32_t *cnt1,
                                 uint32_t *cnt2, double *cval, void *stream);
+/* the same for candidates of several blocks in ONE launch: starts: dev [ncand], the block origin of each candidate */
+int mst_candidate_features_band_multi(const double *band, int64_t n, int32_t dpx, const int64_t *starts, int32_t CH,
+                                      const uint32_t *pixel, const int32_t *half, int32_t ncand, uint32_t *cnt1,
+                                      uint32_t *cnt2, double *cval, void *stream);
 int mst_gather_diagonals_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,
                               const int32_t *diag_k, int32_t nd, double *out, void *stream);
 int mst_diag_means_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH, const int32_t *diag_k,

@@ -118,13 +118,15 @@ __device__ __forceinline__ double band_raw(const double *__restrict__ band, int6
     return band[(int64_t)off * n + start + x];
 }
 
+// `starts` != nullptr: candidate i belongs to the block that starts at starts[i] (candidates of several blocks in one launch)
 __global__ void __launch_bounds__(256)
-features_band_kernel(const double *__restrict__ band, int64_t n, int dpx, int64_t start, int CH,
-                     const uint32_t *__restrict__ pixel, const int32_t *__restrict__ half, int ncand,
+features_band_kernel(const double *__restrict__ band, int64_t n, int dpx, int64_t start, const int64_t *__restrict__ starts,
+                     int CH, const uint32_t *__restrict__ pixel, const int32_t *__restrict__ half, int ncand,
                      uint32_t *__restrict__ cnt1, uint32_t *__restrict__ cnt2, double *__restrict__ cval) {
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= ncand) return;
+    if (starts) start = starts[i];
     const int x = (int)(pixel[i] / (uint32_t)CH), y = (int)(pixel[i] % (uint32_t)CH);
     uint32_t out[2];
 #pragma unroll
@@ -306,8 +308,20 @@ extern "C" int mst_candidate_features_band(const double *band, int64_t n, int32_
     if (ncand == 0) return MST_OK;
     if (!band || !pixel || !half || !cnt1 || !cnt2 || !cval || CH <= 0 || n <= 0 || dpx < 0 || ncand < 0)
         return mst::fail(MST_E_ARG, "mst_candidate_features_band: bad argument");
-    features_band_kernel<<<(ncand + 3) / 4, 256, 0, mst::as_stream(stream)>>>(band, n, dpx, start, CH, pixel, half, ncand,
+    features_band_kernel<<<(ncand + 3) / 4, 256, 0, mst::as_stream(stream)>>>(band, n, dpx, start, nullptr, CH, pixel, half, ncand,
                                                                             cnt1, cnt2, cval);
+    MST_LAUNCH_CHECK();
+    return MST_OK;
+}
+
+extern "C" int mst_candidate_features_band_multi(const double *band, int64_t n, int32_t dpx, const int64_t *starts, int32_t CH,
+                                                 const uint32_t *pixel, const int32_t *half, int32_t ncand, uint32_t *cnt1,
+                                                 uint32_t *cnt2, double *cval, void *stream) {
+    if (ncand == 0) return MST_OK;
+    if (!band || !starts || !pixel || !half || !cnt1 || !cnt2 || !cval || n <= 0 || dpx < 0 || CH <= 0 || ncand < 0)
+        return mst::fail(MST_E_ARG, "mst_candidate_features_band_multi: bad argument");
+    features_band_kernel<<<(ncand + 3) / 4, 256, 0, mst::as_stream(stream)>>>(band, n, dpx, 0, starts, CH, pixel, half, ncand,
+                                                                              cnt1, cnt2, cval);
     MST_LAUNCH_CHECK();
     return MST_OK;
 }

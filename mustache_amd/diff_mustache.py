@@ -39,40 +39,44 @@ def _pair_tails(batch, pairs, pt, pt2, st, intra):
             and batch.nz_count[b1] >= 10000 and batch.nz_count[b2] >= 10000]              # (:430)
     if not live:
         return out
-    blocks = [b for k in live for b in pairs[k][:2]]
+    L = len(live)
+    blocks = [pairs[k][0] for k in live] + [pairs[k][1] for k in live]      # sample 1's blocks, then sample 2's (one launch each)
     cand = fdr_candidates_multi(batch, blocks, pt, st)                                     # (:432-505)
     state = {}
     for j, k in enumerate(live):
-        (q1, i1, c1), (q2, i2, c2) = cand[2 * j], cand[2 * j + 1]
+        (q1, i1, c1), (q2, i2, c2) = cand[j], cand[L + j]
         if i1.size and i2.size:                                                            # (:507)
             state[k] = [q1, i1, c1, q2, i2, c2]
     if intra and state:                                                                    # (:516-529)
         ks = list(state)
         # the reference filters sample 1 first and returns if nothing is left, then sample 2: evaluating both is the same
-        flt = diag_mean_filter_multi(batch, [b for k in ks for b in pairs[k][:2]],
-                                     [state[k][i] for k in ks for i in (1, 4)], [state[k][i] for k in ks for i in (2, 5)])
+        flt = diag_mean_filter_multi(batch, [pairs[k][0] for k in ks] + [pairs[k][1] for k in ks],
+                                     [state[k][1] for k in ks] + [state[k][4] for k in ks],
+                                     [state[k][2] for k in ks] + [state[k][5] for k in ks])
         for j, k in enumerate(ks):
-            state[k][1], state[k][4] = flt[2 * j], flt[2 * j + 1]
+            state[k][1], state[k][4] = flt[j], flt[len(ks) + j]
             if state[k][1].size == 0 or state[k][4].size == 0:
                 del state[k]
     if not state:
         return out
     ks = list(state)
-    cl_blocks = [b for k in ks for b in pairs[k][:2]]
-    cl_q = [state[k][i] for k in ks for i in (0, 3)]
-    cl_idx = [state[k][i] for k in ks for i in (1, 4)]
+    M = len(ks)
+    cl_blocks = [pairs[k][0] for k in ks] + [pairs[k][1] for k in ks]
+    cl_q = [state[k][0] for k in ks] + [state[k][3] for k in ks]
+    cl_idx = [state[k][1] for k in ks] + [state[k][4] for k in ks]
     multi = getattr(batch, "cluster_representatives_multi", None)                          # (:531-561)
     reps_all = multi(cl_blocks, cl_q, cl_idx, pt) if multi is not None else \
         [cluster_representatives(batch, b, q, idx) for b, q, idx in zip(cl_blocks, cl_q, cl_idx)]
     # is the representative's pixel tested in the OTHER sample?  one gather for all pairs
-    other_blocks = [pairs[k][1 - s_] for k in ks for s_ in (0, 1)]
+    other_blocks = [pairs[k][1] for k in ks] + [pairs[k][0] for k in ks]
     rep_pix = [batch.found[b]["pixel"][reps] if reps else np.zeros(0, np.uint32) for b, reps in zip(cl_blocks, reps_all)]
     feats = _features_multi(batch, other_blocks, rep_pix, [np.zeros(len(p), np.int64) for p in rep_pix])
     for j, k in enumerate(ks):
         b1, b2, start = pairs[k]
         res4 = []
         for s_, (b, bo) in enumerate(((b1, b2), (b2, b1))):
-            q, reps, pix, nz_other = cl_q[2 * j + s_], reps_all[2 * j + s_], rep_pix[2 * j + s_], feats[2 * j + s_][0]
+            e = s_ * M + j
+            q, reps, pix, nz_other = cl_q[e], reps_all[e], rep_pix[e], feats[e][0]
             loops = loops_from_reps(batch, b, q, reps, start)
             rec, other = batch.found[b], batch.found[bo]
             # differential subset (:567-568): pair < pt2 and v_self > v_other, where v = 1 off-nz, vAll on nz (0 if not found)

@@ -48,12 +48,13 @@ class _MultiGather:
         d_half = torch.from_numpy(half).to(dev)
         cnt = torch.empty((2, total), dtype=torch.int32, device=dev)
         cval = torch.empty(total, dtype=torch.float64, device=dev)
-        off = 0
-        for b, m in zip(bs, sizes):
-            if m:
-                self._features_launch(b, _off(d_pix, off), _off(d_half, off), m, _off(cnt, off), _off(cnt, total + off),
-                                      _off(cval, off))
-            off += m
+        if not self._features_one_launch(bs, sizes, d_pix, d_half, total, cnt, cval):
+            off = 0
+            for b, m in zip(bs, sizes):
+                if m:
+                    self._features_launch(b, _off(d_pix, off), _off(d_half, off), m, _off(cnt, off), _off(cnt, total + off),
+                                          _off(cval, off))
+                off += m
         cnt_h = cnt.cpu().numpy().view(np.uint32)
         cval_h = cval.cpu().numpy()
         out, off = [], 0
@@ -109,6 +110,9 @@ class _MultiGather:
         return res
 
     def _diag_means_one_launch(self, bs, sizes, d_k, out):
+        return False                        # overridden where all blocks share one source buffer
+
+    def _features_one_launch(self, bs, sizes, d_pix, d_half, total, cnt, cval):
         return False                        # overridden where all blocks share one source buffer
 
     def cluster_representatives_multi(self, bs, qs, idxs, pt):
@@ -211,6 +215,14 @@ class BandBatch(_MultiGather):
         _lib.check(self.engine.lib.mst_gather_diagonals_band(_ptr(self.band), self.n, self.dpx, int(self.starts[b]),
                                                              self.CH, ks, m, out, _stream()))
 
+    def _features_one_launch(self, bs, sizes, d_pix, d_half, total, cnt, cval):
+        starts = np.repeat(np.array([int(self.starts[b]) for b in bs], dtype=np.int64), sizes)
+        d_s = torch.from_numpy(starts).to(self.band.device)
+        _lib.check(self.engine.lib.mst_candidate_features_band_multi(_ptr(self.band), self.n, self.dpx, _ptr(d_s), self.CH,
+                                                                     _ptr(d_pix), _ptr(d_half), int(total), _ptr(cnt),
+                                                                     _off(cnt, total), _ptr(cval), _stream()))
+        return True
+
     def _diag_means_one_launch(self, bs, sizes, d_k, out):
         starts = np.repeat(np.array([int(self.starts[b]) for b in bs], dtype=np.int64), sizes)
         d_s = torch.from_numpy(starts).to(self.band.device)
@@ -239,6 +251,43 @@ class PairBandBatch(_MultiGather):
 
     def _band(self, b):
         return self.bands[0] if b < self.P else self.bands[1]
+
+    def _diag_means_one_launch(self, bs, sizes, d_k, out):
+        """one launch per run of consecutive blocks of the same sample"""
+        starts = np.repeat(np.array([int(self.starts[b]) for b in bs], dtype=np.int64), sizes)
+        d_s = torch.from_numpy(starts).to(self.bands[0].device)
+        off = 0
+        i = 0
+        while i < len(bs):
+            j = i
+            while j < len(bs) and (bs[j] < self.P) == (bs[i] < self.P):
+                j += 1
+            m = int(sum(sizes[i:j]))
+            if m:
+                _lib.check(self.engine.lib.mst_diag_means_band_multi(_ptr(self._band(bs[i])), self.n, self.dpx, _off(d_s, off),
+                                                                     self.CH, _off(d_k, off), m, _off(out, off), _stream()))
+            off += m
+            i = j
+        return True
+
+    def _features_one_launch(self, bs, sizes, d_pix, d_half, total, cnt, cval):
+        """one launch per run of consecutive blocks of the same sample (callers list sample 1's blocks first, then sample 2's)"""
+        starts = np.repeat(np.array([int(self.starts[b]) for b in bs], dtype=np.int64), sizes)
+        d_s = torch.from_numpy(starts).to(self.bands[0].device)
+        off = 0
+        i = 0
+        while i < len(bs):
+            j = i
+            while j < len(bs) and (bs[j] < self.P) == (bs[i] < self.P):
+                j += 1
+            m = int(sum(sizes[i:j]))
+            if m:
+                _lib.check(self.engine.lib.mst_candidate_features_band_multi(
+                    _ptr(self._band(bs[i])), self.n, self.dpx, _off(d_s, off), self.CH, _off(d_pix, off), _off(d_half, off), m,
+                    _off(cnt, off), _off(cnt, total + off), _off(cval, off), _stream()))
+            off += m
+            i = j
+        return True
 
     def _features_launch(self, b, pix, half, m, cnt1, cnt2, cval):
         _lib.check(self.engine.lib.mst_candidate_features_band(_ptr(self._band(b)), self.n, self.dpx, int(self.starts[b]),

@@ -237,3 +237,43 @@ def test_sigma_zero_and_octave_variants_vs_reference_fixture(golden_dir, name):
     assert got.shape == exp.shape and len(exp) > 10
     assert np.array_equal(got[:, :2], exp[:, :2]) and np.array_equal(got[:, 3], exp[:, 3])
     np.testing.assert_allclose(got[:, 2], exp[:, 2], rtol=1e-9)
+
+
+def test_complete_found_set_at_headline_geometry_vs_oracle():
+    """BASELINE config 4's block geometry (4000 x 4000, distance limit 2000) against the CPU oracle on the COMPLETE found
+    set -- not the checksums + first records block_4000.npz holds: three consecutive blocks of a synthetic 1 kb chromosome
+    go through ONE launch of the band-direct kernel, so the middle block receives the tiles it shares with the block before
+    it and gives those it shares with the block after it; its tested-pixel count, every found pixel, level and DoG value must
+    equal the oracle's (rows 3-7: SciPy gaussian_filter / maximum_filter, ~10 s), loc exactly, scale to 1e-12, p to 1e-9."""
+    import torch
+    import oracle
+    from mustache_amd.normalize import normalize_band
+    from mustache_amd.pipeline import ChromosomePipeline, block_tiling
+    from mustache_amd.synth import band_counts
+    n, dpx, res = 8000, 2000, 1000
+    pipe = ChromosomePipeline([1.6, 3.2])
+    raw = band_counts(n, dpx, 400.0, 300, 5, device=pipe.device)
+    band, _, _ = normalize_band(raw, n, dpx, res)
+    CH, start, end = block_tiling(n, dpx)
+    assert CH == 4000 and len(start) == 3
+    recs, fits, nzc = pipe.engine.sigma_loop_band(band, n, dpx, start, CH, skip_empty=True, with_q=False)
+    g = {k: v.copy() for k, v in recs[1].items()}
+    s = start[1]
+    slab = band[:, s:s + CH].cpu().numpy()
+    c = np.zeros((CH, CH))
+    r = np.arange(CH)
+    for d in range(dpx + 2):
+        L = CH - d
+        c[r[:L], r[:L] + d] = slab[d, :L]
+    nz = oracle.block_prologue(c, dpx)
+    ss = oracle.scale_space_levels(c, nz, [1.6, 3.2], blur="scipy")
+    hit = ss.pval != 2
+    assert int(nzc.cpu().numpy().view(np.uint32)[1]) == int(nz.sum()) > 3_000_000
+    pix = np.flatnonzero(nz.ravel())[hit].astype(np.uint32)
+    assert len(pix) > 100_000
+    assert np.array_equal(g["pixel"], pix)
+    assert np.array_equal(g["level"], ss.level[hit].astype(np.uint32))
+    assert np.array_equal(g["value"], ss.best[hit])
+    np.testing.assert_allclose(g["pval"], ss.pval[hit], rtol=1e-9)
+    np.testing.assert_array_equal(fits[1][0][:18], np.array([t["loc"] for t in ss.tested]))
+    np.testing.assert_allclose(fits[1][1][:18], np.array([t["scale"] for t in ss.tested]), rtol=1e-12)

@@ -68,7 +68,7 @@ def one(reps=5, blocks=12):
 
 def main():
     if "--one" in sys.argv:
-        one()
+        one(blocks=int(os.environ.get("EXP_BLOCKS", "12")))       # EXP_BLOCKS=1: a launch's fixed cost shows
         return
     libs = [a for a in sys.argv[1:] if not a.startswith("--")]
     for spec in libs:                      # path[@NAME=VALUE[,NAME=VALUE...]]  (extra environment for PROFILE builds)

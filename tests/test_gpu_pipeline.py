@@ -651,8 +651,9 @@ def test_genome_batched_cli_equals_per_chromosome_cli(tmp_path):
     assert a == b and a.count("\n") > 30
 
 
-@pytest.mark.parametrize("n,dpx,res", [(9630, 400, 5000), (14321, 2000, 1000), (5230, 150, 10000)])
-def test_shared_tiles_equal_tiles_computed_per_block(n, dpx, res):
+@pytest.mark.parametrize("n,dpx,res,octs", [(9630, 400, 5000, OCT), (14321, 2000, 1000, OCT), (5230, 150, 10000, OCT),
+                                            (6200, 1000, 2000, [3.2, 6.4])])      # the last one: the wide-radius tile
+def test_shared_tiles_equal_tiles_computed_per_block(n, dpx, res, octs):
     """Default: tiles sit on a lattice anchored at chromosome coordinate 0 and a tile that lies inside two consecutive blocks
     with its whole blur halo is computed ONCE and delivered to both (mst_scale_space_band, WorkItem).  MST_FLAG_NO_SHARE:
     every block on its own lattice, every tile once per block (the form of rounds 1 and 2).  Both, with and without empty
@@ -664,7 +665,7 @@ def test_shared_tiles_equal_tiles_computed_per_block(n, dpx, res):
     from mustache_amd.normalize import band_from_host_coo, normalize_band
     from mustache_amd.synth import synth_coo
     x, y, v = synth_coo(n, dpx, depth=150.0, seed=17)
-    pipe = ChromosomePipeline(OCT)
+    pipe = ChromosomePipeline(octs)
     eng = pipe.engine
     band, _, _ = normalize_band(band_from_host_coo(x, y, v, n, dpx, pipe.device), n, dpx, res)
     CH, start, end = block_tiling(n, dpx)

@@ -13,7 +13,7 @@ __global__ void __launch_bounds__(256) k(double *out, double a, int iters) {
         for (int u = 0; u < 8; ++u) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (MODE == 0 || MODE >= 4) t[i] = t[i] + a;                                   // v_add_f64
+                if (MODE == 0 || (MODE >= 4 && MODE <= 6)) t[i] = t[i] + a;                                   // v_add_f64
                 if (MODE == 1 || MODE == 4) m[i] = __builtin_amdgcn_mov_dpp(m[i], 0x138, 0xf, 0xf, true);   // v_mov_b32 dpp
                 if (MODE == 2 || MODE == 5) m[i] = (m[i] ^ 0x55) + 3;                         // 2 x 32-bit int VALU
                 if (MODE == 3 || MODE == 6) {                                                  // v_mov_b64 (opaque copy)

@@ -241,3 +241,66 @@ def test_genome_layout_windows_equal_the_chromosome_windows():
             assert torch.equal(win, own), (c, i)
             k += 1
     assert k == len(lay.blocks)
+
+
+def _work_list_counts(start, CH, dpx, share, band_only, ITR=30, ITC=62, RMAX=14):
+    """The tile-sharing rule of mst_scale_space_band restated (DESIGN 3.1 "tile sharing"): tiles of ITR x ITC owned pixels on a
+    lattice anchored at chromosome coordinate 0 (at the block's origin without sharing); a tile is listed for block b unless
+    block b - 1 delivers it; it is delivered to block b + 1 as well iff its staged window -- owned pixels + 1-pixel ring + RMAX
+    halo -- lies inside BOTH blocks.  Returns (work items, lattice cells visited, shared tiles)."""
+    items = tiles = shared = 0
+    given = set()
+    for b, s in enumerate(start):
+        s0 = s if share else 0
+        nxt = share and b + 1 < len(start) and 0 < start[b + 1] - s < CH
+        given_next = set()
+        for a in range(s0 // ITR, (s0 + CH - 1) // ITR + 1):
+            for c in range(s0 // ITC, (s0 + CH - 1) // ITC + 1):
+                tiles += 1
+                y0, x0 = a * ITR - s0 - 1, c * ITC - s0 - 1                  # block coordinates of the ring's corner
+                r_lo, r_hi = max(y0 + 1, 0), min(y0 + ITR, CH - 1)
+                q_lo, q_hi = max(x0 + 1, 0), min(x0 + ITC, CH - 1)
+                if r_lo > r_hi or q_lo > q_hi:
+                    continue
+                if band_only and not (q_hi - r_lo >= 4 and q_lo - r_hi <= dpx + 1):
+                    continue
+                if (a, c) in given:
+                    continue
+                items += 1
+                if nxt:
+                    d = s - start[b + 1]
+                    Y0, X0, H, W = y0 - RMAX, x0 - RMAX, ITR + 2 + 2 * RMAX, ITC + 2 + 2 * RMAX
+                    inside = lambda o: Y0 + o >= 0 and X0 + o >= 0 and Y0 + o + H <= CH and X0 + o + W <= CH
+                    if inside(0) and inside(d):
+                        shared += 1
+                        given_next.add((a, c))
+        given = given_next
+    return items, tiles, shared
+
+
+def test_work_list_of_a_launch_matches_the_sharing_rule():
+    """mst_scale_space_band_items (the launch's work list, host code of the C ABI) against the rule restated above, for the
+    headline geometry, 5 kb, an irregular last block, a chromosome of one block, and with MST_FLAG_NO_SHARE / the tile list."""
+    import ctypes
+    from mustache_amd import _lib
+    from mustache_amd.levels import LevelTable
+    from mustache_amd.pipeline import block_tiling
+    lib = _lib.load()
+    lv = LevelTable(OCT).as_struct()
+    for n, dpx in ((31119, 2000), (9630, 400), (14321, 2000), (5230, 150), (1800, 400), (12345, 1507)):
+        CH, start, end = block_tiling(n, dpx)
+        st = (ctypes.c_int64 * len(start))(*[int(s) for s in start])
+        for flags in (0, 1, 4, 5):                    # 1 = MST_FLAG_SKIP_EMPTY (tile list), 4 = MST_FLAG_NO_SHARE
+            t, s = ctypes.c_int64(0), ctypes.c_int64(0)
+            got = lib.mst_scale_space_band_items(st, len(start), CH, dpx, ctypes.byref(lv), flags, ctypes.byref(t), ctypes.byref(s))
+            exp = _work_list_counts([int(v) for v in start], CH, dpx, not (flags & 4), bool(flags & 1))
+            assert (got, s.value) == (exp[0], exp[2]), (n, dpx, flags, got, s.value, exp)
+            assert t.value == got + s.value          # "tiles" = what the blocks would run one by one
+            if flags == 4:                            # every block on its own lattice, every tile once per block
+                assert s.value == 0 and got == len(start) * (-(-CH // 30)) * (-(-CH // 62))
+    # at 1 kb (blocks overlap by half their edge) the sharing removes a fifth of the dense work and more of the tile list
+    CH, start, end = block_tiling(248957, 2000)
+    st = (ctypes.c_int64 * len(start))(*[int(s) for s in start])
+    t, s = ctypes.c_int64(0), ctypes.c_int64(0)
+    it = lib.mst_scale_space_band_items(st, len(start), CH, 2000, ctypes.byref(lv), 0, ctypes.byref(t), ctypes.byref(s))
+    assert 0.20 < s.value / t.value < 0.25 and it + s.value <= t.value

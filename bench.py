@@ -103,9 +103,11 @@ def parse():
                     help="headline workload only (plus chr21 / band_skip / fma): no genome, variants, file or CPU legs -- "
                          "what the PMC passes of scripts/profile_bench.sh run")
     ap.add_argument("--small", action="store_true", help="debug: 12 blocks instead of 124")
+    ap.add_argument("--with-file", action="store_true", help="keep the from-a-.hic-file leg in a --core run")
     a = ap.parse_args()
     if a.core:
-        a.no_cpu = a.no_file = True
+        a.no_cpu = True
+        a.no_file = not a.with_file
     return a
 
 
@@ -246,46 +248,74 @@ def write_synthetic_hic(path, n, dpx, res, depth, nloops, seed, keep, device, bl
     return write_hic_bulk(path, "chr1", n * res, res, blocks(), block_bins, threads=min(32, os.cpu_count() or 4))
 
 
-def file_leg(w, device, keep=200.0):
-    """file -> loops for a config-4-shaped `.hic` (chr1 at 1 kb), stage by stage.  The records go from the
-    native reader's per-thread arenas into page-locked buffers (int32 bin, int32 distance, float32 value) and from there to
-    the device loader -- no int64 / float64 COO triple, no Python de-duplication between inflate and H2D."""
+def file_leg(w, device, keep=200.0, rank=0, world=1, grouped=False, backend="nccl"):
+    """file -> loops for a config-4-shaped `.hic` (chr1 at 1 kb), stage by stage, on `world` ranks.  The
+    records go from the native reader's per-thread arenas into page-locked buffers (int32 bin, int32 distance, float32 value)
+    and from there to the device loader -- no int64 / float64 COO triple, no Python de-duplication between inflate and H2D.
+    With N > 1 ranks (one process per GPU) the file is read ONCE between them: rank r inflates share r of the blocks
+    (mst_hic_decode_intra_packed_part), the shares are exchanged (sharding.all_gather_packed: RCCL over xGMI from device
+    memory), every rank builds and normalises the same band, runs its contiguous range of blocks, and the loops are gathered
+    -- the times are rank 0's wall clock between two barriers, the per-rank read times are listed beside them."""
     import tempfile
     import torch
+    import torch.distributed as dist
     from mustache_amd.hicfile import HicFile, read_intra_packed
     from mustache_amd.normalize import band_from_packed, normalize_band, pinned_packed_alloc
-    tmp = tempfile.mkdtemp(prefix="mst_bench_")
-    path = os.path.join(tmp, "chr1_1kb.hic")
+
+    def barrier():
+        if grouped:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    tmp = path = None
+    nrec = size = t_write = 0
     try:
-        t0 = time.time()
-        nrec = write_synthetic_hic(path, w.n, w.dpx, w.res, 400.0, 8000, 1, keep, device)
-        t_write = time.time() - t0
-        size = os.path.getsize(path)
+        if rank == 0:
+            tmp = tempfile.mkdtemp(prefix="mst_bench_")
+            path = os.path.join(tmp, "chr1_1kb.hic")
+            t0 = time.time()
+            nrec = write_synthetic_hic(path, w.n, w.dpx, w.res, 400.0, 8000 if w.n > 100000 else 800, 1, keep, device)
+            t_write = time.time() - t0
+            size = os.path.getsize(path)
+        if grouped:
+            box = [path]
+            dist.broadcast_object_list(box, src=0)          # one node: /tmp is shared by the ranks
+            path = box[0]
         t0 = time.time()
         h = HicFile(path)
         t_open = time.time() - t0
         passes = []
         for rep in range(3):        # pass 1 pays for fresh pages (reader arenas, pinned buffers, allocator); 2 and 3 = steady state
-            torch.cuda.synchronize()
+            barrier()
             t = [time.time()]
-            pc = read_intra_packed(h, "chr1", w.res, "KR", w.dpx, 0, alloc=pinned_packed_alloc)
+            pc = read_intra_packed(h, "chr1", w.res, "KR", w.dpx, 0, alloc=pinned_packed_alloc, part=(rank, world))
             t.append(time.time())
-            band = band_from_packed(pc, w.dpx, device)
+            band = band_from_packed(pc, w.dpx, device)      # world > 1: the shares are exchanged in here
+            n = int(band.shape[1])
             torch.cuda.synchronize()
             t.append(time.time())
-            nb, _, _ = normalize_band(band, pc.n, w.dpx, w.res)
+            nb, _, _ = normalize_band(band, n, w.dpx, w.res)
             torch.cuda.synchronize()
             t.append(time.time())
             tm = {}
-            loops = w.pipe.run_band(nb, pc.n, w.dpx, 0.88, 0.1, timings=tm, distributed=False)
-            torch.cuda.synchronize()
+            loops = w.pipe.run_band(nb, n, w.dpx, 0.88, 0.1, timings=tm, distributed=grouped)   # blocks sharded, loops gathered
+            barrier()
             t.append(time.time())
+            reads = [t[1] - t[0]]
+            recs = [len(pc)]
+            if grouped:
+                box = [None] * world
+                dist.all_gather_object(box, (t[1] - t[0], len(pc), pc.blocks_mine))
+                reads, recs = [b[0] for b in box], [b[1] for b in box]
             passes.append({"inflate_decode_pack_s": round(t[1] - t[0], 4), "upload_and_band_scatter_s": round(t[2] - t[1], 4),
                            "normalize_s": round(t[3] - t[2], 4), "kernels_and_tail_s": round(t[4] - t[3], 4),
-                           "total_s": round(t[4] - t[0], 4), "loops": len(loops), "records": len(pc), "n": pc.n})
+                           "total_s": round(t[4] - t[0], 4), "loops": len(loops), "records": int(sum(recs)), "n": n,
+                           "read_s_per_rank": [round(r, 4) for r in reads], "records_per_rank": [int(r) for r in recs],
+                           "hic_blocks_total": pc.blocks_total})
             del pc, band, nb
         h.close()
         best = dict(min(passes[1:], key=lambda p: p["total_s"]))
+        best["ranks"] = world
         best["open_index_s"] = round(t_open, 4)
         best["reader_plus_upload_s"] = round(best["inflate_decode_pack_s"] + best["upload_and_band_scatter_s"], 4)
         best["gpu_step_s"] = round(best["normalize_s"] + best["kernels_and_tail_s"], 4)
@@ -294,15 +324,20 @@ def file_leg(w, device, keep=200.0):
                         "records_written": int(nrec), "bytes": int(size), "write_s_untimed": round(t_write, 1),
                         "pixel_kept_with_probability": "min(1, %g / (d + 1))" % keep}
         best["host_threads"] = os.cpu_count()
-        best["note"] = "synthetic chr1@1kb (thinned with the distance), from the open file to the final loop list on 1 GPU: " \
-                       "threaded inflate + record decode into per-thread arenas + copy into page-locked buffers " \
-                       "(libmustache_io.so), three uploads + mst_band_from_packed, mst_normalize_band, fused kernels + device " \
-                       "BH / selection / clustering + host tail (product mode).  Best of passes 2-3 (steady state of a " \
-                       "whole-genome run: arenas, pinned buffers and the device allocator warm); first_pass beside it"
+        best["note"] = "synthetic chr1@1kb (thinned with the distance), from the open file to the final loop list on %d GPU(s), " \
+                       "rank 0's wall clock between barriers: threaded inflate + record decode into per-thread arenas + copy " \
+                       "into page-locked buffers (libmustache_io.so; with N ranks each inflates 1/N of the file's blocks and " \
+                       "the packed records are all-gathered), uploads + mst_band_scatter_packed, mst_normalize_band, fused " \
+                       "kernels on this rank's blocks + device BH / selection / clustering + host tail (product mode) + the " \
+                       "gather of the loops.  Best of passes 2-3 (steady state of a whole-genome run: arenas, pinned buffers " \
+                       "and the device allocator warm); first_pass beside it" % world
         return best
     finally:
-        import shutil
-        shutil.rmtree(tmp, ignore_errors=True)
+        if tmp:
+            import shutil
+            if grouped:
+                dist.barrier()
+            shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _dense_raw_block(w, block_index):
@@ -351,15 +386,38 @@ def cpu_baseline_pool(w, block_indices, procs):
     return time.time() - t0, res
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves (one process per GPU,
+    torch.distributed.run on 127.0.0.1 with a port that is free right now) and hand their exit code on.  The driver's own
+    `python -m torch.distributed.run ... bench.py --gpus N` keeps working: it sets WORLD_SIZE, and this is skipped."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a torchrun environment: launching `%s`" % (args.gpus, " ".join(cmd)), file=sys.stderr,
+          flush=True)
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
+        # the launcher's environment is what the processes really are: say so and go on rather than fail the run
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: running with %d rank(s)" % (args.gpus, world, world), file=sys.stderr,
+              flush=True)
     # test hooks (used to exercise the N > 1 control flow on a single-GPU box): a gloo process group and all ranks on GPU 0
     backend = os.environ.get("MST_BENCH_BACKEND", "nccl")
     if os.environ.get("MST_BENCH_ONE_DEVICE"):
@@ -371,7 +429,11 @@ def main():
     force_dist = bool(os.environ.get("MST_BENCH_FORCE_DIST")) and world == 1
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29561")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                raise SystemExit("WORLD_SIZE=%d without MASTER_PORT: launch with torch.distributed.run, or run `python "
+                                 "bench.py --gpus N` without any torchrun variable and bench.py starts the ranks itself" % world)
+            os.environ["MASTER_PORT"] = str(_free_port())          # 1-rank group (MST_BENCH_FORCE_DIST): any free port
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
         else:
@@ -429,7 +491,14 @@ def main():
                                          "kernel_ms_mean": round(k_ms, 3), "job_ms_per_step": round(ms_per_step, 3)}),
           file=sys.stderr, flush=True)
     px_per_launch = len(w.mine) * w.CH * w.CH / launches_per_step
-    achieved_tf = px_per_launch * FLOPS_PER_PIXEL / (k_ms * 1e-3) / 1e12
+    # Work really executed: a tile that lies inside two overlapping blocks of a launch is computed ONCE (tile sharing), so the
+    # launch's workgroups cover work_items / tiles of the blocks' pixels.  The roofline prices those only (skipped
+    # work is a separate speed-up, never part of the roofline fraction); the saving is reported as `tile_sharing`.
+    wi = work_items(w, False)
+    share_ratio = wi[0] / float(wi[1])
+    px_computed = px_per_launch * share_ratio
+    achieved_tf = px_computed * FLOPS_PER_PIXEL / (k_ms * 1e-3) / 1e12
+    credited_tf = px_per_launch * FLOPS_PER_PIXEL / (k_ms * 1e-3) / 1e12
     achieved_gbs = px_per_launch * BYTES_PER_PIXEL / (k_ms * 1e-3) / 1e9
     peak_tf = FP64_PEAK_TFLOPS / 2
     exec_fpp = executed_flops_per_pixel()
@@ -437,13 +506,20 @@ def main():
             "frac": round(achieved_tf / peak_tf, 4), "traffic": None,
             "kernel": "scale_space_kernel<Tile<32,64,14>, band>", "kernel_ms": round(k_ms, 3),
             "launches_per_step": launches_per_step, "kernel_ms_per_step": round(k_ms * launches_per_step, 3),
-            "pixels_per_launch": int(px_per_launch), "flops_per_pixel": FLOPS_PER_PIXEL,
+            "pixels_per_launch": int(px_per_launch), "computed_pixels_per_launch": int(round(px_computed)),
+            "flops_per_pixel": FLOPS_PER_PIXEL,
             "executed_flops_per_pixel": round(exec_fpp, 1),
-            "executed_frac": round(px_per_launch * exec_fpp / (k_ms * 1e-3) / 1e12 / peak_tf, 4),
+            "executed_frac": round(px_computed * exec_fpp / (k_ms * 1e-3) / 1e12 / peak_tf, 4),
+            "work_items": wi[0], "tiles": wi[1], "shared_tiles": wi[2], "work_items_per_launch": wi[3],
+            "block_pixel_view": {"achieved": round(credited_tf, 3), "frac": round(credited_tf / peak_tf, 4),
+                                 "note": "the same kernel time with every BLOCK pixel credited (a shared tile counted for both "
+                                         "blocks it is delivered to): the throughput view of `value`, NOT the kernel's efficiency"},
             "note": "peak = FP64 vector add/mul rate without FMA (78.6 TFLOP/s FMA-counted / 2 at the 2.4 GHz spec clock): "
-                    "the taps cannot be contracted into FMAs if the DoG values are to stay bit-identical to SciPy's; "
-                    "`achieved` counts the 1152 algorithmic blur flops per pixel, `executed_*` adds the halo columns, "
-                    "the ring and subtracts the two repeated levels; max / sieve / statistics instructions are not counted",
+                    "the taps cannot be contracted into FMAs if the DoG values are to stay bit-identical to SciPy's.  "
+                    "`achieved` = 1152 algorithmic blur flops per pixel x the pixels of the workgroups that RAN "
+                    "(computed_pixels_per_launch = pixels_per_launch x work_items / tiles) / the launch time from HIP events on "
+                    "the launch stream; `executed_*` adds the halo columns and the ring and subtracts the two repeated levels; "
+                    "max / sieve / statistics instructions are not counted",
             "hbm_model": {"bound": "hbm", "bytes_per_pixel_model": BYTES_PER_PIXEL, "achieved_equivalent": round(achieved_gbs, 1),
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac_of_model_roofline": round(achieved_gbs / HBM_PEAK_GBS, 4),
                           "note": "level-streaming model of BASELINE.md (every level written and re-read): the rate the "
@@ -452,23 +528,18 @@ def main():
     import re
     cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))
                    if re.fullmatch(r"r\d+_pmc_traffic\.json", os.path.basename(f)))
-    wi = work_items(w, False)
-    roof.update({"work_items": wi[0], "tiles": wi[1], "shared_tiles": wi[2], "work_items_per_launch": wi[3],
-                 "executed_frac": round(px_per_launch * exec_fpp * wi[0] / wi[1] / (k_ms * 1e-3) / 1e12 / peak_tf, 4),
-                 "sharing_note": "consecutive blocks overlap by half their edge (mustache.py:899-908); a tile that lies inside two "
-                                 "blocks of a launch with its whole blur halo is computed once and its records / statistics are "
-                                 "delivered to both (identical bits, tests): `achieved` counts the algorithmic flops of every "
-                                 "block pixel as the metric does, `executed_frac` only the workgroups really run -- the figure "
-                                 "comparable with rounds 1-2 is no_share.roofline"})
     pmc = cands[-1] if cands else ""                      # the latest round's profiling session
     if pmc:
         try:
             pj = json.load(open(pmc))
-            roof["traffic"] = round(pj["bytes_per_pixel"] * px_per_launch)        # PMC bytes/pixel x pixels/launch
+            # bytes per computed pixel of the launch form that is timed here (dense, tiles shared) when the session measured
+            # that form (`launch_form`), else the session's figure per block pixel
+            bpp = pj.get("bytes_per_computed_pixel", pj["bytes_per_pixel"])
+            roof["traffic"] = round(bpp * px_computed)
             roof["traffic_source"] = "profiles/%s: FETCH_SIZE (x2, gfx950) + WRITE_SIZE of the fused kernel in that " \
-                                     "round's rocprofv3 --pmc pass (%s), %.2f B/pixel" % (os.path.basename(pmc),
-                                                                                          pj.get("command", "?"),
-                                                                                          pj["bytes_per_pixel"])
+                                     "round's rocprofv3 --pmc pass (%s; launch form: %s), %.2f B per computed pixel" % (
+                                         os.path.basename(pmc), pj.get("command", "?"),
+                                         pj.get("launch_form", "dense, MST_FLAG_NO_SHARE"), bpp)
         except Exception:
             pass
 
@@ -486,10 +557,15 @@ def main():
                  "note": "identical results; only the tiles that can reach the tested band are launched -- `value` counts ALL "
                          "block pixels (the headline value / roofline are always the dense run); band_skip.roofline prices the "
                          "launched tiles alone"}
-    band_skip["roofline"]["frac"] = round(band_skip["roofline"]["achieved"] / peak_tf, 4)
     wis = work_items(w, True)
-    band_skip["roofline"].update({"work_items": wis[0], "tiles": wis[1], "shared_tiles": wis[2], "work_items_per_launch": wis[3],
-                                  "executed_frac_on_run_workgroups": round(band_skip["roofline"]["frac"] * wis[0] / wis[1], 4)})
+    bs_credit = band_skip["roofline"]["achieved"]
+    band_skip["roofline"].update({"achieved": round(bs_credit * wis[0] / wis[1], 3), "frac": round(bs_credit * wis[0] / wis[1] / peak_tf, 4),
+                                  "work_items": wis[0], "tiles": wis[1], "shared_tiles": wis[2], "work_items_per_launch": wis[3],
+                                  "block_pixel_view": {"achieved": round(bs_credit, 3), "frac": round(bs_credit / peak_tf, 4)},
+                                  "note": "the product mode's own roofline: 1152 algorithmic flops per pixel of the band tiles "
+                                          "the workgroups really computed (launched_tile_fraction x block pixels x work_items / "
+                                          "tiles; all of them band tiles: real staging, sieve, statistics) over the kernel "
+                                          "time; block_pixel_view credits a shared tile to both of its blocks"})
 
     # the same two steps with every tile computed once PER BLOCK on the block's own lattice (MST_FLAG_NO_SHARE, the form of
     # rounds 1 and 2): identical records; this is the figure that measures the kernel itself
@@ -512,6 +588,16 @@ def main():
                                           "band_skip": work_items(w, True, share=False)[3]},
                 "note": "MST_FLAG_NO_SHARE: every workgroup's flops are algorithmic flops of one block -- the kernel's own "
                         "efficiency, comparable with the roofline figures of rounds 1 and 2"}
+
+    # tile sharing as what it is: skipped work, reported as its own speed-up (like band_skip), not as kernel efficiency
+    tile_sharing = {"speedup": round(value / no_share["value"], 4),
+                    "kernel_speedup": round(kn / (k_ms * launches_per_step), 4),
+                    "band_skip_speedup": round(band_skip["value"] / no_share["band_skip"]["value"], 4),
+                    "work_items": wi[0], "tiles": wi[1], "shared_tiles": wi[2],
+                    "note": "consecutive blocks overlap by half their edge at 1 kb (mustache.py:899-908); a tile that lies inside "
+                            "two blocks of a launch with its whole blur halo is computed once and its records / statistics are "
+                            "delivered to both (identical bits: tests, and the CPU leg below compares a whole block's found "
+                            "set).  `value` is the step WITH sharing; no_share re-runs it with every tile once per block"}
 
     # opt-in relaxed arithmetic (fused multiply-add per tap pair): DoG no longer bit-identical (~1e-16 relative, north_star
     # allows 1e-5), found set unchanged on every case tested.  Reported separately; `value` is always the exact mode.
@@ -539,7 +625,7 @@ def main():
                      "efficiency_bound_at": {str(k): round(len(w.start) / (k * -(-len(w.start) // k)), 4) for k in (1, 2, 4, 8)},
                      "note": "contiguous split of the blocks: the slowest rank carries ceil(blocks / ranks) blocks, so "
                              "the strong-scaling efficiency cannot exceed blocks / (ranks * ceil(blocks / ranks))"},
-           "roofline": roof, "band_skip": band_skip, "no_share": no_share, "fma_mode": fma_mode,
+           "roofline": roof, "tile_sharing": tile_sharing, "band_skip": band_skip, "no_share": no_share, "fma_mode": fma_mode,
            "normalize_ms_untimed": round(w.normalize_s * 1e3, 2),
            # row 1 of SURVEY 8a next to it: 16 B per band sample (8 read + 8 written) over mst_normalize_band (median of 3,
            # HIP events: the per-diagonal statistics pass + the window pass; the statistics pass reads the band once more)
@@ -547,6 +633,44 @@ def main():
                                   "achieved": round(16.0 * (w.dpx + 2) * w.n / w.normalize_s / 1e9, 1),
                                   "frac": round(16.0 * (w.dpx + 2) * w.n / w.normalize_s / 1e9 / HBM_PEAK_GBS, 4)}}
 
+    if rank == 0 and world == 1 and not args.core:
+        # SURVEY 8d defines the metric's timed region from "normalised COO resident on device", i.e. including row 2's scatter
+        # (mustache.py:919-924, `cc[xc, yc] = vc`).  Here normalisation runs on the band, so the step above starts one stage
+        # later; this leg times that stage for the same chromosome -- the normalised band's non-zero samples as an int64 /
+        # int64 / float64 COO on the device -> mst_band_from_coo (zero fill + scatter) -- and adds it to the step
+        from mustache_amd.normalize import band_from_coo
+        xs, ys, vs = [], [], []
+        cols = 1 << 15
+        for i0 in range(0, w.n, cols):
+            sl = w.band[:, i0:i0 + cols]
+            dd, cc = torch.nonzero(sl, as_tuple=True)
+            xs.append(cc + i0)
+            ys.append(cc + i0 + dd)
+            vs.append(sl[dd, cc])
+            del dd, cc, sl
+        cx, cy, cv = torch.cat(xs), torch.cat(ys), torch.cat(vs)
+        del xs, ys, vs
+        sc_ms = []
+        for it in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rebuilt = band_from_coo(cx, cy, cv, w.n, w.dpx)
+            e1.record()
+            torch.cuda.synchronize()
+            sc_ms.append(e0.elapsed_time(e1))
+            if it == 0:
+                same_band = bool(torch.equal(rebuilt, w.band))
+            del rebuilt
+        sc = sorted(sc_ms[1:])[1] * 1e-3
+        out["row2_scatter"] = {"records": int(cv.numel()), "ms": round(sc * 1e3, 3), "band_rebuilt_identical": same_band,
+                               "GB/s": round((24.0 * cv.numel() + 8.0 * w.band.numel()) / sc / 1e9, 1),
+                               "value_from_coo": round(w.total_mpix / (dt / args.steps + sc), 1), "unit": "Mpix/s",
+                               "note": "mst_band_from_coo on the chromosome's normalised COO (int64 x, int64 y, float64 v on the "
+                                       "device; 24 B read per record + the 8 B/sample zero fill of the band), median of 3, HIP "
+                                       "events; value_from_coo = megapixels / (step + this) = the metric with SURVEY 8d's timed "
+                                       "region 'normalised COO resident on device -> found records on host'"}
+        del cx, cy, cv
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1:
         # informational: the whole per-chromosome run from the normalised band (rows 2-9, empty tiles skipped as the
         # pipeline does by default), next to the untimed normalisation -- NOT part of `value`
@@ -749,8 +873,11 @@ def main():
                                                   "path for resolutions below ~238 bp)"}
         del raww
         out["variants"] = var
-    if rank == 0 and world == 1 and not args.no_file:
-        out["end_to_end_from_file"] = file_leg(w, device)
+    if not args.no_file:
+        # every rank takes part (N > 1: each inflates its share of the file, the shares are exchanged); rank 0 reports
+        fl = file_leg(w, device, rank=rank, world=world, grouped=grouped, backend=backend)
+        out["end_to_end_from_file"] = fl
+        out["ranks"]["read_s"] = fl["read_s_per_rank"]
     if rank == 0 and world == 1 and not args.no_cpu:
         bi = len(w.start) // 2
         import numpy as np
@@ -768,7 +895,11 @@ def main():
                                "kind": "port",
                                "sample": "block %d of the same workload (one 4000x4000 block, %.1f s), rows 3-7 of the "
                                          "oracle = the reference's SciPy calls, single process; the GPU records compared with it "
-                                         "come from a 3-block launch in which this block shares tiles with both neighbours"
+                                         "come from a 3-block launch in which this block shares tiles with both neighbours.  "
+                                         "NOT in this baseline: the reference's normalize_sparse (row 1, ~35 min for this "
+                                         "shape, SURVEY section 6) and its tail -- BH, the 16 M-key argsort, the per-candidate "
+                                         "filter loop, clustering (rows 8-9); the GPU side of the ratio (`value`) is rows 2-7, so "
+                                         "the quoted speed-ups are for rows 3-7 only and conservative for the whole run"
                                          % (bi, cpu_s),
                                "found_pixels_cpu": cpu_found, "found_pixels_gpu": found_gpu,
                                "found_set_pixels_levels_values_identical": bool(same), "pvalue_max_rel_err": p_err,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MST_ABI_VERSION 1
+#define MST_ABI_VERSION 2
 
 #define MST_OK 0
 #define MST_E_ARG (-1)      /* bad argument (null pointer, size, unsupported radius ...) */
@@ -190,6 +190,19 @@ int mst_band_from_coo(const int64_t *x, const int64_t *y, const double *v, int64
  * the host or across PCIe.  band is zero-filled first; records with dist > dpx + 1 are ignored. */
 int mst_band_from_packed(const int32_t *x, const int32_t *dist, const float *v, int64_t nnz, int64_t n, int32_t dpx,
                          double *band, void *stream);
+
+/* Slab-wise form of the same scatter for a streaming read (the reader hands over page-locked slabs of records while later
+ * `.hic` blocks are still being inflated; with one process per GPU every rank scatters the slabs of all ranks): NO clearing
+ * -- the caller zero-fills `band` once -- and the distance as int32 (dist_bytes = 4) or uint16 (dist_bytes = 2: 10 bytes
+ * per record across PCIe; needs dpx + 1 <= 65535).  Slabs may be scattered in any order: a matrix holds every pixel once. */
+int mst_band_scatter_packed(const int32_t *x, const void *dist, int32_t dist_bytes, const float *v, int64_t nnz, int64_t n,
+                            int32_t dpx, double *band, void *stream);
+
+/* Read-back check of packed scatters: *mismatches (dev uint64, zeroed by the caller) += the number of records whose pixel
+ * does not hold their value afterwards -- a pixel written by two records with different values (malformed input; the
+ * reference's scatter keeps the last one, mustache.py:921-924) shows up for one of them whichever store won the race. */
+int mst_band_verify_packed(const int32_t *x, const void *dist, int32_t dist_bytes, const float *v, int64_t nnz, int64_t n,
+                           int32_t dpx, const double *band, uint64_t *mismatches, void *stream);
 
 /* band -> COO order: v[e] = band[|y-x|][min(x, y)]  (the `v[indices] = vals[x[indices]]` write-back, :669). */
 int mst_band_to_coo(const double *band, const int64_t *x, const int64_t *y, int64_t nnz, int64_t n, int32_t dpx,

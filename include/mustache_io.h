@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MST_IO_ABI_VERSION 1
+#define MST_IO_ABI_VERSION 2
 #define MST_IO_OK 0
 #define MST_IO_E_ARG (-1)     /* bad argument */
 #define MST_IO_E_FILE (-2)    /* cannot open / map the file */
@@ -88,6 +88,16 @@ int64_t mst_hic_read_intra_packed(mst_hic *h, const char *chrom, int32_t resolut
 int64_t mst_hic_decode_intra_packed(mst_hic *h, const char *chrom, int32_t resolution, const char *norm,
                                     int64_t max_dist_bins, int64_t chrom_size_bp, int32_t n_threads, int64_t *n_bins);
 int mst_hic_fetch_packed(mst_hic *h, int32_t *x, int32_t *dist, float *v, int64_t capacity, int32_t n_threads);
+/* One process per GPU (the multi-GPU form of the per-chromosome run, reference mustache.py:913-937 forks per block and every
+ * worker inherits the ONE parsed contact list): rank `part` of `n_parts` inflates and decodes only its share of the
+ * chromosome's near-diagonal blocks -- a contiguous run in block index order holding 1 / n_parts of the compressed bytes --
+ * so that N ranks on one host read the file ONCE between them; the ranks then exchange their packed records
+ * (mustache_amd.sharding.all_gather_packed) and every rank scatters the same record set into its band.  *n_bins is this
+ * part's max(binY) + 1 (the chromosome's is the maximum over the parts); *blocks_total / *blocks_mine (optional) count the
+ * near-diagonal blocks of the chromosome and those this part decoded.  mst_hic_fetch_packed delivers the part's records. */
+int64_t mst_hic_decode_intra_packed_part(mst_hic *h, const char *chrom, int32_t resolution, const char *norm,
+                                         int64_t max_dist_bins, int64_t chrom_size_bp, int32_t n_threads, int32_t part,
+                                         int32_t n_parts, int64_t *n_bins, int32_t *blocks_total, int32_t *blocks_mine);
 
 /* ---- text contact maps ------------------------------------------------------------------------------------------------
  * The parse step of read_pd() (reference mustache/mustache.py:254-258): `pd.read_csv(f, sep=sep, header=None)` followed

@@ -700,7 +700,16 @@ static int intra_todo(mst_hic *h, const char *chrom, int32_t resolution, const c
 extern "C" int64_t mst_hic_decode_intra_packed(mst_hic *h, const char *chrom, int32_t resolution, const char *norm,
                                                int64_t max_dist_bins, int64_t chrom_size_bp, int32_t n_threads,
                                                int64_t *n_bins) {
-    if (!h || !chrom || !n_bins || resolution <= 0) return fail(MST_IO_E_ARG, "mst_hic_decode_intra_packed: bad argument");
+    return mst_hic_decode_intra_packed_part(h, chrom, resolution, norm, max_dist_bins, chrom_size_bp, n_threads, 0, 1, n_bins,
+                                            nullptr, nullptr);
+}
+
+extern "C" int64_t mst_hic_decode_intra_packed_part(mst_hic *h, const char *chrom, int32_t resolution, const char *norm,
+                                                    int64_t max_dist_bins, int64_t chrom_size_bp, int32_t n_threads,
+                                                    int32_t part, int32_t n_parts, int64_t *n_bins, int32_t *blocks_total,
+                                                    int32_t *blocks_mine) {
+    if (!h || !chrom || !n_bins || resolution <= 0 || n_parts < 1 || part < 0 || part >= n_parts)
+        return fail(MST_IO_E_ARG, "mst_hic_decode_intra_packed: bad argument");
     *n_bins = 0;
     h->packed_total = -1;
     try {
@@ -710,6 +719,26 @@ extern "C" int64_t mst_hic_decode_intra_packed(mst_hic *h, const char *chrom, in
         bool use_norm = false;
         const int rc = intra_todo(h, chrom, resolution, norm, max_dist_bins, todo, z, norm_vec, &use_norm);
         if (rc != MST_IO_OK) return rc;
+        if (blocks_total) *blocks_total = (int32_t)todo.size();
+        if (n_parts > 1) {
+            // part p of n: a contiguous run of the near-diagonal blocks in file index order, cut so that the parts hold
+            // equal shares of the COMPRESSED bytes (block i belongs to the part its byte midpoint falls into) -- every
+            // block is decoded by exactly one part, whatever n is
+            std::vector<double> mid(todo.size());
+            double run = 0.0;
+            for (size_t i = 0; i < todo.size(); ++i) {
+                mid[i] = run + 0.5 * (double)todo[i]->size;
+                run += (double)todo[i]->size;
+            }
+            std::vector<const BlockRef *> own;
+            for (size_t i = 0; i < todo.size(); ++i) {
+                int p = run > 0.0 ? (int)(mid[i] / run * (double)n_parts) : 0;
+                p = p < 0 ? 0 : (p >= n_parts ? n_parts - 1 : p);
+                if (p == part) own.push_back(todo[i]);
+            }
+            todo.swap(own);
+        }
+        if (blocks_mine) *blocks_mine = (int32_t)todo.size();
         int nt = n_threads > 0 ? n_threads : default_threads();
         if (nt < 1) nt = 1;
         if ((size_t)nt > todo.size()) nt = todo.empty() ? 1 : (int)todo.size();

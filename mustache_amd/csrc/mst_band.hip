@@ -48,6 +48,34 @@ band_scatter_packed_kernel(const int32_t *__restrict__ x, const int32_t *__restr
     }
 }
 
+// the same with the distance as uint16 (10 bytes per record on PCIe; the distance limit is at most 65 533 bins, as
+// mst_normalize_band requires) -- slabs of a streaming read are scattered one by one, in any order
+__global__ void __launch_bounds__(kThreads)
+band_scatter_packed16_kernel(const int32_t *__restrict__ x, const uint16_t *__restrict__ dist, const float *__restrict__ v,
+                             int64_t nnz, int64_t n, int dpx, double *__restrict__ band) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride) {
+        const int64_t lo = x[e], d = dist[e];
+        if (d <= dpx + 1 && lo >= 0 && lo + d < n) band[d * n + lo] = (double)v[e];
+    }
+}
+
+// read-back check of a packed scatter: counts the records whose pixel does not hold their value -- a pixel that two records
+// with different values were written to shows up for one of them whichever store won the race (malformed input: a `.hic`
+// matrix holds every pixel once)
+template <class D>
+__global__ void __launch_bounds__(kThreads)
+band_verify_packed_kernel(const int32_t *__restrict__ x, const D *__restrict__ dist, const float *__restrict__ v, int64_t nnz,
+                          int64_t n, int dpx, const double *__restrict__ band, unsigned long long *__restrict__ mismatches) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride) {
+        const int64_t lo = x[e], d = (int64_t)dist[e];
+        if (d >= 0 && d <= dpx + 1 && lo >= 0 && lo + d < n && band[d * n + lo] != (double)v[e]) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 __global__ void __launch_bounds__(kThreads)
 band_gather_kernel(const double *__restrict__ band, const int64_t *__restrict__ x, const int64_t *__restrict__ y,
                    int64_t nnz, int64_t n, int dpx, double *__restrict__ v) {
@@ -823,6 +851,41 @@ extern "C" int mst_band_from_packed(const int32_t *x, const int32_t *dist, const
     if (nnz == 0) return MST_OK;
     int64_t want = (nnz + kThreads - 1) / kThreads;
     band_scatter_packed_kernel<<<(int)(want < 65536 ? want : 65536), kThreads, 0, s>>>(x, dist, v, nnz, n, dpx, band);
+    MST_LAUNCH_CHECK();
+    return MST_OK;
+}
+
+extern "C" int mst_band_scatter_packed(const int32_t *x, const void *dist, int32_t dist_bytes, const float *v, int64_t nnz,
+                                       int64_t n, int32_t dpx, double *band, void *stream) {
+    if (!band || n <= 0 || dpx < 0 || nnz < 0 || (nnz > 0 && (!x || !dist || !v)) || (dist_bytes != 2 && dist_bytes != 4) ||
+        (dist_bytes == 2 && dpx + 1 > 65535))
+        return mst::fail(MST_E_ARG, "mst_band_scatter_packed: bad argument (dist_bytes 2 or 4; 2 needs dpx + 1 <= 65535)");
+    if (nnz == 0) return MST_OK;
+    hipStream_t s = mst::as_stream(stream);
+    int64_t want = (nnz + kThreads - 1) / kThreads;
+    const int g = (int)(want < 65536 ? want : 65536);
+    if (dist_bytes == 2)
+        band_scatter_packed16_kernel<<<g, kThreads, 0, s>>>(x, (const uint16_t *)dist, v, nnz, n, dpx, band);
+    else
+        band_scatter_packed_kernel<<<g, kThreads, 0, s>>>(x, (const int32_t *)dist, v, nnz, n, dpx, band);
+    MST_LAUNCH_CHECK();
+    return MST_OK;
+}
+
+extern "C" int mst_band_verify_packed(const int32_t *x, const void *dist, int32_t dist_bytes, const float *v, int64_t nnz,
+                                      int64_t n, int32_t dpx, const double *band, uint64_t *mismatches, void *stream) {
+    if (!band || !mismatches || n <= 0 || dpx < 0 || nnz < 0 || (nnz > 0 && (!x || !dist || !v)) ||
+        (dist_bytes != 2 && dist_bytes != 4))
+        return mst::fail(MST_E_ARG, "mst_band_verify_packed: bad argument");
+    if (nnz == 0) return MST_OK;
+    hipStream_t s = mst::as_stream(stream);
+    int64_t want = (nnz + kThreads - 1) / kThreads;
+    const int g = (int)(want < 65536 ? want : 65536);
+    unsigned long long *m = reinterpret_cast<unsigned long long *>(mismatches);
+    if (dist_bytes == 2)
+        band_verify_packed_kernel<uint16_t><<<g, kThreads, 0, s>>>(x, (const uint16_t *)dist, v, nnz, n, dpx, band, m);
+    else
+        band_verify_packed_kernel<int32_t><<<g, kThreads, 0, s>>>(x, (const int32_t *)dist, v, nnz, n, dpx, band, m);
     MST_LAUNCH_CHECK();
     return MST_OK;
 }

@@ -24,19 +24,27 @@ struct StageSlot {
     int dev = -1;
     bool pending = false;
 };
-constexpr int kStageSlots = 16;
+// Two rings per host thread: 16 slots for the small tables (level table, block origins: at most kSmallBytes each, so the ring
+// never holds more than 1 MB of page-locked memory) and 4 slots for the occasional larger list (a difference-kernel tile list
+// of a whole-genome launch: grow-only to the largest seen).  The slots are released when the thread ends -- the main thread's
+// thread_local objects are destroyed at the start of exit(), before the HIP runtime's own teardown.
+constexpr int kSmallSlots = 16, kLargeSlots = 4;
+constexpr size_t kSmallBytes = 64 * 1024;
+template <int N>
 struct StageRing {
-    StageSlot slot[kStageSlots];
+    StageSlot slot[N];
     int next = 0;
-    // no destructor: a host thread's ring lives as long as the thread; at process exit the HIP runtime may already be gone
+    ~StageRing() {
+        for (StageSlot &q : slot) {
+            if (q.pending && q.ev) (void)hipEventSynchronize(q.ev);
+            if (q.ev) (void)hipEventDestroy(q.ev);
+            if (q.p) (void)hipHostFree(q.p);
+            q = StageSlot();
+        }
+    }
 };
-}  // namespace
 
-hipError_t upload_small(void *dst, const void *src, size_t bytes, hipStream_t s) {
-    if (bytes == 0) return hipSuccess;
-    static thread_local StageRing ring;
-    StageSlot &q = ring.slot[ring.next];
-    ring.next = (ring.next + 1) % kStageSlots;
+hipError_t stage(StageSlot &q, size_t granule, void *dst, const void *src, size_t bytes, hipStream_t s) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -58,7 +66,7 @@ hipError_t upload_small(void *dst, const void *src, size_t bytes, hipStream_t s)
         if (q.p) (void)hipHostFree(q.p);
         q.p = nullptr;
         q.cap = 0;
-        const size_t want = (bytes + 65535) / 65536 * 65536;
+        const size_t want = (bytes + granule - 1) / granule * granule;
         e = hipHostMalloc(&q.p, want, hipHostMallocDefault);
         if (e != hipSuccess) return e;
         q.cap = want;
@@ -69,6 +77,95 @@ hipError_t upload_small(void *dst, const void *src, size_t bytes, hipStream_t s)
     e = hipEventRecord(q.ev, s);
     if (e != hipSuccess) return e;
     q.pending = true;
+    return hipSuccess;
+}
+}  // namespace
+
+hipError_t upload_small(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    if (bytes <= kSmallBytes) {
+        static thread_local StageRing<kSmallSlots> ring;
+        StageSlot &q = ring.slot[ring.next];
+        ring.next = (ring.next + 1) % kSmallSlots;
+        return stage(q, kSmallBytes, dst, src, bytes, s);
+    }
+    static thread_local StageRing<kLargeSlots> big;
+    StageSlot &q = big.slot[big.next];
+    big.next = (big.next + 1) % kLargeSlots;
+    return stage(q, 1 << 20, dst, src, bytes, s);
+}
+
+PinnedList::~PinnedList() { release(); }
+
+void PinnedList::release() {
+    (void)wait();
+    for (int i = 0; i < 2; ++i) {
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+        ev[i] = nullptr;
+    }
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    dev = -1;
+}
+
+hipError_t PinnedList::wait() {
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2; ++i) {
+        if (pending[i] && ev[i]) {
+            const hipError_t r = hipEventSynchronize(ev[i]);
+            if (r != hipSuccess) e = r;
+        }
+        pending[i] = false;
+    }
+    return e;
+}
+
+hipError_t PinnedList::assign(const void *src, size_t n) {
+    hipError_t e = wait();                                 // copies out of the old contents may still be in flight
+    if (e != hipSuccess) return e;
+    if (cap < n) {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = (n + 65535) / 65536 * 65536;
+        e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        cap = want;
+    }
+    if (n) memcpy(p, src, n);
+    bytes = n;
+    return hipSuccess;
+}
+
+hipError_t PinnedList::upload(void *dst, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) return e;
+    if (dev != d) {                                        // events belong to a device
+        (void)wait();
+        for (int i = 0; i < 2; ++i) {
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            ev[i] = nullptr;
+        }
+        dev = d;
+    }
+    turn ^= 1;
+    if (pending[turn] && ev[turn]) {                       // the copy before last: long done; keeps the bookkeeping exact
+        e = hipEventSynchronize(ev[turn]);
+        if (e != hipSuccess) return e;
+        pending[turn] = false;
+    }
+    if (!ev[turn]) {
+        e = hipEventCreateWithFlags(&ev[turn], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    e = hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    e = hipEventRecord(ev[turn], s);
+    if (e != hipSuccess) return e;
+    pending[turn] = true;
     return hipSuccess;
 }
 

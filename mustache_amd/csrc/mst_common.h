@@ -42,4 +42,23 @@ inline hipError_t allow_dynamic_lds(const void *kernel, int bytes, unsigned long
 // only after the event recorded behind its copy has completed (normally long ago).
 hipError_t upload_small(void *dst, const void *src, size_t bytes, hipStream_t s);
 
+// A host list that is uploaded again and again unchanged (the work list of a launch, kept in a per-thread cache of recent
+// launches): ONE page-locked copy made when the list is built (assign), every launch copies straight out of it (upload: no host
+// memcpy, no staging slot), and the memory is released with its owner -- after the last copy out of it has completed.
+struct PinnedList {
+    void *p = nullptr;
+    size_t cap = 0, bytes = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};                 // behind the last two copies (callers alternate two streams)
+    int dev = -1, turn = 0;
+    bool pending[2] = {false, false};
+    PinnedList() = default;
+    PinnedList(const PinnedList &) = delete;
+    PinnedList &operator=(const PinnedList &) = delete;
+    ~PinnedList();
+    void release();
+    hipError_t wait();
+    hipError_t assign(const void *src, size_t n);          // waits for copies still reading the old contents
+    hipError_t upload(void *dst, hipStream_t s);
+};
+
 }  // namespace mst

@@ -880,6 +880,7 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
         std::vector<int64_t> key;
         std::vector<WorkItem> items;
         std::vector<int32_t> sop;
+        mst::PinnedList pin_items, pin_sop;      // page-locked copies the launches upload from (no host memcpy per launch)
     };
     static thread_local Cached cache[4];
     static thread_local unsigned cache_turn = 0;
@@ -906,17 +907,21 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
         }
         if (wide) build_items<TileWide>(st, B, CH, BAND ? src.dpx : 0, share, band_only, hit->items, hit->sop, nullptr);
         else build_items<TileDefault>(st, B, CH, BAND ? src.dpx : 0, share, band_only, hit->items, hit->sop, nullptr);
+        hipError_t pe = hit->pin_items.assign(hit->items.data(), sizeof(WorkItem) * hit->items.size());
+        if (pe == hipSuccess) pe = hit->pin_sop.assign(hit->sop.data(), sizeof(int32_t) * (size_t)B * npos);
+        if (pe != hipSuccess) {
+            hit->key.clear();
+            MST_HIP(pe);
+        }
     }
-    const std::vector<WorkItem> &items = hit->items;
-    const std::vector<int32_t> &sop = hit->sop;
-    const int n_items = (int)items.size();
+    const int n_items = (int)hit->items.size();
     if (n_items == 0) {          // no tile reaches the band: nothing is tested, nothing is found
         fill_stats_kernel<<<(B * MST_MAX_TESTED + 255) / 256, 256, 0, s>>>(level_stats, B * MST_MAX_TESTED);
         MST_LAUNCH_CHECK();
         return MST_OK;
     }
-    MST_HIP(mst::upload_small(d_items, items.data(), sizeof(WorkItem) * (size_t)n_items, s));
-    MST_HIP(mst::upload_small(d_sop, sop.data(), sizeof(int32_t) * (size_t)B * npos, s));
+    MST_HIP(hit->pin_items.upload(d_items, s));
+    MST_HIP(hit->pin_sop.upload(d_sop, s));
     if (fma)
         rc = launch_scale_space<TileDefaultFma, BAND>(c, nz, src, CH, d_lv, found, found_cap, found_count, partial, nt,
                                                       skip_empty, d_items, n_items, s);

@@ -173,7 +173,11 @@ def run_pair_genome(pipe, pairs, distance_in_px, st, pt, pt2):
     call_diff_loops_coo on each chromosome alone."""
     from .pipeline import GenomeLayout
     lay = GenomeLayout([n for _, n in pairs], distance_in_px)
-    gbands = [lay.band([d[s_] for d, _ in pairs], pipe.device) for s_ in (0, 1)]
+    # `pairs` is consumed: each sample's chromosome bands are released one by one as they are copied into that sample's
+    # genome band (the caller holds no other reference), so the peak is the genome bands + the bands not yet copied
+    per_sample = [[d[s_] for d, _ in pairs] for s_ in (0, 1)]
+    del pairs[:]
+    gbands = [lay.band(per_sample[s_], pipe.device, consume=True) for s_ in (0, 1)]
     return run_pair_layout(pipe, lay, gbands, st, pt, pt2)
 
 
@@ -416,14 +420,17 @@ def main(argv=None):
     # collected in HBM and the block pairs of ALL chromosomes go through the same launches (run_pair_genome); the reference
     # runs chromosome after chromosome (diff_mustache.py:858-906).  Same rows, in the same chromosome order.
     batched = len(mine) > 1
-    genome_budget = int(os.environ.get("MUSTACHE_GENOME_BATCH_GB", "64")) << 30
+    genome_budget = None                 # bytes of held bands (both samples); pipeline.genome_batch_budget at the first band
     held, held_bytes, pipe = [], 0, None
 
     def flush():
         nonlocal held, held_bytes
         if held:
-            rows = run_pair_genome(pipe, [(h[1], h[2]) for h in held], held[0][3], args.st, args.pt, args.pt2)
-            for (i, _, _, _), o in zip(held, rows):
+            idx, dpx_h = [h[0] for h in held], held[0][3]
+            prs = [(list(h[1]), h[2]) for h in held]
+            held, held_bytes = [], 0             # `prs` holds the only references: run_pair_genome releases them as it copies
+            rows = run_pair_genome(pipe, prs, dpx_h, args.st, args.pt, args.pt2)
+            for i, o in zip(idx, rows):
                 emit(i, o)
         held, held_bytes = [], 0
 
@@ -450,8 +457,17 @@ def main(argv=None):
             print("Normalizing contact map...")
         dbands, n = normalized_pair_bands(pipe, coo1, coo2, res_c, dpx)
         nbytes = sum(b.numel() * 8 for b in dbands)
+        if genome_budget is None:
+            from .pipeline import genome_batch_budget
+            genome_budget = genome_batch_budget(pipe.device)
         if held and (held[0][3] != dpx or held_bytes + nbytes > genome_budget):
             flush()
+        if nbytes > genome_budget:               # this chromosome alone is over the budget: run it by itself, no second copy
+            flush()
+            alone = [(list(dbands), n)]
+            del dbands
+            emit(i, run_pair_genome(pipe, alone, dpx, args.st, args.pt, args.pt2)[0])
+            continue
         held.append((i, dbands, n, dpx))
         held_bytes += nbytes
     flush()

@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
+MST_IO_ABI_VERSION = 2          # include/mustache_io.h
 
 
 class HicError(RuntimeError):
@@ -42,6 +43,10 @@ _SIGNATURES = {
     "mst_hic_decode_intra_packed": (ctypes.c_int64, [_P, ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64,
                                                      ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]),
     "mst_hic_fetch_packed": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64, ctypes.c_int32]),
+    "mst_hic_decode_intra_packed_part": (ctypes.c_int64, [_P, ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p,
+                                                          ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                                          ctypes.c_int32, ctypes.POINTER(ctypes.c_int64),
+                                                          ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "mst_text_read_contacts": (ctypes.c_int64, [ctypes.c_char_p, ctypes.c_char, ctypes.c_char_p, ctypes.c_int32,
                                                 ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_P), ctypes.POINTER(_P),
                                                 ctypes.POINTER(_P)]),
@@ -59,6 +64,9 @@ def load():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        if lib.mst_io_abi_version() != MST_IO_ABI_VERSION:
+            raise RuntimeError("libmustache_io.so ABI %d != %d expected (%s): rebuild with `make -C mustache_amd/csrc`"
+                               % (lib.mst_io_abi_version(), MST_IO_ABI_VERSION, path))
         _lib = lib
     return _lib
 
@@ -138,9 +146,15 @@ class PackedContacts:
     `pinned`: the three torch tensors (page-locked host memory) the arrays are views of, when the caller's allocator
     provided such -- the upload then runs at the full PCIe rate; None for plain NumPy arrays."""
 
-    def __init__(self, x, dist, v, n, res, pinned=None):
+    def __init__(self, x, dist, v, n, res, pinned=None, part=0, n_parts=1, blocks_total=None, blocks_mine=None):
         self.x, self.dist, self.v = x, dist, v
         self.count, self.n, self.res, self.pinned = int(len(v)), int(n), int(res), pinned
+        # n_parts > 1: this object holds only the records of part `part` of the chromosome's `.hic` blocks (one process per
+        # GPU, each rank decodes its share: read_intra_packed(part=...)); `n` is then this part's max(binY) + 1 and the
+        # device loader (normalize.band_from_packed) exchanges the parts between the ranks before it scatters
+        self.part, self.n_parts = int(part), int(n_parts)
+        self.blocks_total, self.blocks_mine = blocks_total, blocks_mine
+        self.read_s = None
 
     def __len__(self):
         return self.count
@@ -151,14 +165,22 @@ class PackedContacts:
         return x, x + self.dist.astype(np.int64), self.v.astype(np.float64)
 
 
-def read_intra_packed(hic, chrom, resolution, norm="KR", max_dist_bins=-1, chrom_size_bp=0, threads=0, alloc=None):
+def read_intra_packed(hic, chrom, resolution, norm="KR", max_dist_bins=-1, chrom_size_bp=0, threads=0, alloc=None,
+                      part=(0, 1)):
     """HicFile -> PackedContacts: mst_hic_decode_intra_packed (records stay in the handle's per-thread arenas) +
     mst_hic_fetch_packed into arrays from `alloc(count)` -> (x int32, dist int32, v float32, keepalive) -- NumPy arrays by
-    default; mustache_amd.normalize.pinned_packed_alloc hands out views of page-locked torch tensors."""
+    default; mustache_amd.normalize.pinned_packed_alloc hands out views of page-locked torch tensors.
+    part = (p, n): decode only share p of n of the chromosome's blocks (one process per GPU: the ranks read the file once
+    between them and exchange the records afterwards)."""
+    import time
+    t0 = time.time()
     nb = ctypes.c_int64()
-    n = _check(hic._lib, hic._lib.mst_hic_decode_intra_packed(hic._h, str(chrom).encode(), int(resolution),
-                                                              str(norm).encode(), int(max_dist_bins), int(chrom_size_bp),
-                                                              int(threads), ctypes.byref(nb)))
+    bt, bm = ctypes.c_int32(), ctypes.c_int32()
+    n = _check(hic._lib, hic._lib.mst_hic_decode_intra_packed_part(hic._h, str(chrom).encode(), int(resolution),
+                                                                   str(norm).encode(), int(max_dist_bins),
+                                                                   int(chrom_size_bp), int(threads), int(part[0]),
+                                                                   int(part[1]), ctypes.byref(nb), ctypes.byref(bt),
+                                                                   ctypes.byref(bm)))
     if alloc is None:
         x, d, v, keep = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.float32), None
     else:
@@ -166,7 +188,10 @@ def read_intra_packed(hic, chrom, resolution, norm="KR", max_dist_bins=-1, chrom
     if n:
         _check(hic._lib, hic._lib.mst_hic_fetch_packed(hic._h, x.ctypes.data_as(_P), d.ctypes.data_as(_P),
                                                        v.ctypes.data_as(_P), int(n), int(threads)))
-    return PackedContacts(x, d, v, nb.value, resolution, pinned=keep)
+    pc = PackedContacts(x, d, v, nb.value, resolution, pinned=keep, part=part[0], n_parts=part[1], blocks_total=bt.value,
+                        blocks_mine=bm.value)
+    pc.read_s = time.time() - t0
+    return pc
 
 
 def read_text_contacts(path, sep, chromosome=None, threads=0):

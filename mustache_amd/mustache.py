@@ -247,7 +247,7 @@ def _check_pair(f, chromosome, chromosome2):
 
 
 def read_contacts(f, norm_method, CHRM_SIZE, res, distance_filter, bias, chromosome, chromosome2, verbose=True,
-                  packed=False):
+                  packed=False, part=(0, 1)):
     """The reading half of regulator() (reference mustache.py:866-889): host I/O only, so main() can fetch the next
     chromosome while the GPU works on the current one.  Returns (x, y, v, res) or None when nothing was read.
     packed=True: a `.hic` file read by the native reader comes back as hicfile.PackedContacts (12 bytes per record, what
@@ -259,7 +259,8 @@ def read_contacts(f, norm_method, CHRM_SIZE, res, distance_filter, bias, chromos
     if f.endswith(".hic") and packed:
         from .readers import hic_backend, read_hic_packed
         if hic_backend() == "native":
-            return read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chromosome, res)
+            # part = (rank, ranks): several GPUs on ONE chromosome -- each rank inflates its share of the blocks only
+            return read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chromosome, res, part=part)
     if f.endswith(".hic"):
         from .readers import read_hic_file
         x, y, v = read_hic_file(f, norm_method, CHRM_SIZE, distance_in_bp, chromosome, chromosome2, res)
@@ -429,7 +430,7 @@ def main(argv=None):
         CHRM_SIZE = chrSize_in_bp["chr" + str(chromosome).replace('chr', '')] if chrSize_in_bp else False
         try:
             return read_contacts(f, args.norm_method, CHRM_SIZE, res, distFilter, biasf, chromosome, chromosome2,
-                                 verbose=args.verbose, packed=True)
+                                 verbose=args.verbose, packed=True, part=(0, 1) if by_chromosome else (rank, _world))
         except BaseException as e:          # re-raised in the main thread, at this chromosome's turn
             return e
 
@@ -466,15 +467,17 @@ def main(argv=None):
     # blocks go through one sequence of launches (pipeline.run_genome) -- same loops as chromosome by chromosome, without
     # the launch-bound tail of 5-31 blocks per chromosome.  `genome_budget` bounds the bands held at once.
     batched = len(mine) > 1 and (_world == 1 or by_chromosome)
-    genome_budget = int(os.environ.get("MUSTACHE_GENOME_BATCH_GB", "64")) << 30
+    genome_budget = None                 # bytes; from the device's free memory at the first band (pipeline.genome_batch_budget)
     held, held_bytes, pipe = [], 0, None
 
     def flush():
         nonlocal held, held_bytes
         if held:
             dpx = held[0][3]
-            loops = pipe.run_genome([h[1] for h in held], [h[2] for h in held], dpx, args.st, args.pt)
-            for (i, _, _, _), o in zip(held, loops):
+            idx, bands, ns = [h[0] for h in held], [h[1] for h in held], [h[2] for h in held]
+            held, held_bytes = [], 0             # `bands` is now the only reference: run_genome releases them as it copies
+            loops = pipe.run_genome(bands, ns, dpx, args.st, args.pt)
+            for i, o in zip(idx, loops):
                 emit(i, o)
         held, held_bytes = [], 0
 
@@ -506,8 +509,18 @@ def main(argv=None):
                 else:
                     band, n = pipe.normalized_band(contacts[0], contacts[1], contacts[2], res_c, dpx)
                 del contacts
+                if genome_budget is None:
+                    from .pipeline import genome_batch_budget
+                    genome_budget = genome_batch_budget(pipe.device)
                 if held and (held[0][3] != dpx or held_bytes + band.numel() * 8 > genome_budget):
                     flush()
+                if band.numel() * 8 > genome_budget:
+                    # one chromosome alone is over the budget (a second copy of its band would not fit beside it): the
+                    # per-chromosome form, which runs straight from this band
+                    flush()
+                    emit(i, pipe.run_band(band, n, dpx, args.st, args.pt, distributed=False))
+                    del band
+                    continue
                 held.append((i, band, n, dpx))
                 held_bytes += band.numel() * 8
                 continue

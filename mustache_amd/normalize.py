@@ -57,19 +57,49 @@ def pinned_packed_alloc(count):
     return ts[0].numpy(), ts[1].numpy(), ts[2].numpy(), ts
 
 
-def band_from_packed(pc, dpx, device):
+def band_from_packed(pc, dpx, device, check=None):
     """hicfile.PackedContacts -> raw band [dpx+2, n] on `device`: three uploads of 4 bytes per record each (from page-locked
-    memory when the records were read into it) and one scatter (mst_band_from_packed).  A `.hic` matrix holds every pixel
-    once, so there is no repeated-pixel check here (band_from_host_coo has one for free-form text input)."""
+    memory when the records were read into it) and one scatter (mst_band_scatter_packed).  With one process per GPU
+    (pc.n_parts > 1: this rank decoded only its share of the `.hic` blocks) the ranks exchange their records first
+    (sharding.all_gather_packed) and every rank scatters all shares -- the band is the same on every rank and the same as in
+    a 1-rank run, bit for bit (a matrix holds every pixel once, so the order of the scatters is immaterial).
+    `check` (default: the environment variable MUSTACHE_CHECK_PACKED): read every record back from the band afterwards; a
+    mismatch means two records with different values share a pixel -- a malformed file; the reference's scatter keeps the
+    last one (mustache.py:921-924) -- and the band is rebuilt through band_from_host_coo, which applies that rule
+    deterministically, with a warning."""
+    import os
     lib = require_gpu()
-    n = int(pc.n)
-    if pc.pinned is not None:
-        xd, dd, vd = (t.to(device, non_blocking=True) for t in pc.pinned)
+    if check is None:
+        check = bool(os.environ.get("MUSTACHE_CHECK_PACKED"))
+    if getattr(pc, "n_parts", 1) > 1:
+        from .sharding import all_gather_packed
+        parts, n = all_gather_packed(pc.x, pc.dist, pc.v, pc.n, device)
+        pc.n_all = n
     else:
-        xd, dd, vd = (torch.from_numpy(a).to(device) for a in (pc.x, pc.dist, pc.v))
-    band = torch.empty((dpx + 2, n), dtype=torch.float64, device=device)
+        n = int(pc.n)
+        if pc.pinned is not None:
+            xd, dd, vd = (t.to(device, non_blocking=True) for t in pc.pinned)
+        else:
+            xd, dd, vd = (torch.from_numpy(a).to(device) for a in (pc.x, pc.dist, pc.v))
+        parts = [(xd, dd, vd, int(pc.count))]
+    band = torch.zeros((dpx + 2, n), dtype=torch.float64, device=device)
     with torch.cuda.device(device):
-        _lib.check(lib.mst_band_from_packed(_ptr(xd), _ptr(dd), _ptr(vd), int(pc.count), n, int(dpx), _ptr(band), _stream()))
+        for xd, dd, vd, cnt in parts:
+            if cnt:
+                _lib.check(lib.mst_band_scatter_packed(_ptr(xd), _ptr(dd), dd.element_size(), _ptr(vd), cnt, n, int(dpx),
+                                                       _ptr(band), _stream()))
+        if check:
+            bad = torch.zeros(1, dtype=torch.int64, device=device)
+            for xd, dd, vd, cnt in parts:
+                if cnt:
+                    _lib.check(lib.mst_band_verify_packed(_ptr(xd), _ptr(dd), dd.element_size(), _ptr(vd), cnt, n, int(dpx),
+                                                          _ptr(band), _ptr(bad), _stream()))
+            if int(bad.item()):
+                xs = np.concatenate([p[0][:p[3]].cpu().numpy().astype(np.int64) for p in parts])
+                ds = np.concatenate([p[1][:p[3]].cpu().numpy().astype(np.int64) for p in parts])
+                vs = np.concatenate([p[2][:p[3]].cpu().numpy().astype(np.float64) for p in parts])
+                del band
+                return band_from_host_coo(xs, xs + ds, vs, n, dpx, device)
     return band
 
 

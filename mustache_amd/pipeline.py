@@ -49,12 +49,31 @@ class GenomeLayout:
         # global block list in chromosome order: (chromosome, block index, local start, global start)
         self.blocks = [(c, i, t[1][i], self.off[c] + t[1][i]) for c, t in enumerate(self.tiling) for i in range(len(t[1]))]
 
-    def band(self, bands, device):
-        """bands[c]: [dpx + 2, n_c] normalised band of chromosome c (device) -> the [dpx + 2, N] genome band."""
+    def band(self, bands, device, consume=False):
+        """bands[c]: [dpx + 2, n_c] normalised band of chromosome c (device) -> the [dpx + 2, N] genome band.
+        consume=True: bands[c] is set to None as soon as it has been copied, so that (when the caller holds no other
+        reference) the chromosome bands are released one by one while the genome band fills -- the peak is the genome
+        band + the bands not yet copied, not twice the genome."""
         g = torch.zeros((self.dpx + 2, self.N), dtype=torch.float64, device=device)
-        for b, n, off in zip(bands, self.ns, self.off):
-            g[:, off:off + n] = b.view(self.dpx + 2, -1)[:, :n]
+        for c, (n, off) in enumerate(zip(self.ns, self.off)):
+            g[:, off:off + n] = bands[c].view(self.dpx + 2, -1)[:, :n]
+            if consume:
+                bands[c] = None
         return g
+
+
+def genome_batch_budget(device=None):
+    """Bytes of normalised chromosome bands a whole-genome run may hold before it flushes them through run_genome.
+    MUSTACHE_GENOME_BATCH_GB, when set, is taken as is; otherwise 35 % of the device memory that is free right now, capped
+    at 64 GiB: at a flush the genome band (as large as the held bands together) is allocated while the held bands are
+    released one by one (GenomeLayout.band(consume=True)), on top of the found-record buffers and workspaces of the launches
+    and the reader's next chromosome being normalised (two more bands) -- 2 x 35 % leaves room for those on any device."""
+    import os
+    env = os.environ.get("MUSTACHE_GENOME_BATCH_GB")
+    if env:
+        return int(float(env) * (1 << 30))
+    free, _total = torch.cuda.mem_get_info(device)
+    return int(min(64 << 30, 0.35 * free))
 
 
 class ChromosomePipeline:
@@ -145,7 +164,9 @@ class ChromosomePipeline:
         download and host tail of one group under the kernel of the next.  Returns the list of loops per chromosome
         (chromosome coordinates), identical to run_band on each chromosome alone."""
         lay = GenomeLayout(ns, dpx)
-        return self.run_layout(lay, lay.band(bands, self.device), st, pt, skip_empty=skip_empty, timings=timings)
+        # `bands` is consumed (entries set to None as they are copied): a caller that drops its own references beforehand
+        # keeps the peak at the genome band + the bands not yet copied
+        return self.run_layout(lay, lay.band(bands, self.device, consume=True), st, pt, skip_empty=skip_empty, timings=timings)
 
     def run_layout(self, lay, gband, st, pt, skip_empty=True, timings=None):
         """run_genome's body on a prepared layout + genome band."""
@@ -178,10 +199,11 @@ class ChromosomePipeline:
     def normalized_band_packed(self, pc, dpx, normalized=False):
         """hicfile.PackedContacts of one chromosome -> (normalised band on the device, n)."""
         from .normalize import band_from_packed
-        band = band_from_packed(pc, dpx, self.device)
-        if not normalized:
-            band, _, _ = normalize_band(band, pc.n, dpx, pc.res)
-        return band, int(pc.n)
+        band = band_from_packed(pc, dpx, self.device)       # pc.n_parts > 1: the ranks exchange their shares in here
+        n = int(band.shape[1])                              # = max(binY) + 1 over ALL shares (mustache.py:894)
+        if not normalized and n > 0:
+            band, _, _ = normalize_band(band, n, dpx, pc.res)
+        return band, n
 
     def run_packed(self, pc, dpx, st, pt, verbose=False, skip_empty=True, distributed=True, timings=None):
         """run() for the native `.hic` reader's packed records."""
@@ -191,6 +213,9 @@ class ChromosomePipeline:
         band, n = self.normalized_band_packed(pc, dpx)
         torch.cuda.synchronize(self.device)
         t1 = time.time()
+        if n == 0:                                          # no rank read a record (every rank sees the same n)
+            print('There is no contact in this chromosome to work on.')
+            return []
         if verbose:
             print("Loop calling...")
         loops = self.run_band(band, n, dpx, st, pt, skip_empty=skip_empty, distributed=distributed, timings=timings)

@@ -11,8 +11,10 @@ Where the reference de-duplicates with Python set differences between consecutiv
 the (x, y) key with NumPy (same set of records; the reference's output order is set-iteration order and is not
 reproduced -- nothing downstream depends on it here).
 """
+import atexit
 import importlib
 import os
+import threading
 
 import numpy as np
 
@@ -136,6 +138,7 @@ def read_hic_file(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, chr2, res):
     return _finish(x, y, v, distance_in_bp, res, chr1 == chr2, chr1)
 
 
+_HIC_LOCK = threading.RLock()
 _HIC_HANDLE = [None, None]           # (path, HicFile): the packed reader's arenas live in the handle -- keep the last one open
 
 
@@ -149,10 +152,24 @@ def _hic_handle(f):
     return _HIC_HANDLE[1]
 
 
-def read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, res):
+def close_hic_handle():
+    """Release the cached `.hic` handle (its mmap and the per-thread arenas sized to the largest chromosome read)."""
+    with _HIC_LOCK:
+        if _HIC_HANDLE[1] is not None:
+            _HIC_HANDLE[1].close()
+        _HIC_HANDLE[0], _HIC_HANDLE[1] = None, None
+
+
+atexit.register(close_hic_handle)
+
+
+def read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, res, part=(0, 1)):
     """read_hic_file's records for an intra-chromosomal run as hicfile.PackedContacts (int32 bin, int32 distance, float32
-    value: what the GPU loader mst_band_from_packed takes) -- same record set as read_hic_file through the native reader,
-    without the int64 / float64 COO triple; None when the chromosome has no contact.  Native backend only."""
+    value: what the GPU loader mst_band_scatter_packed takes) -- same record set as read_hic_file through the native reader,
+    without the int64 / float64 COO triple; None when the chromosome has no contact.  Native backend only.
+    part = (rank, ranks): one process per GPU on ONE chromosome -- this rank decodes only its share of the file's blocks
+    (the ranks read the file once between them; normalize.band_from_packed exchanges the shares).  A share may be empty;
+    it is still returned, so that every rank takes part in the exchange."""
     from .hicfile import read_intra_packed
     norm = "KR" if not norm_method else str(norm_method)
     alloc = None
@@ -162,8 +179,8 @@ def read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, res):
             from .normalize import pinned_packed_alloc as alloc
     except ImportError:
         pass
-    h = _hic_handle(f)
-    if True:
+    with _HIC_LOCK:                       # decode + fetch use the handle's arenas: one reader at a time per process
+        h = _hic_handle(f)
         if not CHRM_SIZE:
             sizes = {"chr" + name.replace("chr", ''): length for name, length in h.chromosomes()[1:]}
             key = "chr" + str(chr1).replace("chr", '')
@@ -172,7 +189,11 @@ def read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, res):
             CHRM_SIZE = sizes[key]
         print("reading %s through the native .hic reader, packed records (MUSTACHE_HIC_BACKEND=auto|native|hicstraw)"
               % os.path.basename(str(f)))
-        pc = read_intra_packed(h, chr1, res, norm, int(distance_in_bp // res), int(CHRM_SIZE), alloc=alloc)
+        pc = read_intra_packed(h, chr1, res, norm, int(distance_in_bp // res), int(CHRM_SIZE), alloc=alloc, part=part)
+    if part[1] > 1:
+        print("rank %d of %d decoded %d of the chromosome's %d .hic blocks (%d records) in %.3f s"
+              % (part[0], part[1], pc.blocks_mine, pc.blocks_total, len(pc), pc.read_s), flush=True)
+        return pc
     if len(pc) == 0:
         print(f'There is no contact in chrmosome {chr1} to work on.')
         return None

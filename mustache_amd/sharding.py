@@ -57,6 +57,47 @@ def gather_records(rec, device=None, group=None, force=False):
     return [parts[r][:counts[r]].cpu().numpy() for r in range(ws)]
 
 
+def all_gather_packed(x, dist_, v, n, device, group=None):
+    """One process per GPU, each rank holds the packed records of ITS share of a chromosome's `.hic` blocks (host arrays:
+    x int32, dist_ int32 or uint16, v float32; `n` = its max(binY) + 1): every rank receives all shares.  Returns
+    (parts, n_all): parts[r] = (x, dist, v, count) device tensors of rank r's records, n_all = max over the ranks.
+    Two collectives: all_gather of (count, n), then all_gather of the padded [bytes] record block -- over RCCL / xGMI from
+    device memory with backend nccl (each rank uploads only its own share across PCIe), over gloo from host memory in the
+    CPU tests.  The record SET every rank ends up with is the same, so the band, its normalisation and everything
+    downstream are identical on every rank and identical to the 1-rank run."""
+    import numpy as np
+    rank, ws = world()
+    on_dev = dist.get_backend(group) == "nccl"
+    where = device if on_dev else "cpu"
+    cnt = int(len(v))
+    meta = torch.tensor([cnt, int(n)], dtype=torch.int64, device=where)
+    metas = [torch.zeros_like(meta) for _ in range(ws)]
+    dist.all_gather(metas, meta, group=group)
+    counts = [int(m[0].item()) for m in metas]
+    n_all = max(int(m[1].item()) for m in metas)
+    dbytes = np.dtype(dist_.dtype).itemsize
+    mx = max(max(counts), 1)
+    seg = [(-(-4 * mx // 16) * 16), (-(-dbytes * mx // 16) * 16), (-(-4 * mx // 16) * 16)]     # 16-byte aligned segments
+    block = torch.zeros(sum(seg), dtype=torch.uint8, device=where)
+    off = 0
+    for arr, sz in zip((x, dist_, v), seg):
+        if cnt:
+            src = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1))
+            block[off:off + src.numel()].copy_(src, non_blocking=on_dev)
+        off += sz
+    got = [torch.empty_like(block) for _ in range(ws)]
+    dist.all_gather(got, block, group=group)
+    parts = []
+    ddt = torch.int32 if dbytes == 4 else torch.uint16
+    for r in range(ws):
+        g = got[r] if on_dev else got[r].to(device)
+        xs = g[0:seg[0]].view(torch.int32)[:counts[r]]
+        ds = g[seg[0]:seg[0] + seg[1]].view(ddt)[:counts[r]]
+        vs = g[seg[0] + seg[1]:].view(torch.float32)[:counts[r]]
+        parts.append((xs, ds, vs, counts[r]))
+    return parts, n_all
+
+
 def gather_loops(loops, device=None, group=None):
     """All ranks pass their list of [x, y, fdr, sigma]; every rank gets the concatenation in rank order
     (rank 0 writes the TSV).  Two collectives: all_gather of the counts, all_gather of the padded records."""

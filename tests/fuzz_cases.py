@@ -1,0 +1,204 @@
+"""Randomised parity cases shared by the GPU test slice (tests/test_gpu_fuzz.py, seeded, a few minutes) and the long sweeps
+(scripts/fuzz_*.py, any seed / case count).  TEST INFRASTRUCTURE: every case runs the HIP path through the package and checks
+it against the CPU oracle (oracle/), which only tests, smoke() and bench.py's CPU leg may import.
+
+Each *_case(rng, ...) draws one case from `rng`, runs it and returns (ok, n_loops, description); ok = coordinates, scales
+(and for the block case the complete found set, DoG values, levels, `loc`) identical to the oracle, p / q within the stated
+tolerance."""
+import numpy as np
+
+OCT = [1.6, 3.2]
+
+
+def _same_loops(got, exp, qtol=1e-6):
+    got = sorted(got, key=lambda r: (int(r[0]), int(r[1])))
+    exp = sorted(exp, key=lambda r: (int(r[0]), int(r[1])))
+    same = [(int(a), int(b), s) for a, b, _, s in got] == [(int(a), int(b), s) for a, b, _, s in exp]
+    qerr = max([abs(g[2] - e[2]) / max(e[2], 1e-300) for g, e in zip(got, exp)], default=0.0) if same else float("nan")
+    return bool(same and qerr <= qtol), qerr
+
+
+def parity_case(rng, eng):
+    """One random dense block (edge 90-760, distance limit 30-420, dense to very sparse, sometimes with rectangular
+    unmappable holes): found set / values / levels / loc identical, p 1e-9, with and without empty-tile skipping; then the
+    whole block through the drop-in mustache() against the oracle's tail."""
+    import torch
+    import oracle
+    from mustache_amd.mustache import mustache
+    from mustache_amd.synth import synth_coo
+    n = int(rng.integers(90, 760))
+    dpx = int(rng.integers(30, max(31, min(n - 10, 420))))
+    depth = float(rng.choice([0.8, 2.0, 8.0, 40.0, 300.0]))
+    seed = int(rng.integers(0, 10 ** 6))
+    hole = rng.random() < 0.3
+    a, b = sorted(rng.integers(0, n, 2))
+    st, pt = float(rng.choice([0.5, 0.7, 0.88])), float(rng.choice([0.05, 0.2, 0.5]))
+    desc = dict(kind="block", n=n, dpx=dpx, depth=depth, seed=seed, hole=bool(hole), st=st, pt=pt)
+    x, y, v = synth_coo(n, dpx, depth=depth, seed=seed, nloops=max(n // 20, 1))
+    if len(v) < 100:
+        return True, 0, dict(desc, skipped="fewer than 100 contacts")
+    oracle.normalize_sparse(x, y, v, 50000, dpx)
+    c = np.zeros((n, n))
+    c[x, y] = v
+    if hole:
+        c[a:b, :] = 0
+        c[:, a:b] = 0
+    ref = c.copy()
+    nz = oracle.block_prologue(ref, dpx)
+    if nz.sum() < 50:
+        return True, 0, dict(desc, skipped="fewer than 50 tested pixels")
+    ss = oracle.scale_space_levels(ref, nz, OCT, blur="scipy")
+    f = ss.pval != 2
+    dev = torch.from_numpy(c.copy()).cuda().unsqueeze(0)
+    nzd, cnt = eng.prologue(dev, dpx, True)
+    ok = True
+    for skip in (True, False):
+        found, fits = eng.sigma_loop(dev, nzd, cnt, skip_empty=skip)
+        r = found[0]
+        ok = ok and (np.array_equal(r["pixel"].astype(np.int64), np.flatnonzero(nz.ravel())[f]) and
+                     np.array_equal(r["value"], ss.best[f]) and np.array_equal(r["level"].astype(np.int64), ss.level[f]) and
+                     np.allclose(r["pval"], ss.pval[f], rtol=1e-9, atol=0, equal_nan=True) and
+                     np.array_equal(fits[0][0], np.array([t["loc"] for t in ss.tested])))
+    exp = oracle.mustache_block(c.copy(), 17, dpx, OCT, st, pt)
+    got = mustache(c.copy(), "1", "1", 5000, [], 17, n + 17, 0, dpx, OCT, st, pt)
+    tail_ok = ([(int(a_), int(b_), s_) for a_, b_, _, s_ in got] == [(int(a_), int(b_), s_) for a_, b_, _, s_ in exp] and
+               np.allclose([q for _, _, q, _ in got], [q for _, _, q, _ in exp], rtol=1e-9))
+    return bool(ok and tail_ok), len(exp), dict(desc, found=int(f.sum()), found_ok=bool(ok), tail_ok=bool(tail_ok))
+
+
+def pipeline_case(rng, pipe, max_n=5200, share_modes=(True,), wide=False):
+    """One random chromosome through the whole GPU pipeline (COO -> band -> normalisation -> band-direct fused kernel -> device
+    BH / selection -> batched tail -> overlap masks) against the oracle's regulator restatement.  share_modes: the values of
+    engine.share_tiles to run (tiles of overlapping blocks computed once / every tile once per block) -- the oracle runs once.
+    wide=True draws a distance limit of 1000-1300 px, where consecutive blocks overlap by half their edge and most tiles are
+    shared (the 1 kb geometry of BASELINE config 4 in small)."""
+    import oracle
+    from mustache_amd.synth import synth_coo
+    if wide:
+        dpx = int(rng.integers(1000, 1300))
+        n = int(rng.integers(3 * dpx, 3 * dpx + 900))
+    else:
+        dpx = int(rng.integers(60, 420))
+        n = int(rng.integers(max(2 * dpx, 500), max_n))
+    res = int(rng.choice([1000, 2000, 5000, 10000, 25000]))
+    depth = float(rng.choice([5.0, 40.0, 300.0]))
+    st, pt = float(rng.choice([0.5, 0.7, 0.88])), float(rng.choice([0.05, 0.1, 0.3]))
+    seed = int(rng.integers(0, 10 ** 6))
+    x, y, v = synth_coo(n, dpx, depth=depth, seed=seed, nloops=max(n // 25, 4))
+    exp = oracle.regulator_coo(x, y, v.copy(), res, dpx, OCT, st, pt)
+    ok, qerr, counts = True, 0.0, []
+    keep = pipe.engine.share_tiles
+    try:
+        for share in share_modes:
+            pipe.engine.share_tiles = share
+            got = pipe.run(x, y, v.copy(), res, dpx, st, pt, distributed=False)
+            s, q = _same_loops(got, exp)
+            ok, qerr = ok and s, max(qerr, q if s else float("inf"))
+            counts.append(len(got))
+    finally:
+        pipe.engine.share_tiles = keep
+    return ok, len(exp), dict(kind="chromosome", n=n, dpx=dpx, res=res, depth=depth, st=st, pt=pt, seed=seed,
+                              branch="A" if (n - dpx) * res > 2e6 else "B", got=counts, exp=len(exp), qerr=qerr,
+                              share_modes=list(share_modes))
+
+
+def genome_case(rng, pipe, max_n=5200, max_chroms=5):
+    """A random set of 2-max_chroms chromosomes (from shorter than one block up) through run_genome -- side by side in one
+    band, a random number of blocks per launch so that blocks of several chromosomes share launches -- against the oracle's
+    regulator restatement per chromosome."""
+    import oracle
+    from mustache_amd.synth import synth_coo
+    dpx = int(rng.integers(60, 420))
+    res = int(rng.choice([1000, 2000, 5000, 10000]))
+    st, pt = float(rng.choice([0.5, 0.7, 0.88])), float(rng.choice([0.05, 0.1, 0.3]))
+    per = int(rng.integers(1, 9))
+    k = int(rng.integers(2, max_chroms + 1))
+    coos = []
+    for c in range(k):
+        n = int(rng.integers(max(dpx + 50, 300), max_n))
+        depth = float(rng.choice([5.0, 40.0, 300.0]))
+        coos.append(synth_coo(n, dpx, depth=depth, seed=int(rng.integers(0, 10 ** 6)), nloops=max(n // 25, 4)))
+    keep = pipe.__dict__.get("blocks_per_launch")
+    pipe.blocks_per_launch = lambda CH, k_=per: k_
+    try:
+        bands, ns = zip(*[pipe.normalized_band(x, y, v.copy(), res, dpx) for x, y, v in coos])
+        got_all = pipe.run_genome(list(bands), list(ns), dpx, st, pt)
+    finally:
+        if keep is None:
+            pipe.__dict__.pop("blocks_per_launch", None)
+        else:
+            pipe.blocks_per_launch = keep
+    ok, total, bad = True, 0, []
+    for c, ((x, y, v), got) in enumerate(zip(coos, got_all)):
+        exp = oracle.regulator_coo(x, y, v.copy(), res, dpx, OCT, st, pt)
+        s, q = _same_loops(got, exp)
+        total += len(exp)
+        if not s:
+            ok = False
+            bad.append(dict(chromosome=c, n=ns[c], got=len(got), exp=len(exp), qerr=q))
+    return ok, total, dict(kind="genome", chromosomes=k, ns=list(ns), dpx=dpx, res=res, st=st, pt=pt, blocks_per_launch=per,
+                           bad=bad)
+
+
+def diff_case(rng, eng):
+    """One random block pair through the two-sample path: the band-direct route in both forms (selected records only + device
+    look-ups = what the driver runs; whole found sets) and the dense drop-in diff_mustache(), against the oracle's
+    restatement of the reference's diff_mustache(): the four loop lists identical in coordinates and scales, q within 1e-6."""
+    import torch
+    import oracle
+    from mustache_amd.diff_mustache import _pair_tail, diff_mustache
+    from mustache_amd.normalize import band_from_coo
+    from mustache_amd.synth import synth_coo
+
+    def key(lists):
+        return [[(int(a), int(b), float(s)) for a, b, _, s in l] for l in lists]
+
+    n = int(rng.integers(260, 900))
+    dpx = int(rng.integers(60, max(61, min(n - 20, 300))))
+    start = int(rng.integers(0, 5000))
+    st, pt, pt2 = float(rng.choice([0.5, 0.7, 0.88])), float(rng.choice([0.1, 0.3])), float(rng.choice([0.1, 0.3]))
+    cs = []
+    for s in range(2):
+        x, y, v = synth_coo(n, dpx, depth=float(rng.choice([40.0, 150.0, 300.0])), seed=int(rng.integers(0, 10 ** 6)),
+                            nloops=max(n // 15, 2))
+        oracle.normalize_sparse(x, y, v, 50000, dpx)
+        c = np.zeros((n, n))
+        c[x, y] = v
+        cs.append(c)
+    exp = oracle.diff_block(cs[0].copy(), cs[1].copy(), start, dpx, OCT, st, pt, pt2)
+    bands = []
+    for c in cs:
+        xx, yy = np.nonzero(np.triu(c))
+        bands.append(band_from_coo(torch.from_numpy(xx).cuda(), torch.from_numpy(yy).cuda(), torch.from_numpy(c[xx, yy]).cuda(),
+                                   n, dpx))
+    batch = eng.run_band_pairs(bands, n, dpx, [0], n, select_below=pt)
+    got_band = _pair_tail(batch, 0, 1, start, pt, pt2, st, True)
+    full = _pair_tail(eng.run_band_pairs(bands, n, dpx, [0], n), 0, 1, start, pt, pt2, st, True)
+    forms_agree = [[tuple(l) for l in ls] for ls in full] == [[tuple(l) for l in ls] for ls in got_band]
+    got_dense = diff_mustache(cs[0].copy(), cs[1].copy(), "1", "1", 5000, start, start + n, 0, dpx, OCT, st, pt, pt2)
+    ok = key(got_band) == key(exp) and key(got_dense) == key(exp)
+    qe = 0.0
+    if ok:
+        for g, e in zip(got_band, exp):
+            for a, b in zip(g, e):
+                qe = max(qe, abs(a[2] - b[2]) / max(b[2], 1e-300))
+    return bool(ok and forms_agree and qe <= 1e-6), sum(len(l) for l in exp), dict(
+        kind="block pair", n=n, dpx=dpx, st=st, pt=pt, pt2=pt2, lists=[len(l) for l in exp], forms_agree=forms_agree, qerr=qe)
+
+
+def geometry_case(pipe, n, dpx, res, depth, st=0.88, pt=0.1, share_modes=(True,)):
+    """A fixed chromosome at a geometry beyond BASELINE's through the whole pipeline against the oracle's regulator."""
+    import oracle
+    from mustache_amd.synth import synth_coo
+    x, y, v = synth_coo(n, dpx, depth=depth, seed=n, nloops=n // 25)
+    exp = oracle.regulator_coo(x, y, v.copy(), res, dpx, OCT, st, pt)
+    ok, qerr = True, 0.0
+    keep = pipe.engine.share_tiles
+    try:
+        for share in share_modes:
+            pipe.engine.share_tiles = share
+            s, q = _same_loops(pipe.run(x, y, v.copy(), res, dpx, st, pt, distributed=False), exp)
+            ok, qerr = ok and s, max(qerr, q if s else float("inf"))
+    finally:
+        pipe.engine.share_tiles = keep
+    return ok, len(exp), dict(kind="geometry", n=n, dpx=dpx, res=res, depth=depth, nnz=len(v), exp=len(exp), qerr=qerr)

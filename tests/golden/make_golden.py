@@ -150,7 +150,7 @@ def make_block(ref, name, n, dpx, seed, start, st, pt, depth=300.0, nloops=None,
           "pzero", int((locs["pAll"] == 0).sum()) if "pAll" in locs else None)
 
 
-def make_big_block(ref, name="block_2000", n=2000, dpx=400, seed=3, start=3200, st=0.8, pt=0.1, octaves=None):
+def make_big_block(ref, name="block_2000", n=2000, dpx=400, seed=3, start=3200, st=0.8, pt=0.1, octaves=None, full=False):
     """One block of BASELINE's 5 kb geometry (2000 x 2000, distance limit 400 px) -- or, as `block_4000`, of the headline
     1 kb geometry (4000 x 4000, distance limit 2000 px; the reference needs ~80 s and ~3 GB for it).  The input is the raw
     synthetic map (regenerated from the seed by the tests, so only its checksum is stored) and the outputs are kept
@@ -174,6 +174,16 @@ def make_big_block(ref, name="block_2000", n=2000, dpx=400, seed=3, start=3200, 
                         found_pvalue_sum=float(np.sum(locs["pAll"][found])),
                         found_pixels_head=pix[:4096].astype(np.int32), found_values_head=locs["vAll"][found][:4096])
     print(name, "nz", int(nz.sum()), "found", int(found.sum()), "loops", len(loops))
+    if full:
+        # the COMPLETE found set of the reference, pixel for pixel: row-major pixel index, the recorded scale as an index into
+        # the sorted distinct Scales values (= the 1-based tested level of the GPU records minus one when all 18 occur), the
+        # winning DoG value vAll (bit pattern) and the BH q-value the reference leaves in pAll (mustache.py:778-779)
+        sig_values = np.unique(sig)
+        np.savez_compressed(os.path.join(HERE, name + "_full.npz"), n=n, dpx=dpx, seed=seed, depth=300.0,
+                            pixel=pix.astype(np.uint32), sigma_values=sig_values,
+                            sigma_index=np.searchsorted(sig_values, sig).astype(np.uint8),
+                            value=locs["vAll"][found], q=locs["pAll"][found])
+        print(name + "_full", len(pix), "records;", len(sig_values), "distinct scales")
 
 
 def make_edges(ref):
@@ -529,7 +539,7 @@ if __name__ == "__main__":
     if "big" in which:
         make_big_block(ref)
     if "big4000" in which:          # BASELINE config 4's block geometry (not in the default list: ~2 min, ~3 GB)
-        make_big_block(ref, "block_4000", n=4000, dpx=2000, seed=4, start=8000, st=0.8, pt=0.1)
+        make_big_block(ref, "block_4000", n=4000, dpx=2000, seed=4, start=8000, st=0.8, pt=0.1, full=True)
     if "octaves" in which:          # -sz / -oc variants (not in the default list): 3 octaves, and sigma0 = 2.0
         make_big_block(ref, "block_700_oc3", n=700, dpx=160, seed=21, start=1400, st=0.7, pt=0.2, octaves=[1.6, 3.2, 6.4])
         make_big_block(ref, "block_640_sz2", n=640, dpx=150, seed=22, start=0, st=0.7, pt=0.2, octaves=[2.0, 4.0])

@@ -33,7 +33,11 @@ def _check_line(j, n_gpus, steps, warmup):
     r = j["roofline"]
     assert r["bound"] == "fp64_valu" and r["unit"] == "TFLOP/s" and r["peak"] == 39.3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert abs(r["achieved"] - r["pixels_per_launch"] * r["flops_per_pixel"] / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-2
+    # the roofline prices the pixels of the workgroups that RAN (a tile shared by two blocks once), not the block pixels
+    assert abs(r["achieved"] - r["computed_pixels_per_launch"] * r["flops_per_pixel"] / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-2
+    assert abs(r["computed_pixels_per_launch"] - r["pixels_per_launch"] * r["work_items"] / r["tiles"]) <= 1
+    assert r["block_pixel_view"]["frac"] >= r["frac"] and j["tile_sharing"]["speedup"] > 1.0
+    assert abs(j["tile_sharing"]["work_items"] - r["work_items"]) == 0
     assert r["executed_flops_per_pixel"] > r["flops_per_pixel"] * 0.9
     assert r["hbm_model"]["bytes_per_pixel_model"] == 592.0
     assert r["kernel_ms_per_step"] <= j["ms_per_step"] * 1.02          # the kernel fits inside the step it dominates
@@ -51,6 +55,8 @@ def test_bench_one_rank_small():
     _check_line(j, 1, 2, 1)
     assert j["band_skip"]["value"] > j["value"] and j["chr21_5kb"]["value"] > 0 and j["end_to_end"]["loops"] > 0
     assert abs(j["band_skip"]["roofline"]["frac"] - j["band_skip"]["roofline"]["achieved"] / 39.3) < 1e-3
+    assert j["band_skip"]["roofline"]["block_pixel_view"]["frac"] >= j["band_skip"]["roofline"]["frac"]
+    assert j["row2_scatter"]["band_rebuilt_identical"] is True and 0 < j["row2_scatter"]["value_from_coo"] < j["value"]
     g = j["genome_5kb"]
     assert g["blocks"] > 300 and g["chromosomes"] == 24 and g["value"] > 0 and g["end_to_end"]["loops"] > 0
     assert j["diff_genome_5kb"]["block_pairs"] == g["blocks"] and j["diff_genome_5kb"]["value"] > 0
@@ -69,6 +75,28 @@ def test_bench_two_ranks_gloo_one_device():
     frags = _fragments(r.stderr)
     assert sorted(f["rank"] for f in frags) == [0, 1] and all(f["backend"] == "gloo" for f in frags)
     assert "cpu_baseline" not in j and "chr21_5kb" not in j        # rank-0-at-N=1-only legs stay out of the N > 1 line
+
+
+def test_bench_two_ranks_self_launched_with_file_leg():
+    """`python bench.py --gpus 2 --small` WITHOUT torchrun: bench.py starts its two ranks itself (free port), both on this
+    box's one GPU over gloo.  The N-rank file leg runs: each rank inflates its share of the `.hic` blocks (the file is read
+    once between the ranks), the shares are exchanged, the loops of the 2-rank run equal the 1-rank run's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(MST_BENCH_BACKEND="gloo", MST_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--small", "--no-cpu"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    _check_line(j, 2, 2, 1)
+    f = j["end_to_end_from_file"]
+    assert f["ranks"] == 2 and len(f["read_s_per_rank"]) == 2 and j["ranks"]["read_s"] == f["read_s_per_rank"]
+    assert all(c > 0 for c in f["records_per_rank"]) and sum(f["records_per_rank"]) == f["records"]
+    assert abs(f["records_per_rank"][0] - f["records_per_rank"][1]) < 0.2 * f["records"]      # shares of the blocks, balanced
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "1", "--warmup", "0", "--small", "--no-cpu",
+                          "--core", "--with-file"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert one.returncode == 0, one.stderr[-3000:]
+    f1 = _last_json(one.stdout)["end_to_end_from_file"]
+    assert f1["ranks"] == 1 and f1["records"] == f["records"] and f1["loops"] == f["loops"] > 0 and f1["n"] == f["n"]
 
 
 def test_bench_two_ranks_rccl_one_device_if_rccl_allows_it():

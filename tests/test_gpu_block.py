@@ -176,6 +176,15 @@ def _check_found_set(eng, g, nzc, found, fit):
     np.testing.assert_allclose(float(np.sum(found["q"])), float(g["found_pvalue_sum"]), rtol=1e-9)
     assert np.array_equal(fit[0], g["fit"][:, 0])
     np.testing.assert_allclose(fit[1], g["fit"][:, 1], rtol=1e-12)
+    if "full" in g:
+        # the reference's COMPLETE found set (block_4000_full.npz: every found pixel, its recorded scale, its winning DoG value
+        # and its q-value) -- a regression is localised to the pixel, not to a checksum
+        f = g["full"]
+        assert np.array_equal(found["pixel"], f["pixel"]), np.flatnonzero(found["pixel"] != f["pixel"])[:10]
+        sig_ref = f["sigma_values"][f["sigma_index"]]
+        assert np.array_equal(sig, sig_ref), np.flatnonzero(sig != sig_ref)[:10]
+        assert np.array_equal(found["value"], f["value"]), np.flatnonzero(found["value"] != f["value"])[:10]
+        np.testing.assert_allclose(found["q"], f["q"], rtol=1e-9)
 
 
 @pytest.mark.parametrize("name", ["block_2000.npz", "block_4000.npz"])
@@ -189,6 +198,11 @@ def test_baseline_size_block_vs_reference_fixture(eng, golden_dir, name):
     from mustache_amd.mustache import mustache
     from mustache_amd.normalize import band_from_coo
     g = _load(golden_dir, name)
+    full = os.path.join(golden_dir, name.replace(".npz", "_full.npz"))
+    if os.path.exists(full):
+        g = dict(g.items())
+        g["full"] = dict(np.load(full).items())
+        assert len(g["full"]["pixel"]) == int(g["found_count"]) > 100_000
     c, n, dpx = _big_block(g)
     for skip_empty in (True, False):
         dev, nz_d, nzc, found, fit = _run_block(eng, c.copy(), dpx, skip_empty)

@@ -456,6 +456,78 @@ def test_two_rank_cli_equals_one_process(golden_dir, tmp_path):
         assert sorted(a[1:]) == sorted(b[1:])
         if tag == "genome":
             assert [l.split("\t")[0] for l in a[1:]] == [l.split("\t")[0] for l in b[1:]], "chromosomes in file order"
+        else:
+            # one chromosome on two ranks: the file is read ONCE between them -- each rank inflates its share of the blocks
+            import re
+            shares = re.findall(r"rank (\d) of 2 decoded (\d+) of the chromosome's (\d+) .hic blocks \((\d+) records\)", r.stdout)
+            assert sorted(int(s[0]) for s in shares) == [0, 1], r.stdout[-1500:]
+            assert sum(int(s[1]) for s in shares) == int(shares[0][2]) and all(int(s[1]) > 0 for s in shares)
+
+
+def _band_digest_worker(rank, ws, port, hic, res, dpx, q):
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from mustache_amd.hicfile import HicFile, read_intra_packed
+    from mustache_amd.normalize import pinned_packed_alloc
+    from mustache_amd.pipeline import ChromosomePipeline
+    pipe = ChromosomePipeline(OCT)
+    with HicFile(hic) as h:
+        pc = read_intra_packed(h, "chrB", res, "NONE", dpx, 0, alloc=pinned_packed_alloc, part=(rank, ws))
+    band, n = pipe.normalized_band_packed(pc, dpx)
+    loops = pipe.run_band(band, n, dpx, 0.7, 0.2, distributed=True)
+    q.put((rank, n, len(pc), pc.blocks_mine, pc.blocks_total, hashlib.sha256(band.cpu().numpy().tobytes()).hexdigest(),
+           [(int(a), int(b), float(c), float(d)) for a, b, c, d in loops]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shared_decode_gives_the_one_rank_band_bit_for_bit(tmp_path):
+    """Two processes on this box's one GPU (gloo): each decodes ITS share of the `.hic` blocks, the shares are exchanged
+    (sharding.all_gather_packed) and every rank scatters + normalises the same record set -- the normalised band's sha-256 is
+    the same on both ranks and equal to the 1-rank band's, and so are the loops."""
+    import hashlib
+    import socket
+    import sys
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from hic_writer import write_hic
+    from mustache_amd.hicfile import HicFile, read_intra_packed
+    from mustache_amd.pipeline import ChromosomePipeline
+    from mustache_amd.synth import synth_coo
+    res, dpx, n = 10000, 100, 3400
+    x, y, v = synth_coo(n, dpx, depth=200.0, seed=2)
+    near = (y - x) <= dpx
+    hic = str(tmp_path / "b.hic")
+    write_hic(hic, [("All", 1), ("chrB", n * res)], {1: {res: (x[near], y[near], np.round(v[near]) + 1.0)}}, {}, version=8,
+              block_bin_count=256, float_counts=False)
+    pipe = ChromosomePipeline(OCT)
+    with HicFile(hic) as h:
+        pc = read_intra_packed(h, "chrB", res, "NONE", dpx, 0)
+    band, n1 = pipe.normalized_band_packed(pc, dpx)
+    want = hashlib.sha256(band.cpu().numpy().tobytes()).hexdigest()
+    loops1 = [(int(a), int(b), float(c), float(d)) for a, b, c, d in pipe.run_band(band, n1, dpx, 0.7, 0.2, distributed=False)]
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_band_digest_worker, args=(r, 2, port, hic, res, dpx, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [g[0] for g in got] == [0, 1]
+    assert all(g[1] == n1 and g[5] == want for g in got), "same n, same band digest on both ranks as in the 1-rank run"
+    assert got[0][2] + got[1][2] == len(pc) and got[0][3] + got[1][3] == got[0][4] == pc.blocks_total
+    assert min(got[0][2], got[1][2]) > 0
+    assert len(loops1) > 10 and sorted(got[0][6]) == sorted(got[1][6]) == sorted(loops1)
 
 
 def test_whole_genome_cool_path_two_ranks_equals_oracle(tmp_path):

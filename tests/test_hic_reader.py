@@ -35,10 +35,10 @@ def test_io_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(ROOT, "mustache_amd", "libmustache_io.so"))
     header = open(os.path.join(ROOT, "include", "mustache_io.h")).read()
     names = set(re.findall(r"\b(mst_(?:io|hic|text)_\w+)\s*\(", header))
-    assert len(names) == 17
+    assert len(names) == 18
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.mst_io_abi_version() == 1
+    assert lib.mst_io_abi_version() == 2
 
 
 @pytest.mark.parametrize("version,float_counts,dense,short_coords,bbc", [
@@ -223,3 +223,37 @@ def test_header_parse_equals_reference_held_parser(tmp_path, golden_dir):
         assert [c[1] for c in chroms] == [int(v) for v in g["chr_length"]]
         assert list(range(len(chroms))) == [int(i) for i in g["chr_index"]]
         assert h.resolutions() == [int(r) for r in g["resolutions"]]
+
+
+@pytest.mark.parametrize("version,n_parts", [(8, 2), (8, 3), (9, 2), (8, 8)])
+def test_part_decodes_partition_the_chromosome(tmp_path, version, n_parts):
+    """One process per GPU on one chromosome: rank p of n decodes share p of the near-diagonal blocks
+    (mst_hic_decode_intra_packed_part).  The shares are disjoint, every block is decoded by exactly one of them, and their
+    union is the record set of the whole read -- the file is read once between the ranks."""
+    from mustache_amd.hicfile import HicFile, read_intra_packed
+    n, res = 3000, 5000
+    x, y, c = _contacts(n, 300, 60000, 11 * version + n_parts, integer=False)
+    p = str(tmp_path / "p.hic")
+    write_hic(p, [("All", 7500), ("chr1", n * res)], {1: {res: (x, y, c)}}, {("KR", 1, res): np.ones(n + 1)},
+              version=version, block_bin_count=100)
+    with HicFile(p) as h:
+        whole = read_intra_packed(h, "chr1", res, "KR", 250)
+        key_w = np.sort(whole.x.astype(np.int64) * (1 << 32) + whole.dist)
+        assert whole.blocks_total == whole.blocks_mine > n_parts and whole.n_parts == 1
+        keys, blocks, top = [], 0, 0
+        for part in range(n_parts):
+            pc = read_intra_packed(h, "chr1", res, "KR", 250, part=(part, n_parts))
+            assert pc.blocks_total == whole.blocks_total and (pc.part, pc.n_parts) == (part, n_parts)
+            blocks += pc.blocks_mine
+            top = max(top, pc.n)
+            k = pc.x.astype(np.int64) * (1 << 32) + pc.dist
+            keys.append(k)
+            # values travel with their pixel
+            order = np.argsort(k)
+            pos = np.searchsorted(key_w, k[order])
+            vw = whole.v[np.argsort(whole.x.astype(np.int64) * (1 << 32) + whole.dist)]
+            assert np.array_equal(vw[pos], pc.v[order])
+        assert blocks == whole.blocks_total and top == whole.n
+        allk = np.concatenate(keys)
+        assert len(allk) == len(key_w) and np.array_equal(np.sort(allk), key_w)      # disjoint and complete
+        assert min(len(k) for k in keys) > 0.5 * len(key_w) / n_parts                # shares balanced by compressed bytes

@@ -198,3 +198,9 @@ def test_baseline_size_block_vs_reference(golden_dir, name):
     assert float(np.sum(ss.scale[found])) == float(g["found_sigma_sum"])
     got = np.array([[float(a), float(b), q_, s_] for a, b, q_, s_ in loops]).reshape(-1, 4)
     assert np.array_equal(got, g["loops"])
+    full = os.path.join(golden_dir, name.replace(".npz", "_full.npz"))
+    if os.path.exists(full):            # the reference's COMPLETE found set at the headline geometry, record for record
+        f = np.load(full)
+        assert np.array_equal(pix, f["pixel"].astype(np.int64))
+        assert np.array_equal(ss.scale[found], f["sigma_values"][f["sigma_index"]])
+        assert np.array_equal(ss.best[found], f["value"])

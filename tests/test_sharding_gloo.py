@@ -109,3 +109,45 @@ def test_gather_records_five_columns_with_an_empty_rank():
     assert res[0][1] == res[1][1] == res[2][1]
     parts = res[0][1]
     assert [len(p) for p in parts] == [0, 2, 4] and parts[2][3] == [2.0, 23.0, 0.125, 7.0, 1e-300]
+
+
+def _packed_worker(rank, ws, port, q, dist_dtype):
+    import torch
+    import torch.distributed as dist
+    from mustache_amd.sharding import all_gather_packed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    rng = np.random.default_rng(100 + rank)
+    m = [1000, 0, 2477][rank]                       # unequal shares, one of them empty
+    x = rng.integers(0, 5000, m).astype(np.int32)
+    d = rng.integers(0, 300, m).astype(dist_dtype)
+    v = rng.uniform(0.5, 9.0, m).astype(np.float32)
+    parts, n_all = all_gather_packed(x, d, v, int((x.astype(np.int64) + d).max()) + 1 if m else 0, torch.device("cpu"))
+    out = [(p[0].numpy().copy(), p[1].numpy().astype(np.int64), p[2].numpy().copy(), p[3]) for p in parts]
+    q.put((rank, n_all, out, (x, d.astype(np.int64), v)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_packed_three_ranks_uint16_and_int32():
+    """sharding.all_gather_packed: every rank ends up with every rank's share (record for record), the common n is the
+    maximum -- with an empty share in the middle, for both distance widths."""
+    for dt in (np.int32, np.uint16):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_packed_worker, args=(r, 3, port, q, dt)) for r in range(3)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=120) for _ in range(3)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        own = [r[3] for r in res]
+        n_want = max(int((o[0].astype(np.int64) + o[1]).max()) + 1 for o in own if len(o[0]))
+        for rank, n_all, parts, _ in res:
+            assert n_all == n_want
+            assert [p[3] for p in parts] == [1000, 0, 2477]
+            for (px, pd, pv, cnt), (ox, od, ov) in zip(parts, own):
+                assert np.array_equal(px, ox) and np.array_equal(pd, od) and np.array_equal(pv, ov)

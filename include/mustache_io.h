@@ -46,6 +46,12 @@ int mst_io_abi_version(void);
 const char *mst_io_last_error(void);
 void mst_io_free(void *p);
 
+/* The block reader's own zlib-stream decoder (csrc/mst_inflate.h: 64-bit bit buffer, 11-bit primary tables, Adler-32
+ * verified) on one stream -- exported so that tests can hold it to zlib itself on arbitrary streams.  Returns the number of
+ * bytes written to dst, MST_IO_E_ZLIB for an invalid stream, MST_IO_E_ARG when `capacity` (+ 266 bytes of working margin) is
+ * too small.  MUSTACHE_HIC_ZLIB=1 makes the `.hic` readers inflate through zlib instead (cross-check). */
+int64_t mst_io_inflate(const uint8_t *src, int64_t n, uint8_t *dst, int64_t capacity);
+
 /* Opens the file (memory-mapped, read-only) and parses header + master index.  hicstraw.HiCFile(f)  (mustache.py:308). */
 int mst_hic_open(const char *path, mst_hic **out);
 void mst_hic_close(mst_hic *h);
@@ -98,6 +104,29 @@ int mst_hic_fetch_packed(mst_hic *h, int32_t *x, int32_t *dist, float *v, int64_
 int64_t mst_hic_decode_intra_packed_part(mst_hic *h, const char *chrom, int32_t resolution, const char *norm,
                                          int64_t max_dist_bins, int64_t chrom_size_bp, int32_t n_threads, int32_t part,
                                          int32_t n_parts, int64_t *n_bins, int32_t *blocks_total, int32_t *blocks_mine);
+
+/* ---- streaming form of the packed read ------------------------------------------------------------------------------------
+ * The same records as mst_hic_decode_intra_packed_part, delivered in SLABS of caller-owned (page-locked) memory while later
+ * blocks are still being inflated, so that the consumer's host-to-device copies overlap the decode: nothing is staged in the
+ * handle, nothing is copied twice, the total count is not needed in advance.  `slab_memory` holds n_slabs slabs of
+ * slab_records * (8 + dist_bytes) bytes each, laid out {binX int32 [slab_records], value float32 [slab_records], binY - binX
+ * uint16 (dist_bytes = 2; needs 0 <= max_dist_bins <= 65535) or int32 (dist_bytes = 4) [slab_records]}; slab_records must be
+ * at least the largest block's record count (blockBinCount^2 bounds it).  Worker threads (n_threads <= 0: the default pool;
+ * never more than n_slabs - 1) each fill one slab at a time and hand it over when the next block would not fit.
+ *   mst_hic_stream_next    waits up to timeout_ms (< 0: for ever) for a filled slab: 1 = *slab / *count set (records [0, count)
+ *                          of that slab), 2 = nothing ready yet, 0 = every record has been delivered, < 0 = error
+ *   mst_hic_stream_release gives a slab back to the workers (after the consumer's copy out of it has completed)
+ *   mst_hic_stream_close   joins the workers and frees the stream; *n_bins = max(binY) + 1 over the delivered records, *total
+ *                          their number, *blocks_total / *blocks_mine as in mst_hic_decode_intra_packed_part
+ * Slabs may be consumed in any order: a matrix holds every pixel once (mst_band_scatter_packed, include/mustache_hip.h).
+ * The handle must stay open and must not serve another read until the stream is closed. */
+typedef struct mst_hic_stream mst_hic_stream;
+int mst_hic_stream_open(mst_hic *h, const char *chrom, int32_t resolution, const char *norm, int64_t max_dist_bins,
+                        int64_t chrom_size_bp, int32_t n_threads, int32_t part, int32_t n_parts, void *slab_memory,
+                        int32_t n_slabs, int64_t slab_records, int32_t dist_bytes, mst_hic_stream **out);
+int mst_hic_stream_next(mst_hic_stream *s, int32_t timeout_ms, int32_t *slab, int64_t *count);
+int mst_hic_stream_release(mst_hic_stream *s, int32_t slab);
+int mst_hic_stream_close(mst_hic_stream *s, int64_t *n_bins, int64_t *total, int32_t *blocks_total, int32_t *blocks_mine);
 
 /* ---- text contact maps ------------------------------------------------------------------------------------------------
  * The parse step of read_pd() (reference mustache/mustache.py:254-258): `pd.read_csv(f, sep=sep, header=None)` followed

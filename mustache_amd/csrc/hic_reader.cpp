@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../../include/mustache_io.h"
+#include "mst_inflate.h"
 
 namespace {
 
@@ -368,11 +369,38 @@ inline void sink_reserve(Records &out, size_t room) {
 }
 inline void sink_reserve(PackedSink &, size_t) {}
 
-template <class Sink>
-void decode_block(int32_t version, const uint8_t *comp, size_t comp_size, std::vector<uint8_t> &buf, Sink &out,
-                  const std::vector<double> *norm, int64_t max_dist) {
-    // inflate (the uncompressed size is not stored: grow until it fits)
-    if (buf.size() < comp_size * 8 + 1024) buf.resize(comp_size * 8 + 1024);
+// MUSTACHE_HIC_ZLIB=1: inflate through zlib instead of mst_inflate.h (the cross-check the tests use)
+bool use_zlib() {
+    static const bool z = [] {
+        const char *e = getenv("MUSTACHE_HIC_ZLIB");
+        return e && *e && *e != '0';
+    }();
+    return z;
+}
+
+// one zlib stream -> buf (grown until it fits: the uncompressed size is not stored); returns the byte count.
+// `readable_past`: bytes known to be readable behind comp + comp_size (the decoder prefetches up to 16).
+size_t inflate_block(const uint8_t *comp, size_t comp_size, size_t readable_past, std::vector<uint8_t> &buf,
+                     std::vector<uint8_t> &pad) {
+    if (buf.size() < comp_size * 4 + 4096) buf.resize(comp_size * 4 + 4096);
+    if (!use_zlib()) {
+        const uint8_t *src = comp;
+        if (readable_past < mst_inflate::kSlack) {          // the last block(s) of the file: decode from a padded copy
+            pad.assign(comp_size + mst_inflate::kSlack, 0);
+            memcpy(pad.data(), comp, comp_size);
+            src = pad.data();
+        }
+        for (;;) {
+            size_t n_out = 0;
+            const int rc = mst_inflate::inflate_zlib(src, comp_size, buf.data(), buf.size() - mst_inflate::kSlack, &n_out);
+            if (rc == mst_inflate::kOk) return n_out;
+            if (rc == mst_inflate::kOutputFull && buf.size() < ((size_t)1 << 31)) {
+                buf.resize(buf.size() * 2);
+                continue;
+            }
+            throw FormatError{"zlib inflate failed"};
+        }
+    }
     size_t n_out = 0;
     for (;;) {
         z_stream zs;
@@ -392,7 +420,25 @@ void decode_block(int32_t version, const uint8_t *comp, size_t comp_size, std::v
         }
         throw FormatError{"zlib inflate failed"};
     }
-    Cursor c(buf.data(), n_out);
+    return n_out;
+}
+
+template <class Sink>
+void decode_records(int32_t version, const uint8_t *data, size_t n_out, Sink &out, const std::vector<double> *norm,
+                    int64_t max_dist);
+
+template <class Sink>
+void decode_block(int32_t version, const uint8_t *comp, size_t comp_size, size_t readable_past, std::vector<uint8_t> &buf,
+                  Sink &out, const std::vector<double> *norm, int64_t max_dist) {
+    static thread_local std::vector<uint8_t> pad;
+    const size_t n_out = inflate_block(comp, comp_size, readable_past, buf, pad);
+    decode_records(version, buf.data(), n_out, out, norm, max_dist);
+}
+
+template <class Sink>
+void decode_records(int32_t version, const uint8_t *data, size_t n_out, Sink &out, const std::vector<double> *norm,
+                    int64_t max_dist) {
+    Cursor c(data, n_out);
     const int32_t n_rec = c.get<int32_t>();
     if (n_rec < 0) throw FormatError{"negative record count in a block"};
     const size_t room = (size_t)n_rec < n_out ? (size_t)n_rec : n_out;      // a record takes at least one byte
@@ -445,6 +491,137 @@ void decode_block(int32_t version, const uint8_t *comp, size_t comp_size, std::v
     }
 }
 
+// ---- streaming read: records land in caller-owned slabs {x int32 [cap], v float32 [cap], dist uint16 | int32 [cap]} ----------
+struct SlabSink {
+    int32_t *x;
+    float *v;
+    void *d;
+    int dist_bytes;
+    int64_t count, cap, y_limit, ymax;
+    void push(int64_t bx, int64_t by, float c) {
+        if (by >= y_limit) return;
+        if (count >= cap) throw FormatError{"a block holds more records than its header says"};
+        x[count] = (int32_t)bx;
+        v[count] = c;
+        if (dist_bytes == 2) ((uint16_t *)d)[count] = (uint16_t)(by - bx);
+        else ((int32_t *)d)[count] = (int32_t)(by - bx);
+        ++count;
+        ymax = by > ymax ? by : ymax;
+    }
+};
+
+inline void emit(SlabSink &out, int64_t bx, int64_t by, float counts, const std::vector<double> *norm, int64_t max_dist) {
+    if (bx > by) {
+        const int64_t t = bx;
+        bx = by;
+        by = t;
+    }
+    if (max_dist >= 0 && by - bx > max_dist) return;
+    float c = counts;
+    if (norm) {
+        if (bx < 0 || (size_t)by >= norm->size()) return;
+        c = (float)((double)counts / ((*norm)[(size_t)bx] * (*norm)[(size_t)by]));
+    }
+    if (std::isnan(c) || !(c > 0.0f)) return;
+    out.push(bx, by, c);
+}
+inline void sink_reserve(SlabSink &, size_t) {}
+
+// The layout almost every block of a real file has -- version 7-9, list of rows -- decoded with raw pointers: the row's byte
+// extent is checked once, the records go through the same emit() as the general decoder (same filters, same arithmetic).
+// Returns false when the block is of another kind (the caller then runs decode_records).
+template <bool SHORT_X, bool SHORT_C>
+void decode_rows(const uint8_t *p, const uint8_t *end, int32_t rows, bool short_y, int32_t x_off, int32_t y_off, SlabSink &out,
+                 const std::vector<double> *norm, int64_t max_dist) {
+    constexpr size_t rec = (SHORT_X ? 2 : 4) + (SHORT_C ? 2 : 4);
+    for (int32_t r = 0; r < rows; ++r) {
+        const size_t head = (short_y ? 2 : 4) + (SHORT_X ? 2 : 4);
+        if ((size_t)(end - p) < head) throw FormatError{"truncated structure"};
+        int32_t y, cols;
+        if (short_y) {
+            int16_t t;
+            memcpy(&t, p, 2);
+            y = t;
+            p += 2;
+        } else {
+            memcpy(&y, p, 4);
+            p += 4;
+        }
+        if (SHORT_X) {
+            int16_t t;
+            memcpy(&t, p, 2);
+            cols = t;
+            p += 2;
+        } else {
+            memcpy(&cols, p, 4);
+            p += 4;
+        }
+        if (cols < 0) cols = 0;                                   // the general decoder's loop runs zero times as well
+        if ((size_t)(end - p) < (size_t)cols * rec) throw FormatError{"truncated structure"};
+        const int64_t by = (int64_t)y_off + y;
+        for (int32_t j = 0; j < cols; ++j) {
+            int32_t x;
+            float val;
+            if (SHORT_X) {
+                int16_t t;
+                memcpy(&t, p, 2);
+                x = t;
+                p += 2;
+            } else {
+                memcpy(&x, p, 4);
+                p += 4;
+            }
+            if (SHORT_C) {
+                int16_t t;
+                memcpy(&t, p, 2);
+                val = (float)t;
+                p += 2;
+            } else {
+                memcpy(&val, p, 4);
+                p += 4;
+            }
+            emit(out, (int64_t)x_off + x, by, val, norm, max_dist);
+        }
+    }
+}
+
+bool decode_rows_fast(int32_t version, const uint8_t *data, size_t n, SlabSink &out, const std::vector<double> *norm,
+                      int64_t max_dist) {
+    if (version < 7) return false;
+    const size_t hdr = 4 + 4 + 4 + 1 + (version > 8 ? 2 : 0) + 1;
+    if (n < hdr) return false;
+    const uint8_t *p = data + 4;
+    int32_t x_off, y_off;
+    memcpy(&x_off, p, 4);
+    memcpy(&y_off, p + 4, 4);
+    p += 8;
+    const bool short_c = *p++ == 0;
+    bool short_x = true, short_y = true;
+    if (version > 8) {
+        short_x = *p++ == 0;
+        short_y = *p++ == 0;
+    }
+    if (*p++ != 1) return false;
+    const uint8_t *end = data + n;
+    int32_t rows;
+    if (short_y) {
+        if (end - p < 2) return false;
+        int16_t t;
+        memcpy(&t, p, 2);
+        rows = t;
+        p += 2;
+    } else {
+        if (end - p < 4) return false;
+        memcpy(&rows, p, 4);
+        p += 4;
+    }
+    if (short_x && short_c) decode_rows<true, true>(p, end, rows, short_y, x_off, y_off, out, norm, max_dist);
+    else if (short_x) decode_rows<true, false>(p, end, rows, short_y, x_off, y_off, out, norm, max_dist);
+    else if (short_c) decode_rows<false, true>(p, end, rows, short_y, x_off, y_off, out, norm, max_dist);
+    else decode_rows<false, false>(p, end, rows, short_y, x_off, y_off, out, norm, max_dist);
+    return true;
+}
+
 int find_chromosome(const mst_hic *h, const char *name) {
     const std::string want(name);
     const std::string bare = want.rfind("chr", 0) == 0 ? want.substr(3) : want;
@@ -461,6 +638,18 @@ int find_chromosome(const mst_hic *h, const char *name) {
 extern "C" int mst_io_abi_version(void) { return MST_IO_ABI_VERSION; }
 extern "C" const char *mst_io_last_error(void) { return g_err; }
 extern "C" void mst_io_free(void *p) { free(p); }
+
+extern "C" int64_t mst_io_inflate(const uint8_t *src, int64_t n, uint8_t *dst, int64_t capacity) {
+    if (!src || !dst || n < 0 || capacity < 0) return fail(MST_IO_E_ARG, "mst_io_inflate: bad argument");
+    std::vector<uint8_t> in((size_t)n + mst_inflate::kSlack, 0), out((size_t)capacity + mst_inflate::kSlack);
+    memcpy(in.data(), src, (size_t)n);
+    size_t produced = 0;
+    const int rc = mst_inflate::inflate_zlib(in.data(), (size_t)n, out.data(), (size_t)capacity, &produced);
+    if (rc == mst_inflate::kOutputFull) return fail(MST_IO_E_ARG, "mst_io_inflate: output does not fit %lld bytes", (long long)capacity);
+    if (rc != mst_inflate::kOk) return fail(MST_IO_E_ZLIB, "mst_io_inflate: not a valid zlib stream");
+    memcpy(dst, out.data(), produced);
+    return (int64_t)produced;
+}
 
 extern "C" int mst_hic_open(const char *path, mst_hic **out) {
     if (!path || !out) return fail(MST_IO_E_ARG, "mst_hic_open: null argument");
@@ -587,7 +776,8 @@ static int read_intra_parts(mst_hic *h, const char *chrom, int32_t resolution, c
             const size_t i = next.fetch_add(1);
             if (i >= todo.size() || bad.load()) return;
             try {
-                decode_block(h->version, h->map + todo[i]->pos, (size_t)todo[i]->size, buf, part[i],
+                decode_block(h->version, h->map + todo[i]->pos, (size_t)todo[i]->size,
+                             h->size - (size_t)todo[i]->pos - (size_t)todo[i]->size, buf, part[i],
                              use_norm ? &norm_vec : nullptr, max_dist_bins);
             } catch (const FormatError &e) {
                 bad_what = e.what;
@@ -764,7 +954,8 @@ extern "C" int64_t mst_hic_decode_intra_packed_part(mst_hic *h, const char *chro
                 if (i >= todo.size() || bad.load()) break;
                 const size_t before = sink.a->v.size();
                 try {
-                    decode_block(h->version, h->map + todo[i]->pos, (size_t)todo[i]->size, buf, sink,
+                    decode_block(h->version, h->map + todo[i]->pos, (size_t)todo[i]->size,
+                                 h->size - (size_t)todo[i]->pos - (size_t)todo[i]->size, buf, sink,
                                  use_norm ? &norm_vec : nullptr, max_dist_bins);
                 } catch (const FormatError &e) {
                     bad_what = e.what;
@@ -849,4 +1040,214 @@ extern "C" int64_t mst_hic_read_intra_packed(mst_hic *h, const char *chrom, int3
     *dist = od;
     *v = ov;
     return total;
+}
+
+// ---- streaming packed read -------------------------------------------------------------------------------------------------
+// Worker threads inflate and decode the chromosome's near-diagonal blocks (this part's share of them) straight into
+// caller-owned slabs; a slab is handed to the consumer as soon as the next block would not fit, so the consumer's H2D copies
+// run while later blocks are still being inflated.  No arena, no second copy, no total count needed in advance.
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+
+struct mst_hic_stream {
+    mst_hic *h = nullptr;
+    std::vector<const BlockRef *> todo;
+    ZoomData zoom;
+    std::vector<double> norm_vec;
+    bool use_norm = false;
+    int64_t max_dist = -1, y_limit = INT64_MAX;
+    uint8_t *base = nullptr;
+    int32_t n_slabs = 0, dist_bytes = 2;
+    int64_t cap = 0;
+    std::vector<int64_t> counts;
+    std::mutex mu;
+    std::condition_variable cv_free, cv_ready;
+    std::deque<int32_t> free_q, ready_q;
+    std::vector<std::thread> workers;
+    std::atomic<size_t> next{0};
+    int active = 0;
+    bool failed = false, cancelled = false;
+    std::string error;
+    int64_t ymax = -1, total = 0;
+    int32_t blocks_total = 0;
+
+    uint8_t *slab(int32_t i) const { return base + (size_t)i * (size_t)cap * (size_t)(8 + dist_bytes); }
+
+    void fail_with(const char *what) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failed) error = what;
+        failed = true;
+        cv_free.notify_all();
+        cv_ready.notify_all();
+    }
+
+    void work() {
+        std::vector<uint8_t> buf, pad;
+        int32_t cur = -1;
+        SlabSink sink{nullptr, nullptr, nullptr, dist_bytes, 0, 0, y_limit, -1};
+        auto publish = [&]() {
+            if (cur < 0) return;
+            std::lock_guard<std::mutex> lk(mu);
+            counts[(size_t)cur] = sink.count;
+            total += sink.count;
+            if (sink.count > 0) {
+                ready_q.push_back(cur);
+                cv_ready.notify_one();
+            } else {
+                free_q.push_back(cur);
+                cv_free.notify_one();
+            }
+            cur = -1;
+        };
+        try {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= todo.size()) break;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (failed || cancelled) break;
+                }
+                const BlockRef *b = todo[i];
+                const size_t n_out = inflate_block(h->map + b->pos, (size_t)b->size, h->size - (size_t)b->pos - (size_t)b->size,
+                                                   buf, pad);
+                if (n_out < 4) throw FormatError{"truncated structure"};
+                int32_t n_rec;
+                memcpy(&n_rec, buf.data(), 4);
+                if (n_rec < 0) throw FormatError{"negative record count in a block"};
+                if ((int64_t)n_rec > cap) throw FormatError{"a block holds more records than a slab (raise slab_records)"};
+                if (cur < 0 || sink.count + n_rec > cap) {
+                    publish();
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_free.wait(lk, [&] { return !free_q.empty() || failed || cancelled; });
+                    if (failed || cancelled) break;
+                    cur = free_q.front();
+                    free_q.pop_front();
+                    lk.unlock();
+                    uint8_t *m = slab(cur);
+                    sink.x = reinterpret_cast<int32_t *>(m);
+                    sink.v = reinterpret_cast<float *>(m + (size_t)cap * 4);
+                    sink.d = m + (size_t)cap * 8;
+                    sink.count = 0;
+                    sink.cap = cap;
+                }
+                if (!decode_rows_fast(h->version, buf.data(), n_out, sink, use_norm ? &norm_vec : nullptr, max_dist))
+                    decode_records(h->version, buf.data(), n_out, sink, use_norm ? &norm_vec : nullptr, max_dist);
+            }
+            publish();
+        } catch (const FormatError &e) {
+            fail_with(e.what);
+        } catch (...) {
+            fail_with("out of memory");
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        ymax = sink.ymax > ymax ? sink.ymax : ymax;
+        if (--active == 0) cv_ready.notify_all();
+    }
+};
+
+extern "C" int mst_hic_stream_open(mst_hic *h, const char *chrom, int32_t resolution, const char *norm, int64_t max_dist_bins,
+                                   int64_t chrom_size_bp, int32_t n_threads, int32_t part, int32_t n_parts, void *slab_memory,
+                                   int32_t n_slabs, int64_t slab_records, int32_t dist_bytes, mst_hic_stream **out) {
+    if (!h || !chrom || !out || resolution <= 0 || n_parts < 1 || part < 0 || part >= n_parts || !slab_memory || n_slabs < 2 ||
+        slab_records < 1 || (dist_bytes != 2 && dist_bytes != 4))
+        return fail(MST_IO_E_ARG, "mst_hic_stream_open: bad argument");
+    if (dist_bytes == 2 && (max_dist_bins < 0 || max_dist_bins > 65535))
+        return fail(MST_IO_E_ARG, "mst_hic_stream_open: 16-bit distances need 0 <= max_dist_bins <= 65535");
+    *out = nullptr;
+    mst_hic_stream *s = nullptr;
+    try {
+        s = new mst_hic_stream();
+        s->h = h;
+        std::vector<const BlockRef *> todo;
+        const int rc = intra_todo(h, chrom, resolution, norm, max_dist_bins, todo, s->zoom, s->norm_vec, &s->use_norm);
+        if (rc != MST_IO_OK) {
+            delete s;
+            return rc;
+        }
+        // todo points into `zoom.blocks`, which intra_todo filled inside s->zoom: the pointers stay valid with the stream
+        s->blocks_total = (int32_t)todo.size();
+        if (n_parts > 1) {
+            std::vector<double> mid(todo.size());
+            double run = 0.0;
+            for (size_t i = 0; i < todo.size(); ++i) {
+                mid[i] = run + 0.5 * (double)todo[i]->size;
+                run += (double)todo[i]->size;
+            }
+            std::vector<const BlockRef *> own;
+            for (size_t i = 0; i < todo.size(); ++i) {
+                int p = run > 0.0 ? (int)(mid[i] / run * (double)n_parts) : 0;
+                p = p < 0 ? 0 : (p >= n_parts ? n_parts - 1 : p);
+                if (p == part) own.push_back(todo[i]);
+            }
+            todo.swap(own);
+        }
+        s->todo.swap(todo);
+        s->max_dist = max_dist_bins;
+        s->y_limit = chrom_size_bp > 0 ? (chrom_size_bp + resolution - 1) / resolution : INT64_MAX;
+        s->base = static_cast<uint8_t *>(slab_memory);
+        s->n_slabs = n_slabs;
+        s->cap = slab_records;
+        s->dist_bytes = dist_bytes;
+        s->counts.assign((size_t)n_slabs, 0);
+        for (int32_t i = 0; i < n_slabs; ++i) s->free_q.push_back(i);
+        int nt = n_threads > 0 ? n_threads : default_threads();
+        if (nt < 1) nt = 1;
+        if ((size_t)nt > s->todo.size()) nt = s->todo.empty() ? 1 : (int)s->todo.size();
+        if (nt > n_slabs - 1) nt = n_slabs - 1;                 // every worker holds a slab; one more keeps the consumer fed
+        s->active = nt;
+        for (int t = 0; t < nt; ++t) s->workers.emplace_back([s] { s->work(); });
+        *out = s;
+        return MST_IO_OK;
+    } catch (const FormatError &e) {
+        delete s;
+        return fail(MST_IO_E_FORMAT, "%s", e.what);
+    } catch (...) {
+        delete s;
+        return fail(MST_IO_E_FORMAT, "unreadable file (out of memory?)");
+    }
+}
+
+extern "C" int mst_hic_stream_next(mst_hic_stream *s, int32_t timeout_ms, int32_t *slab, int64_t *count) {
+    if (!s || !slab || !count) return fail(MST_IO_E_ARG, "mst_hic_stream_next: bad argument");
+    std::unique_lock<std::mutex> lk(s->mu);
+    auto ready = [&] { return !s->ready_q.empty() || s->failed || s->active == 0; };
+    if (timeout_ms < 0) s->cv_ready.wait(lk, ready);
+    else if (!s->cv_ready.wait_for(lk, std::chrono::milliseconds(timeout_ms), ready)) return 2;      // nothing yet
+    if (s->failed) return fail(MST_IO_E_ZLIB, "block decode failed: %s", s->error.c_str());
+    if (!s->ready_q.empty()) {
+        *slab = s->ready_q.front();
+        s->ready_q.pop_front();
+        *count = s->counts[(size_t)*slab];
+        return 1;
+    }
+    return 0;                                                                                         // all delivered
+}
+
+extern "C" int mst_hic_stream_release(mst_hic_stream *s, int32_t slab) {
+    if (!s || slab < 0 || slab >= s->n_slabs) return fail(MST_IO_E_ARG, "mst_hic_stream_release: bad argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->free_q.push_back(slab);
+    s->cv_free.notify_one();
+    return MST_IO_OK;
+}
+
+extern "C" int mst_hic_stream_close(mst_hic_stream *s, int64_t *n_bins, int64_t *total, int32_t *blocks_total,
+                                    int32_t *blocks_mine) {
+    if (!s) return MST_IO_OK;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->cancelled = true;
+        s->cv_free.notify_all();
+    }
+    for (auto &t : s->workers) t.join();
+    int rc = MST_IO_OK;
+    if (s->failed) rc = fail(MST_IO_E_ZLIB, "block decode failed: %s", s->error.c_str());
+    else if (s->ymax >= INT32_MAX) rc = fail(MST_IO_E_FORMAT, "bin index %lld does not fit 32 bits", (long long)s->ymax);
+    if (n_bins) *n_bins = s->ymax + 1;
+    if (total) *total = s->total;
+    if (blocks_total) *blocks_total = s->blocks_total;
+    if (blocks_mine) *blocks_mine = (int32_t)s->todo.size();
+    delete s;
+    return rc;
 }

@@ -53,8 +53,16 @@ constexpr int pitch_for(int need) {
     while (p % 32 != 2 && p % 32 != 30) ++p;
     return p;
 }
+// The rule itself only needs pitch / 2 odd (a unit modulo 32: lane i of a half-wave then lands on slot i * pitch / 2 + c, 32
+// distinct values); pitch_for's 2 / 30 (mod 32) is the subset the product tiles were measured with.  Tiles that must fit a
+// tighter LDS budget (the experimental radius-7 tile) take the smallest even pitch with an odd half.
+constexpr int pitch_min(int need) {
+    int p = need + (need & 1);
+    while ((p / 2) % 2 == 0) p += 2;
+    return p;
+}
 
-template <int RGR_, int RGC_, int RMAX_, int K_ = 8, int MINW_ = 1, bool FMA_ = false>
+template <int RGR_, int RGC_, int RMAX_, int K_ = 8, int MINW_ = 1, bool FMA_ = false, bool TIGHT_ = false>
 struct Tile {
     // FMA = false: SciPy's exact operation sequence (add, multiply, add -- three roundings per tap pair), DoG values
     //              bit-identical to the reference.  This is the default and what every parity claim refers to.
@@ -72,8 +80,8 @@ struct Tile {
     static constexpr int NW = NT / 64;            // waves per workgroup
     static constexpr int CTR = RGR + 2 * RMAX;    // c tile rows / cols held in LDS (stored TRANSPOSED: ct[col][row])
     static constexpr int CTC = RGC + 2 * RMAX;
-    static constexpr int CTP = pitch_for(CTR);
-    static constexpr int VP = pitch_for(RGC + 2 * RMAX);
+    static constexpr int CTP = TIGHT_ ? pitch_min(CTR) : pitch_for(CTR);
+    static constexpr int VP = TIGHT_ ? pitch_min(RGC + 2 * RMAX) : pitch_for(RGC + 2 * RMAX);
     static constexpr int CT_ELEMS = CTC * CTP;
     static constexpr int VB_ELEMS = RGR * VP;
     static constexpr int DE_ELEMS = NCG * 2 * RGR;           // edge strip: [cg][left/right][row]

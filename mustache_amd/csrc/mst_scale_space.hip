@@ -601,6 +601,12 @@ int check_levels(const mst_levels *lv, int *max_radius, int *n_tested) {
 using TileDefault = Tile<32, 64, 14>;   // the reference's default octaves (radius <= 14)
 using TileWide = Tile<32, 32, 28, 4, 1>;   // -sz / -oc variants up to radius 28: 256 threads x 4 pixels (K = 8 spilled SGPRs and left half the SIMDs idle)
 using TileDefaultFma = Tile<32, 64, 14, 8, 1, true>;   // opt-in relaxed arithmetic (MST_FLAG_FMA), default radii only
+#ifdef MST_EXP_TILE7
+// Experiment (round 4, variant builds only: scripts/build_variant.sh ... -DMST_EXP_TILE7=<waves per SIMD>): a tile for level
+// tables whose largest blur radius is 7 (octave 1.6 alone) -- 7-pixel halo, tight pitches: 53.3 KB of LDS, three workgroups
+// per CU if the register allocation allows MST_EXP_TILE7 waves per SIMD.  Prices the "two launches by octave" design.
+using TileOct1 = Tile<32, 64, 7, 8, MST_EXP_TILE7, false, true>;
+#endif
 
 // A block's tile grid has at most this many rows / columns of tiles, whatever the lattice phase of its origin
 template <class T>
@@ -925,6 +931,11 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
     if (fma)
         rc = launch_scale_space<TileDefaultFma, BAND>(c, nz, src, CH, d_lv, found, found_cap, found_count, partial, nt,
                                                       skip_empty, d_items, n_items, s);
+#ifdef MST_EXP_TILE7
+    else if (mr <= 7 && getenv("MST_EXP_USE_TILE7"))
+        rc = launch_scale_space<TileOct1, BAND>(c, nz, src, CH, d_lv, found, found_cap, found_count, partial, nt,
+                                                skip_empty, d_items, n_items, s);
+#endif
     else if (!wide)
         rc = launch_scale_space<TileDefault, BAND>(c, nz, src, CH, d_lv, found, found_cap, found_count, partial, nt,
                                                    skip_empty, d_items, n_items, s);

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "mst_io_abi_version": (ctypes.c_int, []),
     "mst_io_last_error": (ctypes.c_char_p, []),
     "mst_io_free": (None, [_P]),
+    "mst_io_inflate": (ctypes.c_int64, [_P, ctypes.c_int64, _P, ctypes.c_int64]),
     "mst_hic_open": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_P)]),
     "mst_hic_close": (None, [_P]),
     "mst_hic_version": (ctypes.c_int32, [_P]),
@@ -47,6 +48,13 @@ _SIGNATURES = {
                                                           ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                                           ctypes.c_int32, ctypes.POINTER(ctypes.c_int64),
                                                           ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "mst_hic_stream_open": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64,
+                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int64,
+                                           ctypes.c_int32, ctypes.POINTER(_P)]),
+    "mst_hic_stream_next": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)]),
+    "mst_hic_stream_release": (ctypes.c_int, [_P, ctypes.c_int32]),
+    "mst_hic_stream_close": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                            ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "mst_text_read_contacts": (ctypes.c_int64, [ctypes.c_char_p, ctypes.c_char, ctypes.c_char_p, ctypes.c_int32,
                                                 ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_P), ctypes.POINTER(_P),
                                                 ctypes.POINTER(_P)]),
@@ -140,27 +148,73 @@ class HicFile:
         return x, y, v
 
 
+class HicStream:
+    """mst_hic_stream_*: the packed records of one chromosome (or of share `part` of its blocks) delivered slab by slab into
+    caller-owned memory while later blocks are still being inflated.  `memory_ptr` points to n_slabs * slab_records *
+    (8 + dist_bytes) bytes (page-locked for GPU uploads); see include/mustache_io.h for the slab layout."""
+
+    def __init__(self, hic, chrom, resolution, norm, max_dist_bins, chrom_size_bp, memory_ptr, n_slabs, slab_records,
+                 dist_bytes=2, threads=0, part=(0, 1)):
+        self._lib, self._hic = hic._lib, hic
+        self._s = _P()
+        self.slab_records, self.dist_bytes, self.n_slabs = int(slab_records), int(dist_bytes), int(n_slabs)
+        _check(self._lib, self._lib.mst_hic_stream_open(hic._h, str(chrom).encode(), int(resolution), str(norm).encode(),
+                                                        int(max_dist_bins), int(chrom_size_bp), int(threads), int(part[0]),
+                                                        int(part[1]), _P(memory_ptr), int(n_slabs), int(slab_records),
+                                                        int(dist_bytes), ctypes.byref(self._s)))
+        self.n = self.total = self.blocks_total = self.blocks_mine = None
+
+    def next(self, timeout_ms=-1):
+        """(slab index, record count) of a filled slab; None when nothing was ready within timeout_ms; False at the end."""
+        slab, count = ctypes.c_int32(), ctypes.c_int64()
+        rc = _check(self._lib, self._lib.mst_hic_stream_next(self._s, int(timeout_ms), ctypes.byref(slab), ctypes.byref(count)))
+        if rc == 1:
+            return int(slab.value), int(count.value)
+        return None if rc == 2 else False
+
+    def release(self, slab):
+        _check(self._lib, self._lib.mst_hic_stream_release(self._s, int(slab)))
+
+    def close(self):
+        if self._s:
+            n, tot, bt, bm = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+            s, self._s = self._s, _P()
+            _check(self._lib, self._lib.mst_hic_stream_close(s, ctypes.byref(n), ctypes.byref(tot), ctypes.byref(bt),
+                                                             ctypes.byref(bm)))
+            self.n, self.total, self.blocks_total, self.blocks_mine = int(n.value), int(tot.value), int(bt.value), int(bm.value)
+
+    __del__ = close
+
+
 class PackedContacts:
     """Records of one chromosome as the native reader hands them to the GPU loader (mst_band_from_packed): x = binX (int32),
     dist = binY - binX (int32), v = straw's float32 value; `n` = max(binY) + 1 (mustache.py:894), `res` the resolution.
     `pinned`: the three torch tensors (page-locked host memory) the arrays are views of, when the caller's allocator
     provided such -- the upload then runs at the full PCIe rate; None for plain NumPy arrays."""
 
-    def __init__(self, x, dist, v, n, res, pinned=None, part=0, n_parts=1, blocks_total=None, blocks_mine=None):
+    def __init__(self, x, dist, v, n, res, pinned=None, part=0, n_parts=1, blocks_total=None, blocks_mine=None, count=None):
         self.x, self.dist, self.v = x, dist, v
-        self.count, self.n, self.res, self.pinned = int(len(v)), int(n), int(res), pinned
+        self.count, self.n, self.res, self.pinned = int(len(v) if count is None else count), int(n), int(res), pinned
         # n_parts > 1: this object holds only the records of part `part` of the chromosome's `.hic` blocks (one process per
         # GPU, each rank decodes its share: read_intra_packed(part=...)); `n` is then this part's max(binY) + 1 and the
         # device loader (normalize.band_from_packed) exchanges the parts between the ranks before it scatters
         self.part, self.n_parts = int(part), int(n_parts)
         self.blocks_total, self.blocks_mine = blocks_total, blocks_mine
         self.read_s = None
+        # streamed reads (normalize.read_hic_stream_to_device): the records already sit in device memory as a list of
+        # (x int32, dist uint16 | int32, v float32, count) tensors, one per slab; x / dist / v above are then None
+        self.device_parts = None
 
     def __len__(self):
         return self.count
 
     def coo(self):
         """(x, y, v) as the reference's int64 / float64 COO (copies) -- for callers that want the classic triple."""
+        if self.device_parts is not None:
+            x = np.concatenate([p[0][:p[3]].cpu().numpy() for p in self.device_parts] or [np.zeros(0, np.int32)]).astype(np.int64)
+            d = np.concatenate([p[1][:p[3]].cpu().numpy() for p in self.device_parts] or [np.zeros(0, np.int32)]).astype(np.int64)
+            v = np.concatenate([p[2][:p[3]].cpu().numpy() for p in self.device_parts] or [np.zeros(0, np.float32)])
+            return x, x + d, v.astype(np.float64)
         x = self.x.astype(np.int64)
         return x, x + self.dist.astype(np.int64), self.v.astype(np.float64)
 

@@ -247,7 +247,7 @@ def _check_pair(f, chromosome, chromosome2):
 
 
 def read_contacts(f, norm_method, CHRM_SIZE, res, distance_filter, bias, chromosome, chromosome2, verbose=True,
-                  packed=False, part=(0, 1)):
+                  packed=False, part=(0, 1), device=None):
     """The reading half of regulator() (reference mustache.py:866-889): host I/O only, so main() can fetch the next
     chromosome while the GPU works on the current one.  Returns (x, y, v, res) or None when nothing was read.
     packed=True: a `.hic` file read by the native reader comes back as hicfile.PackedContacts (12 bytes per record, what
@@ -260,7 +260,7 @@ def read_contacts(f, norm_method, CHRM_SIZE, res, distance_filter, bias, chromos
         from .readers import hic_backend, read_hic_packed
         if hic_backend() == "native":
             # part = (rank, ranks): several GPUs on ONE chromosome -- each rank inflates its share of the blocks only
-            return read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chromosome, res, part=part)
+            return read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chromosome, res, part=part, device=device)
     if f.endswith(".hic"):
         from .readers import read_hic_file
         x, y, v = read_hic_file(f, norm_method, CHRM_SIZE, distance_in_bp, chromosome, chromosome2, res)
@@ -425,12 +425,19 @@ def main(argv=None):
     biasf = args.biasfile if args.biasfile else False
     pairs = list(zip(chr_list, chr_list2))
 
+    try:                                     # the reader thread below must upload to THIS thread's device, not to GPU 0
+        import torch
+        my_device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    except ImportError:
+        my_device = None
+
     def fetch(i):
         chromosome, chromosome2 = pairs[i]
         CHRM_SIZE = chrSize_in_bp["chr" + str(chromosome).replace('chr', '')] if chrSize_in_bp else False
         try:
             return read_contacts(f, args.norm_method, CHRM_SIZE, res, distFilter, biasf, chromosome, chromosome2,
-                                 verbose=args.verbose, packed=True, part=(0, 1) if by_chromosome else (rank, _world))
+                                 verbose=args.verbose, packed=True, part=(0, 1) if by_chromosome else (rank, _world),
+                                 device=my_device)
         except BaseException as e:          # re-raised in the main thread, at this chromosome's turn
             return e
 

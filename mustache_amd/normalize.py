@@ -57,6 +57,87 @@ def pinned_packed_alloc(count):
     return ts[0].numpy(), ts[1].numpy(), ts[2].numpy(), ts
 
 
+_SLAB_POOL = {}
+
+
+def _slab_pool(n_slabs, slab_records, dist_bytes):
+    """Page-locked slab memory for the streaming `.hic` read, kept for the life of the process (a whole-genome run reuses it
+    chromosome after chromosome; pinning fresh pages costs ~0.3 s per GB)."""
+    key = (int(n_slabs), int(slab_records), int(dist_bytes))
+    buf = _SLAB_POOL.get(key)
+    if buf is None:
+        _SLAB_POOL.clear()
+        buf = _SLAB_POOL[key] = torch.empty(key[0] * key[1] * (8 + key[2]), dtype=torch.uint8, pin_memory=True)
+    return buf
+
+
+def read_hic_stream_to_device(hic, chrom, res, norm, dpx, chrom_size_bp, device, part=(0, 1), threads=0,
+                              slab_records=1 << 20, n_slabs=None):
+    """hicfile.HicFile -> hicfile.PackedContacts whose records already sit in DEVICE memory (pc.device_parts): the native
+    reader's worker threads inflate and decode into page-locked slabs (binX int32, value float32, distance uint16: 10 bytes per
+    record) and every slab is copied to the device on a side stream as soon as it is full -- the PCIe transfer runs under the
+    inflate of the later blocks instead of after it.  part = (rank, ranks): this rank's share of the blocks only.
+    band_from_packed() takes the result (and exchanges the shares between the ranks first when there are several)."""
+    import os
+    import time
+    from .hicfile import HicStream, PackedContacts
+    require_gpu()
+    t0 = time.time()
+    dist_bytes = 2 if dpx + 1 <= 65535 else 4
+    if n_slabs is None:
+        # every worker thread fills one slab at a time; a few more keep uploads in flight while they do
+        n_slabs = int(os.environ.get("MUSTACHE_HIC_SLABS", "0")) or min(72, max(8, (threads or _reader_threads()) + 8))
+    pool = _slab_pool(n_slabs, slab_records, dist_bytes)
+    slab_bytes = slab_records * (8 + dist_bytes)
+    ddt = torch.uint16 if dist_bytes == 2 else torch.int32
+    st = HicStream(hic, chrom, res, norm, int(dpx), int(chrom_size_bp), pool.data_ptr(), n_slabs, slab_records, dist_bytes,
+                   threads=threads, part=part)
+    side = torch.cuda.Stream(device)
+    parts, pending = [], []
+    try:
+        while True:
+            got = st.next(2 if pending else -1)
+            # slabs whose copies have completed go back to the workers
+            while pending and pending[0][0].query():
+                st.release(pending.pop(0)[1])
+            if got is None:
+                continue
+            if got is False:
+                break
+            slab, cnt = got
+            base = slab * slab_bytes
+            hx = pool[base:base + 4 * cnt].view(torch.int32)
+            hv = pool[base + 4 * slab_records:base + 4 * slab_records + 4 * cnt].view(torch.float32)
+            hd = pool[base + 8 * slab_records:base + 8 * slab_records + dist_bytes * cnt].view(ddt)
+            with torch.cuda.stream(side):
+                xd, dd, vd = (t.to(device, non_blocking=True) for t in (hx, hd, hv))
+                ev = side.record_event()
+            parts.append((xd, dd, vd, cnt))
+            pending.append((ev, slab))
+        side.synchronize()
+    finally:
+        st.close()
+    torch.cuda.current_stream(device).wait_stream(side)
+    pc = PackedContacts(None, None, None, st.n, res, part=part[0], n_parts=part[1], blocks_total=st.blocks_total,
+                        blocks_mine=st.blocks_mine, count=st.total)
+    pc.device_parts = parts
+    pc.read_s = time.time() - t0
+    return pc
+
+
+def _reader_threads():
+    """The native reader's default worker count (hardware concurrency capped at twice the container's CPU quota)."""
+    import os
+    hw = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            hw = min(hw, max(1, int(2.0 * float(q) / float(p) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return hw
+
+
 def band_from_packed(pc, dpx, device, check=None):
     """hicfile.PackedContacts -> raw band [dpx+2, n] on `device`: three uploads of 4 bytes per record each (from page-locked
     memory when the records were read into it) and one scatter (mst_band_scatter_packed).  With one process per GPU
@@ -71,10 +152,20 @@ def band_from_packed(pc, dpx, device, check=None):
     lib = require_gpu()
     if check is None:
         check = bool(os.environ.get("MUSTACHE_CHECK_PACKED"))
+    dev_parts = getattr(pc, "device_parts", None)
     if getattr(pc, "n_parts", 1) > 1:
         from .sharding import all_gather_packed
-        parts, n = all_gather_packed(pc.x, pc.dist, pc.v, pc.n, device)
+        if dev_parts is not None:             # streamed read: this rank's records are on the device already
+            cat = lambda k, dt: (torch.cat([p[k][:p[3]] for p in dev_parts]) if dev_parts
+                                 else torch.zeros(0, dtype=dt, device=device))
+            own = (cat(0, torch.int32), cat(1, torch.uint16 if dpx + 1 <= 65535 else torch.int32), cat(2, torch.float32))
+        else:
+            own = (pc.x, pc.dist, pc.v)
+        parts, n = all_gather_packed(own[0], own[1], own[2], pc.n, device)
         pc.n_all = n
+    elif dev_parts is not None:
+        n = int(pc.n)
+        parts = dev_parts
     else:
         n = int(pc.n)
         if pc.pinned is not None:

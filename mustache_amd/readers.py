@@ -163,13 +163,16 @@ def close_hic_handle():
 atexit.register(close_hic_handle)
 
 
-def read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, res, part=(0, 1)):
+def read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, res, part=(0, 1), device=None):
     """read_hic_file's records for an intra-chromosomal run as hicfile.PackedContacts (int32 bin, int32 distance, float32
     value: what the GPU loader mst_band_scatter_packed takes) -- same record set as read_hic_file through the native reader,
     without the int64 / float64 COO triple; None when the chromosome has no contact.  Native backend only.
     part = (rank, ranks): one process per GPU on ONE chromosome -- this rank decodes only its share of the file's blocks
     (the ranks read the file once between them; normalize.band_from_packed exchanges the shares).  A share may be empty;
-    it is still returned, so that every rank takes part in the exchange."""
+    it is still returned, so that every rank takes part in the exchange.
+    With a GPU the read is STREAMED (normalize.read_hic_stream_to_device): slabs of records are copied to `device` (default:
+    the calling thread's current device -- pass it explicitly from a reader thread) while later blocks are still being
+    inflated, and the result holds device tensors; MUSTACHE_HIC_STREAM=0 keeps the one-shot read into page-locked arrays."""
     from .hicfile import read_intra_packed
     norm = "KR" if not norm_method else str(norm_method)
     alloc = None
@@ -189,7 +192,13 @@ def read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, res, part=(
             CHRM_SIZE = sizes[key]
         print("reading %s through the native .hic reader, packed records (MUSTACHE_HIC_BACKEND=auto|native|hicstraw)"
               % os.path.basename(str(f)))
-        pc = read_intra_packed(h, chr1, res, norm, int(distance_in_bp // res), int(CHRM_SIZE), alloc=alloc, part=part)
+        if alloc is not None and os.environ.get("MUSTACHE_HIC_STREAM", "1") != "0":
+            import torch
+            from .normalize import read_hic_stream_to_device
+            dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+            pc = read_hic_stream_to_device(h, chr1, res, norm, int(distance_in_bp // res), int(CHRM_SIZE), dev, part=part)
+        else:
+            pc = read_intra_packed(h, chr1, res, norm, int(distance_in_bp // res), int(CHRM_SIZE), alloc=alloc, part=part)
     if part[1] > 1:
         print("rank %d of %d decoded %d of the chromosome's %d .hic blocks (%d records) in %.3f s"
               % (part[0], part[1], pc.blocks_mine, pc.blocks_total, len(pc), pc.read_s), flush=True)

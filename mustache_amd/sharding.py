@@ -75,14 +75,16 @@ def all_gather_packed(x, dist_, v, n, device, group=None):
     dist.all_gather(metas, meta, group=group)
     counts = [int(m[0].item()) for m in metas]
     n_all = max(int(m[1].item()) for m in metas)
-    dbytes = np.dtype(dist_.dtype).itemsize
+    as_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))     # host arrays or tensors anywhere
+    x, dist_, v = as_t(x), as_t(dist_), as_t(v)
+    dbytes = dist_.element_size()
     mx = max(max(counts), 1)
     seg = [(-(-4 * mx // 16) * 16), (-(-dbytes * mx // 16) * 16), (-(-4 * mx // 16) * 16)]     # 16-byte aligned segments
     block = torch.zeros(sum(seg), dtype=torch.uint8, device=where)
     off = 0
     for arr, sz in zip((x, dist_, v), seg):
         if cnt:
-            src = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1))
+            src = arr.contiguous().view(torch.uint8).reshape(-1)
             block[off:off + src.numel()].copy_(src, non_blocking=on_dev)
         off += sz
     got = [torch.empty_like(block) for _ in range(ws)]

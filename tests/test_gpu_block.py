@@ -31,7 +31,7 @@ def eng():
 def test_library_loaded_is_in_tree():
     from mustache_amd import _lib
     lib = _lib.load()
-    assert lib.mst_abi_version() == 1
+    assert lib.mst_abi_version() == _lib.MST_ABI_VERSION
     assert os.path.dirname(_lib.LIB_PATH).endswith("mustache_amd")
 
 

@@ -776,3 +776,34 @@ def test_shared_tiles_equal_tiles_computed_per_block(n, dpx, res, octs):
     key = lambda r: (int(r[0]), int(r[1]))
     assert [(int(a), int(b), s_) for a, b, _, s_ in sorted(loops_shared, key=key)] == \
            [(int(a), int(b), s_) for a, b, _, s_ in sorted(loops_plain, key=key)]
+
+
+def test_streamed_hic_read_gives_the_one_shot_band(tmp_path):
+    """normalize.read_hic_stream_to_device (slabs copied to the device while later blocks inflate; what `-f x.hic` uses on a
+    GPU) delivers the record set of the one-shot packed read, and band_from_packed builds the identical band from either --
+    with slabs much smaller than the chromosome, so that many are in flight and reused."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from hic_writer import write_hic
+    from mustache_amd.hicfile import HicFile, read_intra_packed
+    from mustache_amd.normalize import band_from_packed, read_hic_stream_to_device
+    from mustache_amd.synth import synth_coo
+    res, dpx, n = 10000, 150, 5200
+    x, y, v = synth_coo(n, dpx, depth=200.0, seed=9)
+    near = (y - x) <= dpx
+    hic = str(tmp_path / "st.hic")
+    kr = np.random.default_rng(2).uniform(0.6, 1.7, n + 1)
+    write_hic(hic, [("All", 1), ("chrB", n * res)], {1: {res: (x[near], y[near], np.round(v[near]) + 1.0)}}, {("KR", 1, res): kr},
+              version=8, block_bin_count=128, float_counts=False)
+    dev = torch.device("cuda", 0)
+    with HicFile(hic) as h:
+        one = read_intra_packed(h, "chrB", res, "KR", dpx, 0)
+        st = read_hic_stream_to_device(h, "chrB", res, "KR", dpx, 0, dev, threads=4, slab_records=20000, n_slabs=6)
+    assert st.count == len(one) > 100000 and st.n == one.n and len(st.device_parts) > 8
+    sx, sy, sv = st.coo()
+    ox, oy, ov = one.coo()
+    so, oo = np.lexsort((sy, sx)), np.lexsort((oy, ox))
+    assert np.array_equal(sx[so], ox[oo]) and np.array_equal(sy[so], oy[oo]) and np.array_equal(sv[so], ov[oo])
+    assert torch.equal(band_from_packed(st, dpx, dev), band_from_packed(one, dpx, dev))
+    assert torch.equal(band_from_packed(st, dpx, dev, check=True), band_from_packed(one, dpx, dev))     # read-back check passes

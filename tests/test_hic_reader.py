@@ -35,7 +35,7 @@ def test_io_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(ROOT, "mustache_amd", "libmustache_io.so"))
     header = open(os.path.join(ROOT, "include", "mustache_io.h")).read()
     names = set(re.findall(r"\b(mst_(?:io|hic|text)_\w+)\s*\(", header))
-    assert len(names) == 18
+    assert len(names) == 23
     for n in names:
         assert hasattr(lib, n), n
     assert lib.mst_io_abi_version() == 2
@@ -257,3 +257,110 @@ def test_part_decodes_partition_the_chromosome(tmp_path, version, n_parts):
         allk = np.concatenate(keys)
         assert len(allk) == len(key_w) and np.array_equal(np.sort(allk), key_w)      # disjoint and complete
         assert min(len(k) for k in keys) > 0.5 * len(key_w) / n_parts                # shares balanced by compressed bytes
+
+
+def test_own_inflate_equals_zlib_on_arbitrary_streams():
+    """csrc/mst_inflate.h (the block reader's zlib-stream decoder) against zlib itself: stored / fixed / dynamic blocks at every
+    compression level on random, repetitive, low-entropy and row-list-like data; a flipped bit or a truncation is either
+    rejected or -- when zlib accepts the stream too -- decodes to zlib's bytes (the Adler-32 is verified)."""
+    import zlib
+    from mustache_amd import hicfile
+    lib = hicfile.load()
+
+    def inf(comp, cap):
+        out = (ctypes.c_uint8 * max(cap, 1))()
+        n = lib.mst_io_inflate(comp, len(comp), out, cap)
+        return n, bytes(out[:max(n, 0)])
+
+    rng = np.random.default_rng(0)
+    rows = np.cumsum(rng.integers(0, 3, 300000)).astype("<i2").tobytes()
+    for case in range(300):
+        kind = case % 5
+        m = int(rng.integers(0, 150000))
+        if kind == 0:
+            data = rng.integers(0, 256, m, dtype=np.uint8).tobytes()
+        elif kind == 1:
+            data = bytes(rng.integers(0, 4, m, dtype=np.uint8))
+        elif kind == 2:
+            data = (b"abcdefgh" * (m // 8 + 1))[:m]
+        elif kind == 3:
+            data = rows[:m]
+        else:
+            data = (rng.integers(0, 256, 40, dtype=np.uint8).tobytes() * (m // 40 + 1))[:m]      # long matches, distance 40
+        comp = zlib.compress(data, int(rng.integers(0, 10)))
+        n, out = inf(comp, len(data) + 300)
+        assert n == len(data) and out == data, (case, kind, m, n)
+        if len(comp) > 8:
+            bad = bytearray(comp)
+            bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            n2, out2 = inf(bytes(bad), len(data) + 300)
+            try:
+                z = zlib.decompress(bytes(bad))
+            except zlib.error:
+                z = None
+            assert n2 < 0 if z is None else (n2 >= 0 and out2 == z), (case, "flipped bit")
+            n3, _ = inf(comp[:int(rng.integers(0, len(comp)))], len(data) + 300)
+            assert n3 < 0, (case, "truncated stream accepted")
+    assert inf(zlib.compress(b"x" * 1000), 100)[0] == -1            # MST_IO_E_ARG: the output does not fit
+
+
+@pytest.mark.parametrize("version,float_counts,dense,short_coords,n_parts,dist_bytes", [
+    (8, True, False, True, 1, 2), (8, False, False, True, 2, 2), (9, True, False, False, 3, 4), (8, True, True, True, 1, 2),
+    (9, False, False, True, 1, 4)])
+def test_streamed_read_equals_packed_read(tmp_path, version, float_counts, dense, short_coords, n_parts, dist_bytes):
+    """mst_hic_stream_*: the slabs delivered by the streaming read hold exactly the records of the one-shot packed read
+    (which inflates through zlib here: MUSTACHE_HIC_ZLIB is honoured per process, so the comparison partner is produced by a
+    subprocess), for row-list and dense blocks, short and long coordinates, both distance widths, several parts."""
+    import subprocess
+    from mustache_amd.hicfile import HicFile, HicStream, read_intra_packed
+    n, res, dpx = 2500, 5000, 260
+    x, y, c = _contacts(n, 320, 50000, 7 * version + n_parts, integer=not float_counts)
+    norm = np.random.default_rng(5).uniform(0.5, 2.0, n + 1)
+    norm[[9, 300]] = np.nan
+    p = str(tmp_path / "s.hic")
+    write_hic(p, [("All", 7500), ("chr1", n * res)], {1: {res: (x, y, c)}}, {("KR", 1, res): norm}, version=version,
+              block_bin_count=64, float_counts=float_counts, dense_blocks=dense, short_coords=short_coords)
+    with HicFile(p) as h:
+        whole = read_intra_packed(h, "chr1", res, "KR", dpx, (n - 3) * res)
+        key_w = whole.x.astype(np.int64) * (1 << 20) + whole.dist
+        order_w = np.argsort(key_w)
+        cap, n_slabs = 6000, 5
+        mem = np.zeros(n_slabs * cap * (8 + dist_bytes), np.uint8)
+        got_k, got_v, blocks, top = [], [], 0, 0
+        for part in range(n_parts):
+            st = HicStream(h, "chr1", res, "KR", dpx, (n - 3) * res, mem.ctypes.data, n_slabs, cap, dist_bytes, threads=3,
+                           part=(part, n_parts))
+            while True:
+                r = st.next(50)
+                if r is None:
+                    continue
+                if r is False:
+                    break
+                slab, cnt = r
+                assert 0 < cnt <= cap
+                base = slab * cap * (8 + dist_bytes)
+                sx = mem[base:base + 4 * cnt].view(np.int32).astype(np.int64)
+                sv = mem[base + 4 * cap:base + 4 * cap + 4 * cnt].view(np.float32).copy()
+                sd = mem[base + 8 * cap:base + 8 * cap + dist_bytes * cnt].view(np.uint16 if dist_bytes == 2 else np.int32)
+                got_k.append(sx * (1 << 20) + sd.astype(np.int64))
+                got_v.append(sv)
+                st.release(slab)
+            st.close()
+            blocks += st.blocks_mine
+            top = max(top, st.n)
+            assert st.blocks_total == whole.blocks_total
+        k, v = np.concatenate(got_k), np.concatenate(got_v)
+        o = np.argsort(k)
+        assert blocks == whole.blocks_total and top == whole.n and len(k) == len(key_w) > 10000
+        assert np.array_equal(k[o], key_w[order_w]) and np.array_equal(v[o], whole.v[order_w])
+    # the same one-shot read through zlib (cross-check of the own inflate on real block payloads)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from mustache_amd.hicfile import HicFile, read_intra_packed\n"
+            "h = HicFile(%r); pc = read_intra_packed(h, 'chr1', %d, 'KR', %d, %d)\n"
+            "print(len(pc), int(pc.x.astype(np.int64).sum()), int(pc.dist.astype(np.int64).sum()), repr(float(pc.v.astype(np.float64).sum())))\n"
+            % (ROOT, p, res, dpx, (n - 3) * res))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MUSTACHE_HIC_ZLIB="1"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = "%d %d %d %r" % (len(whole), int(whole.x.astype(np.int64).sum()), int(whole.dist.astype(np.int64).sum()),
+                            float(whole.v.astype(np.float64).sum()))
+    assert r.stdout.strip() == want

@@ -122,6 +122,17 @@ int mst_found_pvalues(const mst_found *found, uint32_t found_cap, const uint32_t
                       const uint32_t *nz_count, const double *level_stats, int32_t B, int32_t n_tested,
                       double *pval, double *fit, void *stream);
 
+/* mst_found_pvalues with everything a caller needs next delivered in the SAME round trip (one stream synchronisation per launch
+ * instead of one per quantity): pix_out / lvl_out (dev [B][found_cap] int32 / uint8, each may be NULL) receive the records'
+ * pixel index and 1-based tested level as narrow arrays, and summary_host (page-locked host memory of
+ * mst_found_summary_bytes(B) bytes) receives {int32 flags, pad to 16 bytes | uint32 found_count[B] padded to an even count |
+ * uint32 nz_count[B] likewise | double fit[B][MST_MAX_TESTED][2]}.  scratch_dev: >= 16 bytes of device scratch.  Same error
+ * returns as mst_found_pvalues. */
+uint64_t mst_found_summary_bytes(int32_t B);
+int mst_found_finish(const mst_found *found, uint32_t found_cap, const uint32_t *found_count, const uint32_t *nz_count,
+                     const double *level_stats, int32_t B, int32_t n_tested, double *pval, double *fit, int32_t *pix_out,
+                     uint8_t *lvl_out, void *scratch_dev, void *summary_host, void *stream);
+
 /* mustache.py:778, multipletests(p, method='fdr_bh') per block, on the device: q[b][i] for the first count[b] records of
  * each block (sort ascending, p * m / rank with NumPy's operation order, suffix minimum, clip at 1, back to record order).
  * pval, q: dev [B][cap]; count: dev [B]; workspace: dev, >= mst_bh_workspace_bytes(B, cap). */

@@ -6,6 +6,7 @@
 // All of them touch a few thousand pixels per block; they exist so the tail never pulls a dense block to the host.
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "mst_common.h"
 
@@ -32,7 +33,8 @@ __global__ void fit_kernel(const double *__restrict__ level_stats, const uint32_
 // roundings (E = exp(-x); E - 1; negate; 1 - .) so tiny p-values land on the same 2^-53 grid points.
 __global__ void __launch_bounds__(256)
 pvalue_kernel(const mst_found *__restrict__ found, uint32_t found_cap, const uint32_t *__restrict__ found_count,
-              const double *__restrict__ fit, double *__restrict__ pval, int *__restrict__ flags) {
+              const double *__restrict__ fit, double *__restrict__ pval, int *__restrict__ flags,
+              int32_t *__restrict__ pix_out, uint8_t *__restrict__ lvl_out) {
     const int b = blockIdx.y;
     const uint32_t n = found_count[b];
     if (n > found_cap) {
@@ -57,6 +59,10 @@ pvalue_kernel(const mst_found *__restrict__ found, uint32_t found_cap, const uin
             cdf = 0.0;
         }
         pval[(size_t)b * found_cap + i] = 1.0 - cdf;
+        // the records' pixel index and level as separate narrow arrays (what a caller that downloads whole found sets copies:
+        // 4 + 1 + 8 bytes per record instead of 16 + 8, and no element-wise unpacking passes)
+        if (pix_out) pix_out[(size_t)b * found_cap + i] = (int32_t)rec.pixel;
+        if (lvl_out) lvl_out[(size_t)b * found_cap + i] = (uint8_t)rec.level;
     }
 }
 
@@ -349,12 +355,54 @@ extern "C" int mst_found_pvalues(const mst_found *found, uint32_t found_cap, con
     fit_kernel<<<B, 64, 0, s>>>(level_stats, nz_count, n_tested, fit, d_flags);
     MST_LAUNCH_CHECK();
     const int gx = (int)((found_cap + 255) / 256 < 256 ? (found_cap + 255) / 256 : 256);
-    pvalue_kernel<<<dim3(gx > 0 ? gx : 1, B), 256, 0, s>>>(found, found_cap, found_count, fit, pval, d_flags);
+    pvalue_kernel<<<dim3(gx > 0 ? gx : 1, B), 256, 0, s>>>(found, found_cap, found_count, fit, pval, d_flags, nullptr, nullptr);
     MST_LAUNCH_CHECK();
     int flags = 0;
     MST_HIP(hipMemcpyAsync(&flags, d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
     MST_HIP(hipStreamSynchronize(s));
     MST_HIP(hipFreeAsync(d_flags, s));
+    if (flags & 1)
+        return mst::fail(MST_E_OVERFLOW, "found-pixel capacity %u exceeded in at least one block", found_cap);
+#ifdef MST_PROFILE
+    if (getenv("MST_IGNORE_NONFINITE")) flags &= ~2;        // PROFILE builds only: timing ablations produce garbage statistics
+#endif
+    if (flags & 2)
+        return mst::fail(MST_E_NONFINITE, "non-finite DoG statistics (input block holds NaN/inf)");
+    return MST_OK;
+}
+
+extern "C" uint64_t mst_found_summary_bytes(int32_t B) {
+    if (B <= 0) return 0;
+    return 16 + 8 * (uint64_t)((B + 1) / 2) * 2 + sizeof(double) * 2 * MST_MAX_TESTED * (uint64_t)B;
+}
+
+extern "C" int mst_found_finish(const mst_found *found, uint32_t found_cap, const uint32_t *found_count,
+                                const uint32_t *nz_count, const double *level_stats, int32_t B, int32_t n_tested, double *pval,
+                                double *fit, int32_t *pix_out, uint8_t *lvl_out, void *scratch_dev, void *summary_host,
+                                void *stream) {
+    if (!found || !found_count || !nz_count || !level_stats || !pval || !fit || !scratch_dev || !summary_host || B <= 0 ||
+        B > 65535 || n_tested <= 0 || n_tested > MST_MAX_TESTED)
+        return mst::fail(MST_E_ARG, "mst_found_finish: bad argument");
+    hipStream_t s = mst::as_stream(stream);
+    int *d_flags = static_cast<int *>(scratch_dev);
+    MST_HIP(hipMemsetAsync(d_flags, 0, sizeof(int), s));
+    fit_kernel<<<B, 64, 0, s>>>(level_stats, nz_count, n_tested, fit, d_flags);
+    MST_LAUNCH_CHECK();
+    const int gx = (int)((found_cap + 255) / 256 < 256 ? (found_cap + 255) / 256 : 256);
+    pvalue_kernel<<<dim3(gx > 0 ? gx : 1, B), 256, 0, s>>>(found, found_cap, found_count, fit, pval, d_flags, pix_out, lvl_out);
+    MST_LAUNCH_CHECK();
+    // one round trip for everything the host needs before it can size its downloads: flags, record counts, tested-pixel counts
+    // and the fits.  summary_host (page-locked, mst_found_summary_bytes(B)): int32 flags, pad to 16 | uint32 found_count[B]
+    // (padded to a multiple of 2) | uint32 nz_count[B] (same) | double fit[B][MST_MAX_TESTED][2]
+    char *h = static_cast<char *>(summary_host);
+    const size_t cw = 8 * (size_t)((B + 1) / 2);
+    MST_HIP(hipMemcpyAsync(h, d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    MST_HIP(hipMemcpyAsync(h + 16, found_count, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, s));
+    MST_HIP(hipMemcpyAsync(h + 16 + cw, nz_count, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, s));
+    MST_HIP(hipMemcpyAsync(h + 16 + 2 * cw, fit, sizeof(double) * 2 * MST_MAX_TESTED * (size_t)B, hipMemcpyDeviceToHost, s));
+    MST_HIP(hipStreamSynchronize(s));
+    int flags = 0;
+    memcpy(&flags, h, sizeof(int));
     if (flags & 1)
         return mst::fail(MST_E_OVERFLOW, "found-pixel capacity %u exceeded in at least one block", found_cap);
 #ifdef MST_PROFILE

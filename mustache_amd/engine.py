@@ -356,7 +356,7 @@ class ScaleSpaceEngine:
         nz_count = torch.empty(len(starts), dtype=torch.int32, device=self.device)
         res = self.sigma_loop(None, None, nz_count, band_src=(band, int(n), int(dpx), [int(s) for s in starts], int(CH)),
                               **kw)
-        return res + (nz_count,)
+        return res + (nz_count,)       # (a record-capacity overflow re-ran the kernel into this same tensor)
 
     def sigma_loop(self, c, nz, nz_count, skip_empty=True, found_cap=None, download=True, timing=None, sort=True,
                    with_value=True, with_q=True, fma=False, band_src=None, select_below=None):
@@ -367,7 +367,8 @@ class ScaleSpaceEngine:
         on the launch stream.  `band_src` = (band, n, dpx, starts, CH) selects the band-direct kernel (c, nz unused;
         nz_count is then an OUTPUT)."""
         st = self._ss_launch(c, nz, nz_count, skip_empty, found_cap, timing, fma, band_src)
-        return self._ss_results(self._ss_finish(st), download, sort, with_value, with_q, select_below)
+        packed = download and select_below is None and not sort
+        return self._ss_results(self._ss_finish(st, packed=packed), download, sort, with_value, with_q, select_below)
 
     def _ss_launch(self, c, nz, nz_count, skip_empty, found_cap, timing, fma, band_src):
         """Allocate the outputs and enqueue the fused kernel on the current stream (no synchronisation)."""
@@ -406,15 +407,32 @@ class ScaleSpaceEngine:
         return dict(args=(c, nz, nz_count, skip_empty, timing, fma, band_src), B=B, CH=CH, found_cap=found_cap, ws=ws,
                     stats=stats, fit=fit, count=count, found=found, pval=pval, ev=ev)
 
-    def _ss_finish(self, st):
-        """p-values of the found pixels (synchronises the launch stream); a record-capacity overflow re-runs the kernel."""
+    def _summary_pin(self, B):
+        """Page-locked landing area of mst_found_finish's one round trip (flags, counts, tested-pixel counts, fits)."""
+        need = int(self.lib.mst_found_summary_bytes(B))
+        buf = self._pin.get(("summary", B))
+        if buf is None or buf.numel() < need:
+            buf = self._pin[("summary", B)] = torch.empty(need, dtype=torch.uint8, pin_memory=True)
+        return buf
+
+    def _ss_finish(self, st, packed=False):
+        """p-values of the found pixels (ONE synchronisation of the launch stream: mst_found_finish brings the overflow flag, the
+        record counts, the tested-pixel counts and the fits back in the same round trip); a record-capacity overflow re-runs the
+        kernel.  packed=True additionally leaves the records' pixel indices / levels as narrow device arrays (st["pix"], st["lvl"])
+        for a caller that downloads whole found sets."""
         nt = self.levels.n_tested
         with torch.cuda.device(self.device):
             while True:
+                B, cap = st["B"], st["found_cap"]
+                pix = torch.empty((B, cap), dtype=torch.int32, device=self.device) if packed else None
+                lvl = torch.empty((B, cap), dtype=torch.uint8, device=self.device) if packed else None
+                scratch = torch.empty(4, dtype=torch.int32, device=self.device)
+                summ = self._summary_pin(B)
                 try:
-                    _lib.check(self.lib.mst_found_pvalues(_ptr(st["found"]), st["found_cap"], _ptr(st["count"]),
-                                                          _ptr(st["args"][2]), _ptr(st["stats"]), st["B"], nt,
-                                                          _ptr(st["pval"]), _ptr(st["fit"]), _stream()))
+                    _lib.check(self.lib.mst_found_finish(_ptr(st["found"]), cap, _ptr(st["count"]), _ptr(st["args"][2]),
+                                                         _ptr(st["stats"]), B, nt, _ptr(st["pval"]), _ptr(st["fit"]),
+                                                         _ptr(pix), _ptr(lvl), _ptr(scratch), ctypes.c_void_p(summ.data_ptr()),
+                                                         _stream()))
                     break
                 except _lib.MstOverflow:
                     c, nz, nz_count, skip_empty, timing, fma, band_src = st["args"]
@@ -422,7 +440,14 @@ class ScaleSpaceEngine:
                     self._found_cap[st["CH"]] = cap
                     st = self._ss_launch(c, nz, nz_count, skip_empty, cap, timing, fma, band_src)
         if st["ev"] is not None:
-            st["args"][4].append(st["ev"])      # mst_found_pvalues synchronised the stream: the events are complete
+            st["args"][4].append(st["ev"])      # mst_found_finish synchronised the stream: the events are complete
+        h = summ.numpy()
+        cw = 8 * ((B + 1) // 2)
+        st["count_h"] = h[16:16 + 4 * B].view(np.uint32).astype(np.int64)
+        st["nz_h"] = h[16 + cw:16 + cw + 4 * B].view(np.uint32).astype(np.int64)
+        st["fit_h"] = h[16 + 2 * cw:16 + 2 * cw + 16 * _lib.MST_MAX_TESTED * B].view(np.float64).reshape(
+            B, _lib.MST_MAX_TESTED, 2).copy()
+        st["pix"], st["lvl"] = pix, lvl
         return st
 
     def _ss_results(self, st, download, sort, with_value, with_q, select_below):
@@ -430,10 +455,12 @@ class ScaleSpaceEngine:
         nt = self.levels.n_tested
         if not download:
             return found, pval, count, fit, found_cap
+        host = (st.get("count_h"), st.get("fit_h"))
         if select_below is not None:
-            return self._download_selected(found, pval, count, fit, nt, found_cap, float(select_below))
+            return self._download_selected(found, pval, count, fit, nt, found_cap, float(select_below), host=host)
         extra = {"q": self.fdr(pval, count, found_cap)} if with_q else None
-        return self._download(found, pval, count, fit, nt, sort=sort, with_value=with_value, extra=extra)
+        return self._download(found, pval, count, fit, nt, sort=sort, with_value=with_value, extra=extra, host=host,
+                              packed=(st.get("pix"), st.get("lvl")))
 
     def sigma_loop_band_overlapped(self, band, n, dpx, groups, CH, skip_empty=True, timing=None, fma=False, download=True,
                                    sort=True, with_value=True, with_q=True, select_below=None):
@@ -447,9 +474,12 @@ class ScaleSpaceEngine:
 
         def finish(st):
             with torch.cuda.stream(st["stream"]):
-                st2 = self._ss_finish(st)
+                st2 = self._ss_finish(st, packed=download and select_below is None and not sort)
                 res = self._ss_results(st2, download, sort, with_value, with_q, select_below)
-            return res + (st["nzc"],)
+            # the tested-pixel counts came back with the finish's round trip: hand them out as a HOST tensor (callers' .cpu() is
+            # then free) unless the caller asked for device buffers
+            nzc = torch.from_numpy(st2["nz_h"].astype(np.uint32).view(np.int32)) if download else st2["args"][2]
+            return res + (nzc,)
 
         pending = None
         for gi, starts in enumerate(groups):
@@ -483,7 +513,7 @@ class ScaleSpaceEngine:
             _lib.check(self.lib.mst_bh_fdr(_ptr(pval), _ptr(count), B, found_cap, _ptr(q), _ptr(ws), ws_bytes, _stream()))
         return q
 
-    def _download_selected(self, found, pval, count, fit, nt, found_cap, pt, full_sort=False, pair=None):
+    def _download_selected(self, found, pval, count, fit, nt, found_cap, pt, full_sort=False, pair=None, host=None):
         """BH-FDR and the selection q < pt on the device; only the selected records come back.  Default: mst_bh_select
         (sorts only the records that can be selected -- same selected set, bit-identical q); full_sort=True runs mst_bh_fdr
         over all records and then mst_select_below (kept as the cross-check).  pair = (ppair [2P, found_cap], P), two-sample
@@ -519,18 +549,35 @@ class ScaleSpaceEngine:
                 cap = self._select_cap = int(n_h.max()) * 2         # rare: re-run with room for every selected record
             mx = int(n_h.max(initial=0))
             extra_h = {}
+            self._pin_flip ^= 1
             if pair is not None:
                 ppair, P = pair
                 g = torch.empty((3, B, cap), dtype=torch.float64, device=self.device)
                 _lib.check(self.lib.mst_pair_gather(_ptr(found), found_cap, _ptr(count), _ptr(ppair), int(P), _ptr(idx),
                                                     _ptr(pix), _ptr(n_sel), cap, mx, _ptr(g[0]), _ptr(g[1]), _ptr(g[2]),
                                                     _stream()))
-                g_h = g[:, :, :max(mx, 1)].cpu().numpy()
+                g_p = self._pinned("sel_pair", (3, B, max(mx, 1)), torch.float64)       # lands with the batch below
+                g_p.copy_(g[:, :, :max(mx, 1)], non_blocking=True)
+                g_h = g_p.numpy()
                 extra_h = {"pair": g_h[0], "value": g_h[1], "v_other": g_h[2]}
-            pix_h = pix[:, :max(mx, 1)].cpu().numpy().view(np.uint32)
-            lvl_h = lvl[:, :max(mx, 1)].cpu().numpy().view(np.uint32)
-            q_h = qs[:, :max(mx, 1)].cpu().numpy()
-            fit_h = fit.cpu().numpy()
+            # the three record arrays in ONE round trip (page-locked staging, one synchronisation); the fits came back with
+            # mst_found_finish already when the caller has them
+            w = max(mx, 1)
+            pix_p = self._pinned("sel_pix", (B, w), torch.int32)
+            lvl_p = self._pinned("sel_lvl", (B, w), torch.int32)
+            q_p = self._pinned("sel_q", (B, w), torch.float64)
+            pix_p.copy_(pix[:, :w], non_blocking=True)
+            lvl_p.copy_(lvl[:, :w], non_blocking=True)
+            q_p.copy_(qs[:, :w], non_blocking=True)
+            fit_p = None
+            if host is None or host[1] is None:
+                fit_p = self._pinned("sel_fit", tuple(fit.shape), torch.float64)
+                fit_p.copy_(fit, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            pix_h = pix_p.numpy().view(np.uint32)
+            lvl_h = lvl_p.numpy().view(np.uint32)
+            q_h = q_p.numpy()
+            fit_h = fit_p.numpy() if fit_p is not None else host[1]
         out, fits = [], []
         for b in range(B):
             m = int(n_h[b])
@@ -552,15 +599,19 @@ class ScaleSpaceEngine:
             buf = self._pin[slot] = torch.empty(max(need, 1), dtype=dtype, pin_memory=True)
         return buf[:need].view(*shape)
 
-    def _download(self, found, pval, count, fit, nt, sort=True, extra=None, with_value=True):
+    def _download(self, found, pval, count, fit, nt, sort=True, extra=None, with_value=True, host=None, packed=None):
         """Found records -> host.  The kernel appends records per workgroup, so their order inside a block is
         arbitrary; with sort=True they are ordered by pixel index on the device first (row-major = the reference's nz
         order, which the tail's look-ups rely on).  The returned arrays are views into pinned staging memory (see
         _pinned); with_value=False leaves the winning DoG values on the device (only the two-sample path needs them)."""
         self._pin_flip ^= 1
-        cnt_d = count.to(torch.int64)
-        cnt = cnt_d.cpu().numpy()
-        fit_h = fit.cpu().numpy()
+        if host is not None and host[0] is not None:       # counts and fits came back with mst_found_finish's round trip
+            cnt, fit_h = host
+            cnt_d = count.to(torch.int64) if sort else None
+        else:
+            cnt_d = count.to(torch.int64)
+            cnt = cnt_d.cpu().numpy()
+            fit_h = fit.cpu().numpy()
         B = len(cnt)
         mx = int(cnt.max()) if B else 0
         out, fits = [], []
@@ -582,8 +633,12 @@ class ScaleSpaceEngine:
             pix_h = self._pinned("pix", (B, mx), torch.int32)
             lvl_h = self._pinned("lvl", (B, mx), torch.uint8)
             pv_h = self._pinned("pv", (B, mx), torch.float64)
-            pix_h.copy_((word & 0xFFFFFFFF).to(torch.int32), non_blocking=True)
-            lvl_h.copy_((word >> 32).to(torch.uint8), non_blocking=True)
+            if not sort and packed is not None and packed[0] is not None:
+                pix_h.copy_(packed[0][:, :mx], non_blocking=True)          # narrow arrays written by the p-value kernel
+                lvl_h.copy_(packed[1][:, :mx], non_blocking=True)
+            else:
+                pix_h.copy_((word & 0xFFFFFFFF).to(torch.int32), non_blocking=True)
+                lvl_h.copy_((word >> 32).to(torch.uint8), non_blocking=True)
             pv_h.copy_(pv, non_blocking=True)
             if with_value:
                 val_h = self._pinned("val", (B, mx), torch.int64)

@@ -40,3 +40,27 @@ for nt in (8, 16, 32, 64, 128, 256):
     print("threads %3d: decode %.4f s  pinned alloc %.4f s  fetch %.4f s  (%d records)" % (nt, t1 - t0, t2 - t1, t3 - t2, cnt),
           flush=True)
     h.close()
+
+# ---- round 4: the streamed read (own inflate, row-list decode into page-locked slabs, slabs uploaded while later blocks
+# inflate) next to it -- wall time until the records are in HBM; MUSTACHE_HIC_ZLIB=1 in the environment swaps zlib back in
+from mustache_amd.normalize import band_from_packed, read_hic_stream_to_device   # noqa: E402
+dev = torch.device("cuda:0")
+for nt in (8, 16, 24, 32, 48, 64):
+    h = HicFile(path)
+    ts = []
+    for rep in range(4):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        pc = read_hic_stream_to_device(h, "chr1", 1000, "KR", 2000, 0, dev, threads=nt, n_slabs=nt + 8)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        band = band_from_packed(pc, 2000, dev)
+        torch.cuda.synchronize()
+        t2 = time.time()
+        ts.append((t1 - t0, t2 - t1))
+        cnt = pc.count
+        del pc, band
+    best = min(ts[1:])
+    print("streamed, threads %3d: records in HBM after %.4f s, zero fill + scatter %.4f s  (%d records; first call %.4f s)"
+          % (nt, best[0], best[1], cnt, ts[0][0]), flush=True)
+    h.close()

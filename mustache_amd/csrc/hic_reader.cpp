@@ -306,7 +306,9 @@ bool block_near_diagonal(int32_t version, int32_t number, int32_t bbc, int32_t b
     }
     const int64_t r = number / bcc, col = number % bcc;                    // number = row * blockColumnCount + column
     const int64_t d = r > col ? r - col : col - r;
-    return d <= max_dist / bbc + 1;
+    // bins of block row r / column col differ by at least (d - 1) * blockBinCount + 1 when d >= 1 -- exact, so the blocks just
+    // beyond the distance limit (a few per cent of a 1 kb chromosome's compressed bytes) are not inflated for nothing
+    return d == 0 || (d - 1) * (int64_t)bbc + 1 <= max_dist;
 }
 
 struct Records {

@@ -599,7 +599,13 @@ int check_levels(const mst_levels *lv, int *max_radius, int *n_tested) {
 }
 
 using TileDefault = Tile<32, 64, 14>;   // the reference's default octaves (radius <= 14)
+#ifdef MST_EXP_WIDE64
+// Experiment (round 4, variant builds): the wide-radius tile with the default tile's 32 x 64 region -- 512 threads x 4 pixels,
+// ~131 KB of LDS, ONE workgroup of 8 waves per CU; 1.26 x fewer executed blur flops than the 32 x 32 region at radius 14-28
+using TileWide = Tile<32, 64, 28, 4, 1, false, true>;
+#else
 using TileWide = Tile<32, 32, 28, 4, 1>;   // -sz / -oc variants up to radius 28: 256 threads x 4 pixels (K = 8 spilled SGPRs and left half the SIMDs idle)
+#endif
 using TileDefaultFma = Tile<32, 64, 14, 8, 1, true>;   // opt-in relaxed arithmetic (MST_FLAG_FMA), default radii only
 #ifdef MST_EXP_TILE7
 // Experiment (round 4, variant builds only: scripts/build_variant.sh ... -DMST_EXP_TILE7=<waves per SIMD>): a tile for level

@@ -14,9 +14,17 @@ namespace {
 
 // {loc, scale} per (block, tested level):  loc = min|D|, scale = mean|D| - loc   (scipy expon.fit,
 // scipy/stats/_continuous_distns.py:2134-2147)
+// (summary: optional device image of mst_found_finish's host summary -- counts and fits are copied into it here, so that ONE
+// device-to-host copy brings everything back)
 __global__ void fit_kernel(const double *__restrict__ level_stats, const uint32_t *__restrict__ nz_count,
-                           int n_tested, double *__restrict__ fit, int *__restrict__ flags) {
+                           int n_tested, double *__restrict__ fit, int *__restrict__ flags,
+                           const uint32_t *__restrict__ found_count, char *__restrict__ summary, int B) {
     const int b = blockIdx.x, t = threadIdx.x;
+    if (summary && t == 0) {
+        const size_t cw = 8 * (size_t)((B + 1) / 2);
+        reinterpret_cast<uint32_t *>(summary + 16)[b] = found_count[b];
+        reinterpret_cast<uint32_t *>(summary + 16 + cw)[b] = nz_count[b];
+    }
     if (t >= n_tested) return;
     const double mn = level_stats[((size_t)b * MST_MAX_TESTED + t) * 2];
     const double sm = level_stats[((size_t)b * MST_MAX_TESTED + t) * 2 + 1];
@@ -25,6 +33,11 @@ __global__ void fit_kernel(const double *__restrict__ level_stats, const uint32_
     const double scale = sm / cnt - loc;
     fit[((size_t)b * MST_MAX_TESTED + t) * 2] = loc;
     fit[((size_t)b * MST_MAX_TESTED + t) * 2 + 1] = scale;
+    if (summary) {
+        double *sf = reinterpret_cast<double *>(summary + 16 + 2 * 8 * (size_t)((B + 1) / 2));
+        sf[((size_t)b * MST_MAX_TESTED + t) * 2] = loc;
+        sf[((size_t)b * MST_MAX_TESTED + t) * 2 + 1] = scale;
+    }
     if (nz_count[b] > 0 && !(isfinite(mn) && isfinite(sm))) atomicOr(flags, 2);
 }
 
@@ -352,7 +365,7 @@ extern "C" int mst_found_pvalues(const mst_found *found, uint32_t found_cap, con
     int *d_flags = nullptr;
     MST_HIP(hipMallocAsync((void **)&d_flags, sizeof(int), s));
     MST_HIP(hipMemsetAsync(d_flags, 0, sizeof(int), s));
-    fit_kernel<<<B, 64, 0, s>>>(level_stats, nz_count, n_tested, fit, d_flags);
+    fit_kernel<<<B, 64, 0, s>>>(level_stats, nz_count, n_tested, fit, d_flags, nullptr, nullptr, B);
     MST_LAUNCH_CHECK();
     const int gx = (int)((found_cap + 255) / 256 < 256 ? (found_cap + 255) / 256 : 256);
     pvalue_kernel<<<dim3(gx > 0 ? gx : 1, B), 256, 0, s>>>(found, found_cap, found_count, fit, pval, d_flags, nullptr, nullptr);
@@ -379,30 +392,34 @@ extern "C" uint64_t mst_found_summary_bytes(int32_t B) {
 extern "C" int mst_found_finish(const mst_found *found, uint32_t found_cap, const uint32_t *found_count,
                                 const uint32_t *nz_count, const double *level_stats, int32_t B, int32_t n_tested, double *pval,
                                 double *fit, int32_t *pix_out, uint8_t *lvl_out, void *scratch_dev, void *summary_host,
-                                void *stream) {
+                                uint32_t prefetch_cols, int32_t *pix_host, uint8_t *lvl_host, double *pval_host, void *stream) {
     if (!found || !found_count || !nz_count || !level_stats || !pval || !fit || !scratch_dev || !summary_host || B <= 0 ||
         B > 65535 || n_tested <= 0 || n_tested > MST_MAX_TESTED)
         return mst::fail(MST_E_ARG, "mst_found_finish: bad argument");
+    if (prefetch_cols > 0 && (!pix_out || !lvl_out || !pix_host || !lvl_host || !pval_host))
+        return mst::fail(MST_E_ARG, "mst_found_finish: a record prefetch needs pix_out / lvl_out and the three host arrays");
     hipStream_t s = mst::as_stream(stream);
-    int *d_flags = static_cast<int *>(scratch_dev);
-    MST_HIP(hipMemsetAsync(d_flags, 0, sizeof(int), s));
-    fit_kernel<<<B, 64, 0, s>>>(level_stats, nz_count, n_tested, fit, d_flags);
+    char *d_sum = static_cast<char *>(scratch_dev);           // device image of the summary (mst_found_summary_bytes(B))
+    int *d_flags = reinterpret_cast<int *>(d_sum);
+    MST_HIP(hipMemsetAsync(d_flags, 0, 16, s));
+    fit_kernel<<<B, 64, 0, s>>>(level_stats, nz_count, n_tested, fit, d_flags, found_count, d_sum, B);
     MST_LAUNCH_CHECK();
     const int gx = (int)((found_cap + 255) / 256 < 256 ? (found_cap + 255) / 256 : 256);
     pvalue_kernel<<<dim3(gx > 0 ? gx : 1, B), 256, 0, s>>>(found, found_cap, found_count, fit, pval, d_flags, pix_out, lvl_out);
     MST_LAUNCH_CHECK();
-    // one round trip for everything the host needs before it can size its downloads: flags, record counts, tested-pixel counts
-    // and the fits.  summary_host (page-locked, mst_found_summary_bytes(B)): int32 flags, pad to 16 | uint32 found_count[B]
-    // (padded to a multiple of 2) | uint32 nz_count[B] (same) | double fit[B][MST_MAX_TESTED][2]
-    char *h = static_cast<char *>(summary_host);
-    const size_t cw = 8 * (size_t)((B + 1) / 2);
-    MST_HIP(hipMemcpyAsync(h, d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
-    MST_HIP(hipMemcpyAsync(h + 16, found_count, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, s));
-    MST_HIP(hipMemcpyAsync(h + 16 + cw, nz_count, sizeof(uint32_t) * B, hipMemcpyDeviceToHost, s));
-    MST_HIP(hipMemcpyAsync(h + 16 + 2 * cw, fit, sizeof(double) * 2 * MST_MAX_TESTED * (size_t)B, hipMemcpyDeviceToHost, s));
+    // ONE copy for everything the host needs before it can size its downloads: flags, record counts, tested-pixel counts, fits
+    MST_HIP(hipMemcpyAsync(summary_host, d_sum, mst_found_summary_bytes(B), hipMemcpyDeviceToHost, s));
+    // ... and, speculatively, the first prefetch_cols records of every block (the caller's guess of the largest count: when it
+    // holds, the records are on the host after this call's single synchronisation and no second round trip is needed)
+    if (prefetch_cols > 0) {
+        const size_t w = prefetch_cols < found_cap ? prefetch_cols : found_cap;
+        MST_HIP(hipMemcpy2DAsync(pix_host, w * 4, pix_out, (size_t)found_cap * 4, w * 4, (size_t)B, hipMemcpyDeviceToHost, s));
+        MST_HIP(hipMemcpy2DAsync(lvl_host, w, lvl_out, (size_t)found_cap, w, (size_t)B, hipMemcpyDeviceToHost, s));
+        MST_HIP(hipMemcpy2DAsync(pval_host, w * 8, pval, (size_t)found_cap * 8, w * 8, (size_t)B, hipMemcpyDeviceToHost, s));
+    }
     MST_HIP(hipStreamSynchronize(s));
     int flags = 0;
-    memcpy(&flags, h, sizeof(int));
+    memcpy(&flags, summary_host, sizeof(int));
     if (flags & 1)
         return mst::fail(MST_E_OVERFLOW, "found-pixel capacity %u exceeded in at least one block", found_cap);
 #ifdef MST_PROFILE

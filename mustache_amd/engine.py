@@ -311,6 +311,7 @@ class ScaleSpaceEngine:
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.levels = LevelTable(octave_values, s)
         self._select_cap = 4096
+        self._prefetch_guess = {}       # CH -> record columns mst_found_finish copies to the host speculatively
         self._side_streams = None
         self._lv_struct = self.levels.as_struct()
         self._found_cap = {}
@@ -426,13 +427,21 @@ class ScaleSpaceEngine:
                 B, cap = st["B"], st["found_cap"]
                 pix = torch.empty((B, cap), dtype=torch.int32, device=self.device) if packed else None
                 lvl = torch.empty((B, cap), dtype=torch.uint8, device=self.device) if packed else None
-                scratch = torch.empty(4, dtype=torch.int32, device=self.device)
                 summ = self._summary_pin(B)
+                scratch = torch.empty(summ.numel(), dtype=torch.uint8, device=self.device)
+                # record prefetch (whole-found-set downloads): the largest count the last launch of this block size saw, + 5 %
+                guess = min(cap, self._prefetch_guess.get(st["CH"], 0)) if packed else 0
+                pre = None
+                if guess > 0:
+                    self._pin_flip ^= 1
+                    pre = (self._pinned("pix", (B, guess), torch.int32), self._pinned("lvl", (B, guess), torch.uint8),
+                           self._pinned("pv", (B, guess), torch.float64))
                 try:
                     _lib.check(self.lib.mst_found_finish(_ptr(st["found"]), cap, _ptr(st["count"]), _ptr(st["args"][2]),
                                                          _ptr(st["stats"]), B, nt, _ptr(st["pval"]), _ptr(st["fit"]),
                                                          _ptr(pix), _ptr(lvl), _ptr(scratch), ctypes.c_void_p(summ.data_ptr()),
-                                                         _stream()))
+                                                         guess, *((ctypes.c_void_p(t.data_ptr()) for t in pre) if pre else
+                                                                  (None, None, None)), _stream()))
                     break
                 except _lib.MstOverflow:
                     c, nz, nz_count, skip_empty, timing, fma, band_src = st["args"]
@@ -448,6 +457,13 @@ class ScaleSpaceEngine:
         st["fit_h"] = h[16 + 2 * cw:16 + 2 * cw + 16 * _lib.MST_MAX_TESTED * B].view(np.float64).reshape(
             B, _lib.MST_MAX_TESTED, 2).copy()
         st["pix"], st["lvl"] = pix, lvl
+        st["prefetched"] = None
+        if packed:
+            mx = int(st["count_h"].max(initial=0))
+            if pre is not None:
+                # the records are on the host already when the guess held; False = tried (the staging set is already flipped)
+                st["prefetched"] = pre + (guess,) if mx <= guess else False
+            self._prefetch_guess[st["CH"]] = mx + mx // 20 + 64
         return st
 
     def _ss_results(self, st, download, sort, with_value, with_q, select_below):
@@ -460,7 +476,7 @@ class ScaleSpaceEngine:
             return self._download_selected(found, pval, count, fit, nt, found_cap, float(select_below), host=host)
         extra = {"q": self.fdr(pval, count, found_cap)} if with_q else None
         return self._download(found, pval, count, fit, nt, sort=sort, with_value=with_value, extra=extra, host=host,
-                              packed=(st.get("pix"), st.get("lvl")))
+                              packed=(st.get("pix"), st.get("lvl")), prefetched=st.get("prefetched"))
 
     def sigma_loop_band_overlapped(self, band, n, dpx, groups, CH, skip_empty=True, timing=None, fma=False, download=True,
                                    sort=True, with_value=True, with_q=True, select_below=None):
@@ -599,12 +615,25 @@ class ScaleSpaceEngine:
             buf = self._pin[slot] = torch.empty(max(need, 1), dtype=dtype, pin_memory=True)
         return buf[:need].view(*shape)
 
-    def _download(self, found, pval, count, fit, nt, sort=True, extra=None, with_value=True, host=None, packed=None):
+    def _download(self, found, pval, count, fit, nt, sort=True, extra=None, with_value=True, host=None, packed=None,
+                  prefetched=None):
         """Found records -> host.  The kernel appends records per workgroup, so their order inside a block is
         arbitrary; with sort=True they are ordered by pixel index on the device first (row-major = the reference's nz
         order, which the tail's look-ups rely on).  The returned arrays are views into pinned staging memory (see
         _pinned); with_value=False leaves the winning DoG values on the device (only the two-sample path needs them)."""
-        self._pin_flip ^= 1
+        if prefetched and not sort and not extra and not with_value and host is not None:
+            # mst_found_finish already copied the records (its guess of the largest count held): nothing left to fetch
+            cnt, fit_h = host
+            pix_n = prefetched[0].numpy().view(np.uint32)
+            lvl_n, pv_n = prefetched[1].numpy(), prefetched[2].numpy()
+            out, fits = [], []
+            for b in range(len(cnt)):
+                m = int(cnt[b])
+                out.append(dict(pixel=pix_n[b, :m], level=lvl_n[b, :m], pval=pv_n[b, :m]))
+                fits.append((fit_h[b, :nt, 0].copy(), fit_h[b, :nt, 1].copy()))
+            return out, fits
+        if prefetched is None:
+            self._pin_flip ^= 1
         if host is not None and host[0] is not None:       # counts and fits came back with mst_found_finish's round trip
             cnt, fit_h = host
             cnt_d = count.to(torch.int64) if sort else None

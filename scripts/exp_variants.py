@@ -71,12 +71,12 @@ def main():
         one(blocks=int(os.environ.get("EXP_BLOCKS", "12")))       # EXP_BLOCKS=1: a launch's fixed cost shows
         return
     libs = [a for a in sys.argv[1:] if not a.startswith("--")]
-    for spec in libs:                      # path[@NAME=VALUE[,NAME=VALUE...]]  (extra environment for PROFILE builds)
+    for spec in libs:                      # path[@NAME=VALUE[;NAME=VALUE...]]  (extra environment for PROFILE builds)
         lib, _, extra = spec.partition("@")
         env = dict(os.environ)
         if lib != "default":
             env["MUSTACHE_HIP_LIB"] = os.path.abspath(lib)
-        for kv in filter(None, extra.split(",")):
+        for kv in filter(None, extra.split(";")):           # NAME=VALUE pairs separated by ';' (values may hold commas)
             k, _, v = kv.partition("=")
             env[k] = v
         t0 = time.time()

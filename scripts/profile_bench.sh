@@ -4,7 +4,7 @@
 # profiles/<tag>_summary.md comes from the same build on the same box.
 # usage: scripts/profile_bench.sh <tag>     (outputs under gpurun_out/prof_<tag>/; copy summary + json + csv into profiles/)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -114,19 +114,40 @@ def pmc(dirname, kernel_sub):
     return per
 
 traffic = {}
+# the PMC runs' own bench line says how many work items the launch that `value` times has (dense, tiles shared)
+pmc_line = {}
+try:
+    for l in open(os.path.join(src, "bench_pmc_FETCH_SIZE.log")):
+        if l.startswith("{"):
+            pmc_line = json.loads(l)
+except Exception:
+    pass
+prf = pmc_line.get("roofline", {})
+shared_items = (prf.get("work_items_per_launch") or [None])[0]
+
+
+def counters_of(grid_threads):
+    """counters of the first fused-kernel dispatch with that many threads (None: the largest dispatch), over all PMC passes"""
+    out = {}
+    for d in sorted(os.listdir(src)):
+        if d.startswith("pmc_"):
+            per = pmc(d, "scale_space_kernel")
+            if not per:
+                continue
+            want = grid_threads if grid_threads is not None else max(v["_grid"] for v in per.values())
+            hits = [k for k, v in per.items() if v["_grid"] == want]
+            if not hits:
+                continue
+            for k, v in per[min(hits)].items():
+                if k != "_grid":
+                    out[k] = v
+    return out
+
+
 lines += ["## PMC, the largest dispatch of the fused kernel on 12 blocks (192 Mpix): the dense launch with MST_FLAG_NO_SHARE "
           "(every tile once per block, 104 520 workgroups) -- the form comparable with rounds 1 and 2", ""]
-allc = {}
-for d in sorted(os.listdir(src)):
-    if d.startswith("pmc_"):
-        per = pmc(d, "scale_space_kernel")
-        if not per:
-            continue
-        big = max(v["_grid"] for v in per.values())
-        first = min(k for k, v in per.items() if v["_grid"] == big)
-        for k, v in per[first].items():
-            if k != "_grid":
-                allc[k] = v
+allc = counters_of(None)
+shared = counters_of(((shared_items + 7) // 8 * 8) * 256) if shared_items else {}
 lines += ["| counter | value |", "|---|---|"] + ["| %s | %.6g |" % kv for kv in sorted(allc.items())]
 px = 12 * 4000 * 4000
 if "FETCH_SIZE" in allc and "WRITE_SIZE" in allc:
@@ -139,6 +160,18 @@ if "FETCH_SIZE" in allc and "WRITE_SIZE" in allc:
                "bytes_per_launch": (fetch_b + write_b) / px * 124 * 4000 * 4000,
                "note": "FETCH_SIZE x2 (gfx950 correction), KiB units; measured on 12 blocks, scaled per pixel to the "
                        "124-block launch bench.py times"}
+    if "FETCH_SIZE" in shared and "WRITE_SIZE" in shared and prf.get("tiles"):
+        # the launch form bench.py times for `value`: dense, a tile inside two overlapping blocks computed once
+        sb = shared["FETCH_SIZE"] * 1024 * 2 + shared["WRITE_SIZE"] * 1024
+        computed_px = px * prf["work_items"] / float(prf["tiles"])
+        traffic.update({"launch_form": "dense, tiles shared (the launch `value` times): %d work items for %d tiles of 12 blocks"
+                                       % (prf["work_items"], prf["tiles"]),
+                        "bytes_per_launch_12_blocks_shared": sb, "bytes_per_computed_pixel": sb / computed_px,
+                        "bytes_per_block_pixel_shared": sb / px})
+        lines += ["", "The launch form bench.py times for `value` (dense, tiles of overlapping blocks computed once: %d work items "
+                  "instead of %d): fetch %.1f MB (x2-corrected) + write %.1f MB = **%.2f B per computed pixel** (%.2f B per block "
+                  "pixel)." % (prf["work_items"], prf["tiles"], shared["FETCH_SIZE"] * 2048 / 1e6, shared["WRITE_SIZE"] * 1024 / 1e6,
+                               sb / computed_px, sb / px)]
     lines += ["", "HBM traffic of the launch: fetch %.1f MB (x2-corrected) + write %.1f MB = **%.2f B/pixel** "
               "(algorithmic level-streaming model: 592 B/pixel.  With the dense-block source the input alone is 8 "
               "B/pixel + 1 B/pixel of mask; with the band source -- the default since r01e -- only the in-band part of "

@@ -341,7 +341,7 @@ def test_overlapped_launches_equal_one_launch():
     groups = [start[0:2], start[2:3], start[3:]]
     b = 0
     for starts_g, (recs, fits_g, nzc_g) in zip(groups, pipe.engine.sigma_loop_band_overlapped(band, n, dpx, groups, CH)):
-        assert torch.equal(nzc_g, nzc[b:b + len(starts_g)])
+        assert torch.equal(nzc_g.cpu(), nzc[b:b + len(starts_g)].cpu())
         for j in range(len(starts_g)):
             for k in ("pixel", "level", "value", "pval", "q"):
                 assert np.array_equal(recs[j][k], one[b + j][k]), (b + j, k)

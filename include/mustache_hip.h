@@ -123,19 +123,19 @@ int mst_found_pvalues(const mst_found *found, uint32_t found_cap, const uint32_t
                       double *pval, double *fit, void *stream);
 
 /* mst_found_pvalues with everything a caller needs next delivered in the SAME round trip (one stream synchronisation per launch
- * instead of one per quantity): pix_out / lvl_out (dev [B][found_cap] int32 / uint8, each may be NULL) receive the records'
- * pixel index and 1-based tested level as narrow arrays, and summary_host (page-locked host memory of
- * mst_found_summary_bytes(B) bytes) receives {int32 flags, pad to 16 bytes | uint32 found_count[B] padded to an even count |
- * uint32 nz_count[B] likewise | double fit[B][MST_MAX_TESTED][2]} in one copy (scratch_dev: device memory of the same size).
- * prefetch_cols > 0 additionally copies the first min(prefetch_cols, found_cap) records of every block -- pixel, level,
- * p-value -- into pix_host / lvl_host / pval_host (page-locked, dense [B][that many]) before the synchronisation: a caller
- * that downloads whole found sets passes its guess of the largest count and, when the counts in the summary confirm it, needs
- * no second round trip.  Same error returns as mst_found_pvalues. */
+ * instead of one per quantity).  summary_host (page-locked, mst_found_summary_bytes(B) bytes; scratch_dev: device memory of the
+ * same size) receives {int32 flags, pad to 16 bytes | uint32 found_count[B] padded to an even count | uint32 nz_count[B]
+ * likewise | double fit[B][MST_MAX_TESTED][2]} in one copy.  pack_pitch > 0: the first pack_pitch records of every block are
+ * also written as three narrow, densely pitched device arrays pix_out int32 / lvl_out uint8 / pv_out float64 [B][pack_pitch]
+ * (pixel index, 1-based tested level, p-value) -- what a caller that downloads whole found sets wants; with pix_host /
+ * lvl_host / pv_host (page-locked, same shapes; all three or none) they are copied to the host before the synchronisation, so a
+ * caller whose pack_pitch (its guess of the largest count) is confirmed by the summary needs no second round trip.
+ * Same error returns as mst_found_pvalues. */
 uint64_t mst_found_summary_bytes(int32_t B);
 int mst_found_finish(const mst_found *found, uint32_t found_cap, const uint32_t *found_count, const uint32_t *nz_count,
-                     const double *level_stats, int32_t B, int32_t n_tested, double *pval, double *fit, int32_t *pix_out,
-                     uint8_t *lvl_out, void *scratch_dev, void *summary_host, uint32_t prefetch_cols, int32_t *pix_host,
-                     uint8_t *lvl_host, double *pval_host, void *stream);
+                     const double *level_stats, int32_t B, int32_t n_tested, double *pval, double *fit, uint32_t pack_pitch,
+                     int32_t *pix_out, uint8_t *lvl_out, double *pv_out, void *scratch_dev, void *summary_host,
+                     int32_t *pix_host, uint8_t *lvl_host, double *pv_host, void *stream);
 
 /* mustache.py:778, multipletests(p, method='fdr_bh') per block, on the device: q[b][i] for the first count[b] records of
  * each block (sort ascending, p * m / rank with NumPy's operation order, suffix minimum, clip at 1, back to record order).

@@ -47,7 +47,7 @@ __global__ void fit_kernel(const double *__restrict__ level_stats, const uint32_
 __global__ void __launch_bounds__(256)
 pvalue_kernel(const mst_found *__restrict__ found, uint32_t found_cap, const uint32_t *__restrict__ found_count,
               const double *__restrict__ fit, double *__restrict__ pval, int *__restrict__ flags,
-              int32_t *__restrict__ pix_out, uint8_t *__restrict__ lvl_out) {
+              int32_t *__restrict__ pix_out, uint8_t *__restrict__ lvl_out, double *__restrict__ pv_out, uint32_t pitch) {
     const int b = blockIdx.y;
     const uint32_t n = found_count[b];
     if (n > found_cap) {
@@ -72,10 +72,13 @@ pvalue_kernel(const mst_found *__restrict__ found, uint32_t found_cap, const uin
             cdf = 0.0;
         }
         pval[(size_t)b * found_cap + i] = 1.0 - cdf;
-        // the records' pixel index and level as separate narrow arrays (what a caller that downloads whole found sets copies:
-        // 4 + 1 + 8 bytes per record instead of 16 + 8, and no element-wise unpacking passes)
-        if (pix_out) pix_out[(size_t)b * found_cap + i] = (int32_t)rec.pixel;
-        if (lvl_out) lvl_out[(size_t)b * found_cap + i] = (uint8_t)rec.level;
+        // the first `pitch` records of the block once more as three narrow, densely pitched arrays: what a caller that downloads
+        // whole found sets copies -- 4 + 1 + 8 bytes per record in three CONTIGUOUS transfers, no element-wise unpacking passes
+        if (pix_out && i < pitch) {
+            pix_out[(size_t)b * pitch + i] = (int32_t)rec.pixel;
+            lvl_out[(size_t)b * pitch + i] = (uint8_t)rec.level;
+            pv_out[(size_t)b * pitch + i] = 1.0 - cdf;
+        }
     }
 }
 
@@ -368,7 +371,8 @@ extern "C" int mst_found_pvalues(const mst_found *found, uint32_t found_cap, con
     fit_kernel<<<B, 64, 0, s>>>(level_stats, nz_count, n_tested, fit, d_flags, nullptr, nullptr, B);
     MST_LAUNCH_CHECK();
     const int gx = (int)((found_cap + 255) / 256 < 256 ? (found_cap + 255) / 256 : 256);
-    pvalue_kernel<<<dim3(gx > 0 ? gx : 1, B), 256, 0, s>>>(found, found_cap, found_count, fit, pval, d_flags, nullptr, nullptr);
+    pvalue_kernel<<<dim3(gx > 0 ? gx : 1, B), 256, 0, s>>>(found, found_cap, found_count, fit, pval, d_flags, nullptr, nullptr,
+                                                           nullptr, 0);
     MST_LAUNCH_CHECK();
     int flags = 0;
     MST_HIP(hipMemcpyAsync(&flags, d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -391,13 +395,16 @@ extern "C" uint64_t mst_found_summary_bytes(int32_t B) {
 
 extern "C" int mst_found_finish(const mst_found *found, uint32_t found_cap, const uint32_t *found_count,
                                 const uint32_t *nz_count, const double *level_stats, int32_t B, int32_t n_tested, double *pval,
-                                double *fit, int32_t *pix_out, uint8_t *lvl_out, void *scratch_dev, void *summary_host,
-                                uint32_t prefetch_cols, int32_t *pix_host, uint8_t *lvl_host, double *pval_host, void *stream) {
+                                double *fit, uint32_t pack_pitch, int32_t *pix_out, uint8_t *lvl_out, double *pv_out,
+                                void *scratch_dev, void *summary_host, int32_t *pix_host, uint8_t *lvl_host, double *pv_host,
+                                void *stream) {
     if (!found || !found_count || !nz_count || !level_stats || !pval || !fit || !scratch_dev || !summary_host || B <= 0 ||
         B > 65535 || n_tested <= 0 || n_tested > MST_MAX_TESTED)
         return mst::fail(MST_E_ARG, "mst_found_finish: bad argument");
-    if (prefetch_cols > 0 && (!pix_out || !lvl_out || !pix_host || !lvl_host || !pval_host))
-        return mst::fail(MST_E_ARG, "mst_found_finish: a record prefetch needs pix_out / lvl_out and the three host arrays");
+    if (pack_pitch > 0 && (!pix_out || !lvl_out || !pv_out))
+        return mst::fail(MST_E_ARG, "mst_found_finish: pack_pitch > 0 needs pix_out, lvl_out and pv_out");
+    if (pix_host && (pack_pitch == 0 || !lvl_host || !pv_host))
+        return mst::fail(MST_E_ARG, "mst_found_finish: the record prefetch needs pack_pitch > 0 and all three host arrays");
     hipStream_t s = mst::as_stream(stream);
     char *d_sum = static_cast<char *>(scratch_dev);           // device image of the summary (mst_found_summary_bytes(B))
     int *d_flags = reinterpret_cast<int *>(d_sum);
@@ -405,17 +412,18 @@ extern "C" int mst_found_finish(const mst_found *found, uint32_t found_cap, cons
     fit_kernel<<<B, 64, 0, s>>>(level_stats, nz_count, n_tested, fit, d_flags, found_count, d_sum, B);
     MST_LAUNCH_CHECK();
     const int gx = (int)((found_cap + 255) / 256 < 256 ? (found_cap + 255) / 256 : 256);
-    pvalue_kernel<<<dim3(gx > 0 ? gx : 1, B), 256, 0, s>>>(found, found_cap, found_count, fit, pval, d_flags, pix_out, lvl_out);
+    pvalue_kernel<<<dim3(gx > 0 ? gx : 1, B), 256, 0, s>>>(found, found_cap, found_count, fit, pval, d_flags,
+                                                           pack_pitch ? pix_out : nullptr, lvl_out, pv_out, pack_pitch);
     MST_LAUNCH_CHECK();
     // ONE copy for everything the host needs before it can size its downloads: flags, record counts, tested-pixel counts, fits
     MST_HIP(hipMemcpyAsync(summary_host, d_sum, mst_found_summary_bytes(B), hipMemcpyDeviceToHost, s));
-    // ... and, speculatively, the first prefetch_cols records of every block (the caller's guess of the largest count: when it
-    // holds, the records are on the host after this call's single synchronisation and no second round trip is needed)
-    if (prefetch_cols > 0) {
-        const size_t w = prefetch_cols < found_cap ? prefetch_cols : found_cap;
-        MST_HIP(hipMemcpy2DAsync(pix_host, w * 4, pix_out, (size_t)found_cap * 4, w * 4, (size_t)B, hipMemcpyDeviceToHost, s));
-        MST_HIP(hipMemcpy2DAsync(lvl_host, w, lvl_out, (size_t)found_cap, w, (size_t)B, hipMemcpyDeviceToHost, s));
-        MST_HIP(hipMemcpy2DAsync(pval_host, w * 8, pval, (size_t)found_cap * 8, w * 8, (size_t)B, hipMemcpyDeviceToHost, s));
+    // ... and, speculatively, the packed records (the caller sized pack_pitch to its guess of the largest count: when the counts
+    // in the summary confirm it, the records are on the host after this call's single synchronisation)
+    if (pix_host) {
+        const size_t m = (size_t)B * pack_pitch;
+        MST_HIP(hipMemcpyAsync(pix_host, pix_out, m * 4, hipMemcpyDeviceToHost, s));
+        MST_HIP(hipMemcpyAsync(lvl_host, lvl_out, m, hipMemcpyDeviceToHost, s));
+        MST_HIP(hipMemcpyAsync(pv_host, pv_out, m * 8, hipMemcpyDeviceToHost, s));
     }
     MST_HIP(hipStreamSynchronize(s));
     int flags = 0;

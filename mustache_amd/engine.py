@@ -425,23 +425,26 @@ class ScaleSpaceEngine:
         with torch.cuda.device(self.device):
             while True:
                 B, cap = st["B"], st["found_cap"]
-                pix = torch.empty((B, cap), dtype=torch.int32, device=self.device) if packed else None
-                lvl = torch.empty((B, cap), dtype=torch.uint8, device=self.device) if packed else None
+                # whole-found-set downloads: the first `pitch` records of every block also come out as narrow, densely
+                # pitched arrays and are copied to the host inside the same call; pitch = the largest count the last launch of
+                # this block size saw + 5 % (the first launch of a size has no guess and takes the two-step download)
+                pitch = min(cap, self._prefetch_guess.get(st["CH"], 0)) if packed else 0
                 summ = self._summary_pin(B)
                 scratch = torch.empty(summ.numel(), dtype=torch.uint8, device=self.device)
-                # record prefetch (whole-found-set downloads): the largest count the last launch of this block size saw, + 5 %
-                guess = min(cap, self._prefetch_guess.get(st["CH"], 0)) if packed else 0
-                pre = None
-                if guess > 0:
+                dev3 = host3 = None
+                if pitch > 0:
+                    dev3 = (torch.empty((B, pitch), dtype=torch.int32, device=self.device),
+                            torch.empty((B, pitch), dtype=torch.uint8, device=self.device),
+                            torch.empty((B, pitch), dtype=torch.float64, device=self.device))
                     self._pin_flip ^= 1
-                    pre = (self._pinned("pix", (B, guess), torch.int32), self._pinned("lvl", (B, guess), torch.uint8),
-                           self._pinned("pv", (B, guess), torch.float64))
+                    host3 = (self._pinned("pix", (B, pitch), torch.int32), self._pinned("lvl", (B, pitch), torch.uint8),
+                             self._pinned("pv", (B, pitch), torch.float64))
+                vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
                 try:
                     _lib.check(self.lib.mst_found_finish(_ptr(st["found"]), cap, _ptr(st["count"]), _ptr(st["args"][2]),
-                                                         _ptr(st["stats"]), B, nt, _ptr(st["pval"]), _ptr(st["fit"]),
-                                                         _ptr(pix), _ptr(lvl), _ptr(scratch), ctypes.c_void_p(summ.data_ptr()),
-                                                         guess, *((ctypes.c_void_p(t.data_ptr()) for t in pre) if pre else
-                                                                  (None, None, None)), _stream()))
+                                                         _ptr(st["stats"]), B, nt, _ptr(st["pval"]), _ptr(st["fit"]), pitch,
+                                                         *(vp(t) for t in (dev3 or (None, None, None))), _ptr(scratch),
+                                                         vp(summ), *(vp(t) for t in (host3 or (None, None, None))), _stream()))
                     break
                 except _lib.MstOverflow:
                     c, nz, nz_count, skip_empty, timing, fma, band_src = st["args"]
@@ -456,13 +459,12 @@ class ScaleSpaceEngine:
         st["nz_h"] = h[16 + cw:16 + cw + 4 * B].view(np.uint32).astype(np.int64)
         st["fit_h"] = h[16 + 2 * cw:16 + 2 * cw + 16 * _lib.MST_MAX_TESTED * B].view(np.float64).reshape(
             B, _lib.MST_MAX_TESTED, 2).copy()
-        st["pix"], st["lvl"] = pix, lvl
         st["prefetched"] = None
         if packed:
             mx = int(st["count_h"].max(initial=0))
-            if pre is not None:
+            if host3 is not None:
                 # the records are on the host already when the guess held; False = tried (the staging set is already flipped)
-                st["prefetched"] = pre + (guess,) if mx <= guess else False
+                st["prefetched"] = host3 if mx <= pitch else False
             self._prefetch_guess[st["CH"]] = mx + mx // 20 + 64
         return st
 
@@ -476,7 +478,7 @@ class ScaleSpaceEngine:
             return self._download_selected(found, pval, count, fit, nt, found_cap, float(select_below), host=host)
         extra = {"q": self.fdr(pval, count, found_cap)} if with_q else None
         return self._download(found, pval, count, fit, nt, sort=sort, with_value=with_value, extra=extra, host=host,
-                              packed=(st.get("pix"), st.get("lvl")), prefetched=st.get("prefetched"))
+                              prefetched=st.get("prefetched"))
 
     def sigma_loop_band_overlapped(self, band, n, dpx, groups, CH, skip_empty=True, timing=None, fma=False, download=True,
                                    sort=True, with_value=True, with_q=True, select_below=None):
@@ -615,8 +617,7 @@ class ScaleSpaceEngine:
             buf = self._pin[slot] = torch.empty(max(need, 1), dtype=dtype, pin_memory=True)
         return buf[:need].view(*shape)
 
-    def _download(self, found, pval, count, fit, nt, sort=True, extra=None, with_value=True, host=None, packed=None,
-                  prefetched=None):
+    def _download(self, found, pval, count, fit, nt, sort=True, extra=None, with_value=True, host=None, prefetched=None):
         """Found records -> host.  The kernel appends records per workgroup, so their order inside a block is
         arbitrary; with sort=True they are ordered by pixel index on the device first (row-major = the reference's nz
         order, which the tail's look-ups rely on).  The returned arrays are views into pinned staging memory (see
@@ -662,12 +663,8 @@ class ScaleSpaceEngine:
             pix_h = self._pinned("pix", (B, mx), torch.int32)
             lvl_h = self._pinned("lvl", (B, mx), torch.uint8)
             pv_h = self._pinned("pv", (B, mx), torch.float64)
-            if not sort and packed is not None and packed[0] is not None:
-                pix_h.copy_(packed[0][:, :mx], non_blocking=True)          # narrow arrays written by the p-value kernel
-                lvl_h.copy_(packed[1][:, :mx], non_blocking=True)
-            else:
-                pix_h.copy_((word & 0xFFFFFFFF).to(torch.int32), non_blocking=True)
-                lvl_h.copy_((word >> 32).to(torch.uint8), non_blocking=True)
+            pix_h.copy_((word & 0xFFFFFFFF).to(torch.int32), non_blocking=True)
+            lvl_h.copy_((word >> 32).to(torch.uint8), non_blocking=True)
             pv_h.copy_(pv, non_blocking=True)
             if with_value:
                 val_h = self._pinned("val", (B, mx), torch.int64)

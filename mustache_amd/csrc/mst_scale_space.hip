@@ -151,6 +151,24 @@ struct WorkItem {
     int32_t y0, x0, b, delta2;      // delta2 != 0: also delivered to block b + 1 (delta2 = start_b - start_{b+1} < 0)
 };
 
+// The kernel's argument block as the hardware lays it out (each argument at its natural alignment, in order): the wide-radius
+// instantiation re-reads the arguments only its EPILOGUE needs from there, so that they do not occupy scalar registers through
+// the level loop (29 taps of two registers each leave none to spare; the default tile is untouched).
+struct KernArgs {
+    const double *c;
+    const uint8_t *nz;
+    BandSrc src;
+    int CH;
+    const DevLevels *lv;
+    mst_found *found;
+    uint32_t found_cap;
+    uint32_t *found_count;
+    double *partial;
+    const WorkItem *items;
+    int n_items, n_tested, skip_empty, variant;
+    unsigned long long *trace;
+};
+
 template <class T, bool BAND>
 __global__ void __launch_bounds__(T::NT, T::MINW)
 scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz, BandSrc src, int CH,
@@ -487,6 +505,22 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
     // ---- found pixels -> per-block record list.  One atomicAdd per WORKGROUP reserves its slots (a returning atomic
     // per pixel serialises ~150k same-address operations per block at the L2); inside the reservation the order is
     // wave, then k, then lane.  The list is sorted by pixel index before it reaches the host.
+    int e_b = b, e_b2 = b2, e_x0 = x0, e_delta2 = item.delta2, e_CH = CH;      // what the epilogue needs of the work item
+    if constexpr (T::RMAX > 14) {
+        typedef const KernArgs __attribute__((address_space(4))) *KernArgsPtr;       // constant address space: scalar loads
+        KernArgsPtr ka = (KernArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        found = ka->found;
+        found_cap = ka->found_cap;
+        found_count = ka->found_count;
+        n_tested = ka->n_tested;
+        part = ka->partial + (size_t)slot * n_tested * 2;
+        const WorkItem again = ka->items[slot];
+        e_b = again.b;
+        e_b2 = again.delta2 != 0 ? again.b + 1 : -1;
+        e_x0 = again.x0;
+        e_delta2 = again.delta2;
+        e_CH = ka->CH;
+    }
     uint32_t my_total = 0;
     uint32_t before[K];                 // records of this wave that precede mine for the same k
     uint32_t kbase[K];                  // records of this wave for smaller k
@@ -508,8 +542,8 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
             cnt_lds[w] = tot;
             tot += n;
         }
-        cnt_lds[T::NW] = tot ? atomicAdd(found_count + b, tot) : 0u;
-        cnt_lds[T::NW + 1] = (tot && b2 >= 0) ? atomicAdd(found_count + b2, tot) : 0u;
+        cnt_lds[T::NW] = tot ? atomicAdd(found_count + e_b, tot) : 0u;
+        cnt_lds[T::NW + 1] = (tot && e_b2 >= 0) ? atomicAdd(found_count + e_b2, tot) : 0u;
     }
     __syncthreads();
     const uint32_t wave_base = cnt_lds[T::NW] + cnt_lds[wave];
@@ -519,13 +553,13 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
         if (lvl[k]) {
             const uint32_t off = kbase[k] + before[k];
             mst_found rec;
-            rec.pixel = (uint32_t)gy * (uint32_t)CH + (uint32_t)(x0 + cg * K + k);
+            rec.pixel = (uint32_t)gy * (uint32_t)e_CH + (uint32_t)(e_x0 + cg * K + k);
             rec.level = lvl[k];
             rec.value = best[k];
-            if (wave_base + off < found_cap) found[(size_t)b * found_cap + wave_base + off] = rec;
-            if (b2 >= 0 && wave_base2 + off < found_cap) {          // the same pixel in the neighbouring block's coordinates
-                rec.pixel = (uint32_t)(gy + item.delta2) * (uint32_t)CH + (uint32_t)(x0 + cg * K + k + item.delta2);
-                found[(size_t)b2 * found_cap + wave_base2 + off] = rec;
+            if (wave_base + off < found_cap) found[(size_t)e_b * found_cap + wave_base + off] = rec;
+            if (e_b2 >= 0 && wave_base2 + off < found_cap) {        // the same pixel in the neighbouring block's coordinates
+                rec.pixel = (uint32_t)(gy + e_delta2) * (uint32_t)e_CH + (uint32_t)(e_x0 + cg * K + k + e_delta2);
+                found[(size_t)e_b2 * found_cap + wave_base2 + off] = rec;
             }
         }
     }
@@ -599,13 +633,11 @@ int check_levels(const mst_levels *lv, int *max_radius, int *n_tested) {
 }
 
 using TileDefault = Tile<32, 64, 14>;   // the reference's default octaves (radius <= 14)
-#ifdef MST_EXP_WIDE64
-// Experiment (round 4, variant builds): the wide-radius tile with the default tile's 32 x 64 region -- 512 threads x 4 pixels,
-// ~131 KB of LDS, ONE workgroup of 8 waves per CU; 1.26 x fewer executed blur flops than the 32 x 32 region at radius 14-28
+// -sz / -oc variants up to radius 28: the default tile's 32 x 64 region with 512 threads x 4 pixels and tight LDS pitches
+// (131 KB: ONE workgroup of 8 waves per CU, 155 VGPRs).  Round 4 measured it against the 32 x 32 / 256-thread tile of rounds 2-3
+// (two workgroups per CU, 251 VGPRs, 1.26 x more executed blur flops): octaves (3.2, 6.4) 45.6 -> 25.4 ms per 12 blocks dense,
+// 18.8 -> 10.2 ms with the tile list, identical found sets (LABBOOK.md R4.2)
 using TileWide = Tile<32, 64, 28, 4, 1, false, true>;
-#else
-using TileWide = Tile<32, 32, 28, 4, 1>;   // -sz / -oc variants up to radius 28: 256 threads x 4 pixels (K = 8 spilled SGPRs and left half the SIMDs idle)
-#endif
 using TileDefaultFma = Tile<32, 64, 14, 8, 1, true>;   // opt-in relaxed arithmetic (MST_FLAG_FMA), default radii only
 #ifdef MST_EXP_TILE7
 // Experiment (round 4, variant builds only: scripts/build_variant.sh ... -DMST_EXP_TILE7=<waves per SIMD>): a tile for level

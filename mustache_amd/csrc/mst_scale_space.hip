@@ -632,7 +632,13 @@ int check_levels(const mst_levels *lv, int *max_radius, int *n_tested) {
     return MST_OK;
 }
 
+#ifdef MST_EXP_DEFAULT_COLS
+// Experiment (round 4, variant builds): the default radii on a K = 4 tile of MST_EXP_DEFAULT_COLS columns -- 96: 768 threads =
+// 12 waves = THREE per SIMD in one workgroup per CU (<= 168 VGPRs, ~115 KB of LDS); 64: 512 threads, two per SIMD
+using TileDefault = Tile<32, MST_EXP_DEFAULT_COLS, 14, 4, 1, false, true>;
+#else
 using TileDefault = Tile<32, 64, 14>;   // the reference's default octaves (radius <= 14)
+#endif
 // -sz / -oc variants up to radius 28: the default tile's 32 x 64 region with 512 threads x 4 pixels and tight LDS pitches
 // (131 KB: ONE workgroup of 8 waves per CU, 155 VGPRs).  Round 4 measured it against the 32 x 32 / 256-thread tile of rounds 2-3
 // (two workgroups per CU, 251 VGPRs, 1.26 x more executed blur flops): octaves (3.2, 6.4) 45.6 -> 25.4 ms per 12 blocks dense,

@@ -384,12 +384,13 @@ class ScaleSpaceEngine:
         lv = ctypes.byref(self._lv_struct)
         ws_bytes = int(self.lib.mst_scale_space_workspace_bytes(B, CH, lv))
         with torch.cuda.device(self.device):
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
-            stats = torch.empty((B, _lib.MST_MAX_TESTED, 2), dtype=torch.float64, device=self.device)
-            fit = torch.empty((B, _lib.MST_MAX_TESTED, 2), dtype=torch.float64, device=self.device)
-            count = torch.empty(B, dtype=torch.int32, device=self.device)
-            found = torch.empty((B, found_cap, 2), dtype=torch.int64, device=self.device)  # 16-byte records
-            pval = torch.empty((B, found_cap), dtype=torch.float64, device=self.device)
+            # one allocation, six views (a launch of six 2000 x 2000 blocks is 1.75 ms of kernel: every allocator call counts)
+            T = _lib.MST_MAX_TESTED
+            ws, stats, fit, count, found, pval = self._carve(
+                (ws_bytes, torch.uint8, (ws_bytes,)), (B * T * 16, torch.float64, (B, T, 2)),
+                (B * T * 16, torch.float64, (B, T, 2)), (B * 4, torch.int32, (B,)),
+                (B * found_cap * 16, torch.int64, (B, found_cap, 2)),            # 16-byte records
+                (B * found_cap * 8, torch.float64, (B, found_cap)))
             ev = None
             if timing is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -407,6 +408,15 @@ class ScaleSpaceEngine:
                 ev[1].record()
         return dict(args=(c, nz, nz_count, skip_empty, timing, fma, band_src), B=B, CH=CH, found_cap=found_cap, ws=ws,
                     stats=stats, fit=fit, count=count, found=found, pval=pval, ev=ev)
+
+    def _carve(self, *parts):
+        """One device allocation cut into typed views: parts = (bytes, dtype, shape); every view starts 256-byte aligned."""
+        offs, total = [], 0
+        for nbytes, _, _ in parts:
+            offs.append(total)
+            total += -(-int(nbytes) // 256) * 256
+        arena = torch.empty(max(total, 256), dtype=torch.uint8, device=self.device)
+        return tuple(arena[o:o + int(nb)].view(dt).view(*shape) for o, (nb, dt, shape) in zip(offs, parts))
 
     def _summary_pin(self, B):
         """Page-locked landing area of mst_found_finish's one round trip (flags, counts, tested-pixel counts, fits)."""
@@ -430,15 +440,18 @@ class ScaleSpaceEngine:
                 # this block size saw + 5 % (the first launch of a size has no guess and takes the two-step download)
                 pitch = min(cap, self._prefetch_guess.get(st["CH"], 0)) if packed else 0
                 summ = self._summary_pin(B)
-                scratch = torch.empty(summ.numel(), dtype=torch.uint8, device=self.device)
                 dev3 = host3 = None
                 if pitch > 0:
-                    dev3 = (torch.empty((B, pitch), dtype=torch.int32, device=self.device),
-                            torch.empty((B, pitch), dtype=torch.uint8, device=self.device),
-                            torch.empty((B, pitch), dtype=torch.float64, device=self.device))
+                    scratch, d_pix, d_lvl, d_pv = self._carve((summ.numel(), torch.uint8, (summ.numel(),)),
+                                                              (B * pitch * 4, torch.int32, (B, pitch)),
+                                                              (B * pitch, torch.uint8, (B, pitch)),
+                                                              (B * pitch * 8, torch.float64, (B, pitch)))
+                    dev3 = (d_pix, d_lvl, d_pv)
                     self._pin_flip ^= 1
                     host3 = (self._pinned("pix", (B, pitch), torch.int32), self._pinned("lvl", (B, pitch), torch.uint8),
                              self._pinned("pv", (B, pitch), torch.float64))
+                else:
+                    scratch = torch.empty(summ.numel(), dtype=torch.uint8, device=self.device)
                 vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
                 try:
                     _lib.check(self.lib.mst_found_finish(_ptr(st["found"]), cap, _ptr(st["count"]), _ptr(st["args"][2]),
@@ -485,6 +498,17 @@ class ScaleSpaceEngine:
         """sigma_loop_band over several groups of blocks with copy/compute overlap: the groups' fused kernels run back
         to back on two alternating side streams, and the p-values / BH / selection / download of group i run while the
         kernel of group i + 1 is executing.  Yields, per group, what sigma_loop_band returns."""
+        if len(groups) == 1:
+            # nothing to overlap: run on the caller's stream, without the side streams' events (a small launch -- six blocks of
+            # 2000 x 2000 are 1.75 ms of kernel -- pays for every host-side call)
+            starts = groups[0]
+            nzc = torch.empty(len(starts), dtype=torch.int32, device=self.device)
+            st = self._ss_launch(None, None, nzc, skip_empty, None, timing, fma,
+                                 (band, int(n), int(dpx), [int(v) for v in starts], int(CH)))
+            st2 = self._ss_finish(st, packed=download and select_below is None and not sort)
+            res = self._ss_results(st2, download, sort, with_value, with_q, select_below)
+            yield res + ((torch.from_numpy(st2["nz_h"].astype(np.uint32).view(np.int32)) if download else st2["args"][2]),)
+            return
         cur = torch.cuda.current_stream(self.device)
         ready = cur.record_event()              # the band was produced on the caller's stream
         if self._side_streams is None:

@@ -12,7 +12,7 @@ for C in "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VAL
          "SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_UNALIGNED_STALL SQ_INST_LEVEL_LDS" \
          "SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --kernel-trace -d $OUT/g$i -o pmc --output-format csv -- python $REPO/bench.py --small --steps 1 --warmup 0 --no-cpu > $OUT/log_g$i.txt 2>&1
+  rocprofv3 --pmc $C --kernel-trace -d $OUT/g$i -o pmc --output-format csv -- python $REPO/bench.py --small --steps 1 --warmup 0 --core > $OUT/log_g$i.txt 2>&1
 done
 python - <<PY
 import csv, glob, collections

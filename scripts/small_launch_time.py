@@ -26,3 +26,27 @@ dt = (time.time() - t0) / steps
 k = sum(a.elapsed_time(b) for a, b in w.kernel_ms) / steps
 print("chr21 @ 5 kb: %.3f ms per step = %.0f Mpix/s; fused kernel %.3f ms (%.0f Mpix/s); everything else %.3f ms"
       % (dt * 1e3, w.total_mpix / dt, k, w.total_mpix / (k * 1e-3), dt * 1e3 - k))
+
+# where the rest goes: host time of the enqueue (_ss_launch: allocations, work list, uploads, kernel launch) and of the finish
+# (mst_found_finish incl. its wait for the kernel, then building the per-block records)
+eng = w.pipe.engine
+acc = {"launch": 0.0, "finish": 0.0, "results": 0.0}
+for name in ("_ss_launch", "_ss_finish", "_ss_results"):
+    def wrap(fn, key):
+        def inner(*a, **k):
+            t = time.perf_counter()
+            r = fn(*a, **k)
+            acc[key] += time.perf_counter() - t
+            return r
+        return inner
+    setattr(eng, name, wrap(getattr(eng, name), name.split("_")[-1]))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    w.step(False)
+torch.cuda.synchronize()
+tot = (time.perf_counter() - t0) / steps
+print("host view per step: total %.3f ms | _ss_launch (enqueue) %.3f | _ss_finish (incl. waiting for the kernel) %.3f | "
+      "_ss_results %.3f | python around them %.3f"
+      % (tot * 1e3, acc["launch"] / steps * 1e3, acc["finish"] / steps * 1e3, acc["results"] / steps * 1e3,
+         (tot - sum(acc.values()) / steps) * 1e3))

@@ -312,6 +312,7 @@ class ScaleSpaceEngine:
         self.levels = LevelTable(octave_values, s)
         self._select_cap = 4096
         self._prefetch_guess = {}       # CH -> record columns mst_found_finish copies to the host speculatively
+        self._buffers = {}              # small launch buffer sets kept for reuse (_carve)
         self._side_streams = None
         self._lv_struct = self.levels.as_struct()
         self._found_cap = {}
@@ -371,8 +372,8 @@ class ScaleSpaceEngine:
         packed = download and select_below is None and not sort
         return self._ss_results(self._ss_finish(st, packed=packed), download, sort, with_value, with_q, select_below)
 
-    def _ss_launch(self, c, nz, nz_count, skip_empty, found_cap, timing, fma, band_src):
-        """Allocate the outputs and enqueue the fused kernel on the current stream (no synchronisation)."""
+    def _ss_launch(self, c, nz, nz_count, skip_empty, found_cap, timing, fma, band_src, reuse=None):
+        """Allocate the outputs and enqueue the fused kernel on the current stream (no synchronisation).  `reuse`: see _carve."""
         if band_src is not None:
             band, bn, bdpx, bstarts, CH = band_src
             B = len(bstarts)
@@ -390,7 +391,7 @@ class ScaleSpaceEngine:
                 (ws_bytes, torch.uint8, (ws_bytes,)), (B * T * 16, torch.float64, (B, T, 2)),
                 (B * T * 16, torch.float64, (B, T, 2)), (B * 4, torch.int32, (B,)),
                 (B * found_cap * 16, torch.int64, (B, found_cap, 2)),            # 16-byte records
-                (B * found_cap * 8, torch.float64, (B, found_cap)))
+                (B * found_cap * 8, torch.float64, (B, found_cap)), reuse=None if reuse is None else ("launch", reuse))
             ev = None
             if timing is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -407,16 +408,26 @@ class ScaleSpaceEngine:
             if ev is not None:
                 ev[1].record()
         return dict(args=(c, nz, nz_count, skip_empty, timing, fma, band_src), B=B, CH=CH, found_cap=found_cap, ws=ws,
-                    stats=stats, fit=fit, count=count, found=found, pval=pval, ev=ev)
+                    stats=stats, fit=fit, count=count, found=found, pval=pval, ev=ev, reuse=reuse)
 
-    def _carve(self, *parts):
-        """One device allocation cut into typed views: parts = (bytes, dtype, shape); every view starts 256-byte aligned."""
-        offs, total = [], 0
-        for nbytes, _, _ in parts:
-            offs.append(total)
-            total += -(-int(nbytes) // 256) * 256
-        arena = torch.empty(max(total, 256), dtype=torch.uint8, device=self.device)
-        return tuple(arena[o:o + int(nb)].view(dt).view(*shape) for o, (nb, dt, shape) in zip(offs, parts))
+    def _carve(self, *parts, reuse=None):
+        """Device buffers for one launch: parts = (bytes, dtype, shape).  `reuse` (a hashable key, or None): SMALL sets (< 256 MB)
+        are kept and handed out again for the same key -- a launch of six 2000 x 2000 blocks is 1.75 ms of kernel, and a dozen
+        allocator calls per step are 2 % of it; callers pass a key only when the buffers do not outlive the call (the results
+        are host copies) and alternate the key's slot between launches in flight."""
+        total = sum(int(p[0]) for p in parts)
+        key = None
+        if reuse is not None and total < (256 << 20):
+            key = (reuse,) + tuple((int(p[0]), p[1]) for p in parts)
+            hit = self._buffers.get(key)
+            if hit is not None:
+                return hit
+        out = tuple(torch.empty(shape, dtype=dt, device=self.device) for _, dt, shape in parts)
+        if key is not None:
+            if len(self._buffers) > 16:
+                self._buffers.clear()
+            self._buffers[key] = out
+        return out
 
     def _summary_pin(self, B):
         """Page-locked landing area of mst_found_finish's one round trip (flags, counts, tested-pixel counts, fits)."""
@@ -445,7 +456,8 @@ class ScaleSpaceEngine:
                     scratch, d_pix, d_lvl, d_pv = self._carve((summ.numel(), torch.uint8, (summ.numel(),)),
                                                               (B * pitch * 4, torch.int32, (B, pitch)),
                                                               (B * pitch, torch.uint8, (B, pitch)),
-                                                              (B * pitch * 8, torch.float64, (B, pitch)))
+                                                              (B * pitch * 8, torch.float64, (B, pitch)),
+                                                              reuse=None if st.get("reuse") is None else ("finish", st["reuse"]))
                     dev3 = (d_pix, d_lvl, d_pv)
                     self._pin_flip ^= 1
                     host3 = (self._pinned("pix", (B, pitch), torch.int32), self._pinned("lvl", (B, pitch), torch.uint8),
@@ -463,7 +475,7 @@ class ScaleSpaceEngine:
                     c, nz, nz_count, skip_empty, timing, fma, band_src = st["args"]
                     cap = st["found_cap"] * 4   # rare: a block with an unusually dense set of local maxima
                     self._found_cap[st["CH"]] = cap
-                    st = self._ss_launch(c, nz, nz_count, skip_empty, cap, timing, fma, band_src)
+                    st = self._ss_launch(c, nz, nz_count, skip_empty, cap, timing, fma, band_src, reuse=st.get("reuse"))
         if st["ev"] is not None:
             st["args"][4].append(st["ev"])      # mst_found_finish synchronised the stream: the events are complete
         h = summ.numpy()
@@ -504,7 +516,7 @@ class ScaleSpaceEngine:
             starts = groups[0]
             nzc = torch.empty(len(starts), dtype=torch.int32, device=self.device)
             st = self._ss_launch(None, None, nzc, skip_empty, None, timing, fma,
-                                 (band, int(n), int(dpx), [int(v) for v in starts], int(CH)))
+                                 (band, int(n), int(dpx), [int(v) for v in starts], int(CH)), reuse=0 if download else None)
             st2 = self._ss_finish(st, packed=download and select_below is None and not sort)
             res = self._ss_results(st2, download, sort, with_value, with_q, select_below)
             yield res + ((torch.from_numpy(st2["nz_h"].astype(np.uint32).view(np.int32)) if download else st2["args"][2]),)
@@ -532,7 +544,8 @@ class ScaleSpaceEngine:
             with torch.cuda.stream(s):
                 nzc = torch.empty(len(starts), dtype=torch.int32, device=self.device)
                 st = self._ss_launch(None, None, nzc, skip_empty, None, timing, fma,
-                                     (band, int(n), int(dpx), [int(v) for v in starts], int(CH)))
+                                     (band, int(n), int(dpx), [int(v) for v in starts], int(CH)),
+                                     reuse=(1 + gi % 2) if download else None)     # two launches in flight: two buffer sets
                 st["kernel_done"] = s.record_event()
             st["stream"], st["nzc"] = s, nzc
             if pending is not None:

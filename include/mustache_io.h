@@ -12,13 +12,16 @@
  *
  * hic-straw is a third-party dependency that is absent from the reference tree and from the build image, and no `.hic`
  * file is available offline: the file layout below is restated from the published format (Juicer / straw,
- * github.com/aidenlab/straw, `straw.cpp`: readHeader, readFooter, readMatrixZoomData, readBlock, readNormalizationVector)
- * and is exercised against files produced by tests/hic_writer.py, an independent writer of the same layout.  The HEADER
- * parse (magic, version, master-index offset, genome, attributes, chromosome table, resolutions) is pinned on code the
- * reference tree itself holds -- diff_mustache.py:182-249 readcstr()/read_header(), imported by tests/golden/make_golden.py
- * for version-8 files (that function predates version 9's 64-bit lengths).  BLOCK decoding -- v8/v9 block indexing, the
- * float32 norm-vector division, short-count sentinels -- stays UNPINNED against hic-straw; mustache_amd.readers therefore
- * prefers hic-straw whenever that module is importable and uses this reader otherwise (MUSTACHE_HIC_BACKEND overrides).
+ * github.com/aidenlab/straw, `straw.cpp`: readHeader, readFooter, readMatrixZoomData, readBlock, readNormalizationVector).
+ * What pins it: the HEADER parse (magic, version, master-index offset, genome, attributes, chromosome table, resolutions) on
+ * code the reference tree itself holds -- diff_mustache.py:182-249 readcstr()/read_header(), imported by
+ * tests/golden/make_golden.py for version-8 files; the window / de-duplication / filter semantics on the reference's own
+ * read_hic_file (tests/golden/readers_ref.npz); BLOCK decoding -- v6 plain records, v7-v9 row lists and dense grids, 16- and
+ * 32-bit coordinates, short and float counts, the float32 / float64 norm-vector division, block selection by distance -- on TWO
+ * independent readings of the format agreeing with this reader: the writer tests/hic_writer.py and the pure-Python reader
+ * tests/hic_pyreader.py (written from the format description; no shared code), incl. hand-assembled corner cases
+ * (tests/test_hic_two_readings.py).  hic-straw output on a real file remains unavailable offline; mustache_amd.readers
+ * therefore still prefers hic-straw whenever that module is importable (MUSTACHE_HIC_BACKEND overrides).
  *
  * Conventions: int status (0 = ok, < 0 = MST_IO_E_*), mst_io_last_error() returns a thread-local message, no C++
  * exception crosses the ABI, arrays handed out are malloc'ed and released with mst_io_free().

@@ -42,10 +42,13 @@ inline uint32_t e_kind(uint32_t e) { return (e >> 5) & 7u; }
 inline uint32_t e_value(uint32_t e) { return (e >> 8) & 0xFFFFu; }
 inline uint32_t e_extra(uint32_t e) { return (e >> 24) & 15u; }
 
-inline uint32_t reverse_bits(uint32_t code, int len) {
-    uint32_t r = 0;
-    for (int i = 0; i < len; ++i) r |= ((code >> i) & 1u) << (len - 1 - i);
-    return r;
+inline uint32_t reverse_bits(uint32_t code, int len) {          // len <= 15: swap the bits of a 16-bit word, keep the top `len`
+    uint32_t v = code & 0xFFFFu;
+    v = ((v & 0x5555u) << 1) | ((v >> 1) & 0x5555u);
+    v = ((v & 0x3333u) << 2) | ((v >> 2) & 0x3333u);
+    v = ((v & 0x0F0Fu) << 4) | ((v >> 4) & 0x0F0Fu);
+    v = ((v & 0x00FFu) << 8) | ((v >> 8) & 0x00FFu);
+    return v >> (16 - len);
 }
 
 static const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115,

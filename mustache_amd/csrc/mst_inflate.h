@@ -325,11 +325,8 @@ inline int inflate_raw(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, s
         // ---- symbols of the block.  (A fully branch-free form -- distance table looked up for every symbol, bits consumed
         // under a mask, one 8-byte copy per symbol -- was built and measured: it removes the literal-or-match mispredictions
         // but chains both table look-ups into the bit buffer's dependency, 21 cycles per symbol against 12 for this form.)
-        for (;;) {
-            if (MST_OVERRUN()) return kCorrupt;
-            if ((size_t)(out_end - out) < kOutMargin) return kOutputFull;
-            MST_REFILL();
-            uint32_t e = t.litlen[bitbuf & ((1u << kLitlenRoot) - 1)];
+        // software-pipelined: the table entry of the NEXT symbol is fetched before the current symbol's output work (the copy of
+        // a match, the third literal's store), so its L1 latency is off the bit buffer's dependency chain
 #define MST_RESOLVE(tab_)                                                                   \
     if (__builtin_expect(e_kind(e) == kSub, 0)) {                                           \
         bitbuf >>= e_bits(e);                                                               \
@@ -338,6 +335,11 @@ inline int inflate_raw(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, s
     }                                                                                       \
     bitbuf >>= e_bits(e);                                                                   \
     bitcnt -= e_bits(e);
+        MST_REFILL();
+        uint32_t e = t.litlen[bitbuf & ((1u << kLitlenRoot) - 1)];          // fetched, not yet consumed
+        for (;;) {
+            if (MST_OVERRUN()) return kCorrupt;
+            if ((size_t)(out_end - out) < kOutMargin) return kOutputFull;
             MST_RESOLVE(t.litlen)
             if (e_kind(e) == kLiteral) {
                 *out++ = (uint8_t)e_value(e);
@@ -348,7 +350,10 @@ inline int inflate_raw(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, s
                     e = t.litlen[bitbuf & ((1u << kLitlenRoot) - 1)];
                     MST_RESOLVE(t.litlen)
                     if (e_kind(e) == kLiteral) {
-                        *out++ = (uint8_t)e_value(e);
+                        const uint8_t lit3 = (uint8_t)e_value(e);
+                        MST_REFILL();
+                        e = t.litlen[bitbuf & ((1u << kLitlenRoot) - 1)];
+                        *out++ = lit3;
                         continue;
                     }
                 }
@@ -364,6 +369,8 @@ inline int inflate_raw(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, s
             if (__builtin_expect(e_kind(e) != kDistance, 0)) return kCorrupt;
             const uint32_t dist = e_value(e) + MST_TAKE(e_extra(e));
             if (__builtin_expect(dist > (size_t)(out - dst), 0)) return kCorrupt;
+            MST_REFILL();
+            e = t.litlen[bitbuf & ((1u << kLitlenRoot) - 1)];               // the symbol after the match, before its copy
             const uint8_t *from = out - dist;
             uint8_t *const stop = out + len;
             if (len <= 8 && dist >= len) {         // the common case in row lists: 3-4 bytes from a few records back

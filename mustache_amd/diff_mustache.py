@@ -146,8 +146,15 @@ def normalized_pair_bands(pipe, coo1, coo2, res, distance_in_px):
     import torch
     from .normalize import band_from_host_coo, normalize_band
     dev = pipe.device
+    from .hicfile import PackedContacts
+    from .normalize import band_from_packed
     ns, coos = [], []
-    for (x, y, v) in (coo1, coo2):
+    for coo in (coo1, coo2):
+        if isinstance(coo, PackedContacts):            # a `.hic` sample read by the native reader (records possibly on the device)
+            ns.append(int(coo.n))
+            coos.append(coo)
+            continue
+        x, y, v = coo
         x = np.ascontiguousarray(np.asarray(x), dtype=np.int64)
         y = np.ascontiguousarray(np.asarray(y), dtype=np.int64)
         v = np.ascontiguousarray(np.asarray(v), dtype=np.float64)
@@ -155,8 +162,11 @@ def normalized_pair_bands(pipe, coo1, coo2, res, distance_in_px):
         coos.append((x, y, v))
     n = max(ns)                                                            # (:632)
     dbands = []
-    for (x, y, v), n_s in zip(coos, ns):
-        band = band_from_host_coo(x, y, v, n_s, distance_in_px, dev)
+    for coo, n_s in zip(coos, ns):
+        if isinstance(coo, PackedContacts):
+            band = band_from_packed(coo, distance_in_px, dev)
+        else:
+            band = band_from_host_coo(coo[0], coo[1], coo[2], n_s, distance_in_px, dev)
         band, _, _ = normalize_band(band, n_s, distance_in_px, res)       # (:634-635 -> mustache.py:623)
         if n_s < n:
             pad = torch.zeros((distance_in_px + 2, n), dtype=torch.float64, device=dev)
@@ -248,8 +258,13 @@ def read_pair(f1, f2, norm_method, CHRM_SIZE, res, distance_in_bp, bias1, bias2,
     coos = []
     for f, bias in ((f1, bias1), (f2, bias2)):
         if f.endswith(".hic"):
-            from .readers import read_hic_file
-            coo = read_hic_file(f, norm_method, CHRM_SIZE, distance_in_bp, chromosome, chromosome2, res)
+            from .readers import hic_backend, read_hic_file, read_hic_packed
+            if hic_backend() == "native":
+                # the packed / streamed form the single-sample CLI uses: same record set as read_hic_file (pinned on the
+                # reference's, tests/test_readers_ref.py) without the int64 / float64 triple; None = no contact
+                coo = read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chromosome, res)
+            else:
+                coo = read_hic_file(f, norm_method, CHRM_SIZE, distance_in_bp, chromosome, chromosome2, res)
         elif f.endswith(".cool"):
             from .readers import read_cooler
             x, y, v, r2 = read_cooler(f, distance_in_bp, chromosome, chromosome2, norm_method)
@@ -262,7 +277,9 @@ def read_pair(f1, f2, norm_method, CHRM_SIZE, res, distance_in_bp, bias1, bias2,
         else:
             coo = read_pd(f, distance_in_bp, bias, chromosome, res)
         coos.append(coo)
-    if coos[0] is None or coos[1] is None or len(coos[0][2]) == 0 or len(coos[1][2]) == 0:
+    from .hicfile import PackedContacts
+    empty = lambda c: c is None or (len(c) == 0 if isinstance(c, PackedContacts) else len(c[2]) == 0)
+    if empty(coos[0]) or empty(coos[1]):
         return None
     return coos[0], coos[1], res
 

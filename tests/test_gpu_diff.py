@@ -236,3 +236,49 @@ def test_pair_genome_batched_equals_chromosome_by_chromosome():
     for a, b in zip(alone, together):
         assert [(int(r[0]), int(r[1]), float(r[2]), float(r[3]), int(r[4])) for r in a] == \
                [(int(r[0]), int(r[1]), float(r[2]), float(r[3]), int(r[4])) for r in b]
+
+
+def test_diff_cli_from_hic_files_equals_cli_from_text(tmp_path):
+    """BASELINE config 5's input form: both samples as `.hic` files through the native reader's packed / streamed path
+    (`-f1 a.hic -f2 b.hic`, no -ch: every chromosome of the file) write the same four files as the same contacts given as
+    text -- integer counts, NONE normalisation, so that the float32 the `.hic` path carries is exact."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from hic_writer import write_hic
+    from mustache_amd.diff_mustache import main, SUFFIX
+    from mustache_amd.synth import synth_coo
+    dpx, res = 200, 10000
+    chroms = [("All", 1), ("chrS", 2300 * res), ("chrT", 1800 * res)]
+    hics, txts = [], []
+    for smp, seeds in enumerate(((61, 63), (62, 64))):
+        mats, rows = {}, []
+        for ci, (name, length) in enumerate(chroms[1:], start=1):
+            x, y, v = synth_coo(length // res, dpx, depth=300.0, seed=seeds[ci - 1])
+            near = (y - x) <= dpx
+            x, y, c = x[near], y[near], np.round(v[near]) + 1.0
+            mats[ci] = {res: (x, y, c)}
+            rows.append((name, x, y, c))
+        h = str(tmp_path / ("s%d.hic" % smp))
+        write_hic(h, chroms, mats, {}, version=8, block_bin_count=200, float_counts=False)
+        hics.append(h)
+        per = []
+        for name, x, y, c in rows:
+            t = str(tmp_path / ("s%d_%s.txt" % (smp, name)))
+            with open(t, "w") as fh:
+                for a, b, cc in zip(x, y, c):
+                    fh.write("%d\t%d\t%r\n" % (a * res, b * res, float(cc)))
+            per.append(t)
+        txts.append(per)
+    common = ["-r", "10kb", "-pt", "0.2", "-pt2", "0.2", "-st", "0.8", "-d", str(dpx * res), "-norm", "NONE"]
+    out_h = str(tmp_path / "from_hic")
+    main(["-f1", hics[0], "-f2", hics[1], "-o", out_h] + common)
+    total = 0
+    for k, name in enumerate(("chrS", "chrT")):
+        out_t = str(tmp_path / ("from_txt_" + name))
+        main(["-f1", txts[0][k], "-f2", txts[1][k], "-ch", name, "-o", out_t] + common)
+        for suf in SUFFIX.values():
+            want = [l for l in open(out_t + suf).read().strip().split("\n")[1:] if l]
+            got = [l for l in open(out_h + suf).read().strip().split("\n")[1:] if l.startswith(name + "\t")]
+            assert got == want, (name, suf, len(got), len(want))
+            total += len(want)
+    assert total > 30

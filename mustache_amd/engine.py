@@ -490,7 +490,9 @@ class ScaleSpaceEngine:
             if host3 is not None:
                 # the records are on the host already when the guess held; False = tried (the staging set is already flipped)
                 st["prefetched"] = host3 if mx <= pitch else False
-            self._prefetch_guess[st["CH"]] = mx + mx // 20 + 64
+            # next guess: 10 % above this launch's largest count, but never much below the last guess -- the launches of a run
+            # differ (a genome's chromosomes, a chromosome's ends), and a guess that fails costs a second download
+            self._prefetch_guess[st["CH"]] = max(mx + mx // 10 + 64, int(0.995 * self._prefetch_guess.get(st["CH"], 0)))
         return st
 
     def _ss_results(self, st, download, sort, with_value, with_q, select_below):

@@ -92,7 +92,8 @@ def read_hic_stream_to_device(hic, chrom, res, norm, dpx, chrom_size_bp, device,
     ddt = torch.uint16 if dist_bytes == 2 else torch.int32
     st = HicStream(hic, chrom, res, norm, int(dpx), int(chrom_size_bp), pool.data_ptr(), n_slabs, slab_records, dist_bytes,
                    threads=threads, part=part)
-    side = torch.cuda.Stream(device)
+    from .engine import device_streams
+    side = device_streams(torch.device(device))[2]          # the process's one copy stream of this device
     parts, pending = [], []
     try:
         while True:

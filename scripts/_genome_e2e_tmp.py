@@ -1,0 +1,34 @@
+import sys, time, torch
+sys.path.insert(0, '.')
+import bench
+dev = torch.device('cuda:0')
+def instrument(eng):
+    acc = {}
+    for name in ("_ss_launch", "_ss_finish", "_ss_results", "_download_selected"):
+        def wrap(fn, key):
+            def inner(*a, **k):
+                t = time.perf_counter(); r = fn(*a, **k); acc[key] = acc.get(key, 0.0) + time.perf_counter() - t; return r
+            return inner
+        setattr(eng, name, wrap(getattr(eng, name), name))
+    return acc
+def run(wg, tag):
+    acc = instrument(wg.pipe.engine)
+    wg.pipe.run_layout(wg.layout, wg.band, 0.88, 0.1)
+    acc.clear()
+    ts = []; tms = []
+    for _ in range(5):
+        tm = {}
+        torch.cuda.synchronize(); t0 = time.time()
+        wg.pipe.run_layout(wg.layout, wg.band, 0.88, 0.1, timings=tm)
+        torch.cuda.synchronize(); ts.append(time.time() - t0); tms.append(tm)
+    print(tag, "e2e median %.4f" % sorted(ts)[2], "scale_space_s %.4f tail_s %.4f" % (tms[2]["scale_space_s"], tms[2]["tail_s"]),
+          {k: round(v / 5 * 1e3, 2) for k, v in acc.items()}, flush=True)
+which = sys.argv[1]
+if which == "fresh":
+    wg = bench.GenomeWorkload("g", 5000, 400, 300.0, 1000, dev, two_samples=False)
+    run(wg, "fresh")
+else:
+    w = bench.Workload("c", 248957, 2000, 1000, 400.0, 8000, 1, dev, 0, 1)
+    for _ in range(2): w.step(False)
+    wg = bench.GenomeWorkload("g", 5000, 400, 300.0, 1000, dev, two_samples=False)
+    run(wg, "after chr1")

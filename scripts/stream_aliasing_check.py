@@ -1,3 +1,11 @@
+#!/usr/bin/env python3
+"""Does a whole-genome run cost the same whatever ran before it in the process?  (GPU box.)
+    python scripts/stream_aliasing_check.py fresh      # the genome workload in a fresh process
+    python scripts/stream_aliasing_check.py after      # ... after a chr1 @ 1 kb workload of another engine ran
+Round 4 found the second form 0.032 -> 0.053 s: every engine created its own side streams, HIP maps streams to a few hardware
+queues in creation order, and the genome engine's launch stream landed on the default stream's queue -- the host tail's small
+kernels then waited behind the next launch's fused kernel.  engine.device_streams() (one fixed set per device and process)
+removed the dependence; this script is the check."""
 import sys, time, torch
 sys.path.insert(0, '.')
 import bench

@@ -41,6 +41,11 @@ extern "C" {
 #define MST_FLAG_NO_SHARE 4   /* band source only: compute every tile once PER BLOCK on the block's own tile lattice (the form
                                * of rounds 1 and 2).  Default: a tile that lies inside two consecutive blocks with its whole
                                * blur halo is computed once and delivered to both (identical records; see mst_scale_space_band) */
+#define MST_FLAG_GRAPH 8      /* band source only: when a call repeats with EVERY argument unchanged (same device buffers, same
+                               * block origins, same level table, same stream kind) it is captured into a hipGraph the second
+                               * time and replayed afterwards -- one graph launch instead of ~16 runtime calls in front of the
+                               * fused kernel (small launches are latency-bound).  Identical results; ignored on the legacy
+                               * default stream (it cannot be captured) and by PROFILE builds. */
 #define MST_FLAG_FMA 2        /* OPT-IN relaxed arithmetic: fuse the multiply-add of each tap pair.  DoG values then differ
                                  from the reference's by ~1e-16 relative (instead of being bit-identical); default off */
 

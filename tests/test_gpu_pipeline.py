@@ -807,3 +807,53 @@ def test_streamed_hic_read_gives_the_one_shot_band(tmp_path):
     assert np.array_equal(sx[so], ox[oo]) and np.array_equal(sy[so], oy[oo]) and np.array_equal(sv[so], ov[oo])
     assert torch.equal(band_from_packed(st, dpx, dev), band_from_packed(one, dpx, dev))
     assert torch.equal(band_from_packed(st, dpx, dev, check=True), band_from_packed(one, dpx, dev))     # read-back check passes
+
+
+def test_graph_replay_gives_identical_records():
+    """MST_FLAG_GRAPH (the engine's single-launch path with host results): the first call runs the ordinary way, the second is
+    captured into a hipGraph, later ones replay it -- every call returns the records of an ordinary launch, bit for bit; a change
+    of the band's CONTENT (same buffer) is seen by the replay, a different block list is a different graph."""
+    import torch
+    from mustache_amd.normalize import band_from_coo, normalize_band
+    from mustache_amd.pipeline import ChromosomePipeline, block_tiling
+    from mustache_amd.synth import synth_coo
+    n, dpx, res = 5200, 400, 5000
+    pipe = ChromosomePipeline(OCT)
+    eng = pipe.engine
+    bands = []
+    for seed in (71, 72):
+        x, y, v = synth_coo(n, dpx, depth=120.0, seed=seed)
+        b = band_from_coo(*(torch.from_numpy(a).to(pipe.device) for a in (x, y, v)), n, dpx)
+        bands.append(normalize_band(b, n, dpx, res)[0])
+    CH, start, end = block_tiling(n, dpx)
+    want = []
+    for b in bands:
+        recs, fits, nzc = eng.sigma_loop_band(b, n, dpx, start, CH, skip_empty=True, sort=False, with_value=False, with_q=False)
+        want.append(([{k: r[k].copy() for k in r} for r in recs], [(f[0].copy(), f[1].copy()) for f in fits],
+                     nzc.cpu().numpy().copy()))
+    live = bands[0].clone()
+
+    def step(starts):
+        (recs, fits, nzc), = list(eng.sigma_loop_band_overlapped(live, n, dpx, [starts], CH, skip_empty=True, sort=False,
+                                                                with_value=False, with_q=False))
+        return recs, fits, nzc.cpu().numpy()
+
+    def same(got, exp, blocks):
+        recs, fits, nzc = got
+        for j, b in enumerate(blocks):
+            o, e = np.argsort(recs[j]["pixel"]), np.argsort(exp[0][b]["pixel"])
+            for k in ("pixel", "level", "pval"):
+                assert np.array_equal(recs[j][k][o], exp[0][b][k][e]), (b, k)
+            assert np.array_equal(fits[j][0], exp[1][b][0]) and np.array_equal(fits[j][1], exp[1][b][1])
+            assert int(nzc[j]) == int(exp[2][b])
+
+    all_blocks = list(range(len(start)))
+    for it in range(4):                                  # ordinary, captured, replayed, replayed
+        same(step(start), want[0], all_blocks)
+    live.copy_(bands[1])                                 # same buffer, new contents: the replayed graph reads them
+    for it in range(2):
+        same(step(start), want[1], all_blocks)
+    sub = start[1:]                                      # a different block list: its own graph after two calls
+    for it in range(3):
+        same(step(sub), want[1], all_blocks[1:])
+    same(step(start), want[1], all_blocks)               # and back to the first graph

@@ -330,6 +330,7 @@ class ScaleSpaceEngine:
         self._select_cap = 4096
         self._prefetch_guess = {}       # CH -> record columns mst_found_finish copies to the host speculatively
         self._buffers = {}              # small launch buffer sets kept for reuse (_carve)
+        self._starts_arrays, self._ws_bytes = {}, {}
         self._side_streams = None
         self._lv_struct = self.levels.as_struct()
         self._found_cap = {}
@@ -394,15 +395,22 @@ class ScaleSpaceEngine:
         if band_src is not None:
             band, bn, bdpx, bstarts, CH = band_src
             B = len(bstarts)
-            st_arr = (ctypes.c_int64 * B)(*bstarts)
+            skey = tuple(bstarts)
+            st_arr = self._starts_arrays.get(skey)          # repeated launches of the same blocks: no re-marshalling
+            if st_arr is None:
+                if len(self._starts_arrays) > 64:
+                    self._starts_arrays.clear()
+                st_arr = self._starts_arrays[skey] = (ctypes.c_int64 * B)(*bstarts)
         else:
             B, CH, _ = c.shape
         if found_cap is None:
             found_cap = self._found_cap.get(CH, max(4096, (CH * CH) // 32))
         lv = ctypes.byref(self._lv_struct)
-        ws_bytes = int(self.lib.mst_scale_space_workspace_bytes(B, CH, lv))
+        ws_bytes = self._ws_bytes.get((B, CH))
+        if ws_bytes is None:
+            ws_bytes = self._ws_bytes[(B, CH)] = int(self.lib.mst_scale_space_workspace_bytes(B, CH, lv))
         with torch.cuda.device(self.device):
-            # one allocation, six views (a launch of six 2000 x 2000 blocks is 1.75 ms of kernel: every allocator call counts)
+            # the six launch buffers (kept between calls for small launches, see _carve)
             T = _lib.MST_MAX_TESTED
             ws, stats, fit, count, found, pval = self._carve(
                 (ws_bytes, torch.uint8, (ws_bytes,)), (B * T * 16, torch.float64, (B, T, 2)),

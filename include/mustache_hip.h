@@ -135,12 +135,13 @@ int mst_found_pvalues(const mst_found *found, uint32_t found_cap, const uint32_t
  * (pixel index, 1-based tested level, p-value) -- what a caller that downloads whole found sets wants; with pix_host /
  * lvl_host / pv_host (page-locked, same shapes; all three or none) they are copied to the host before the synchronisation, so a
  * caller whose pack_pitch (its guess of the largest count) is confirmed by the summary needs no second round trip.
- * Same error returns as mst_found_pvalues. */
+ * flags: 0, or MST_FLAG_GRAPH (a call that repeats with every argument unchanged is replayed as one hipGraph: for small,
+ * latency-bound launches; it slows large pipelined ones).  Same error returns as mst_found_pvalues. */
 uint64_t mst_found_summary_bytes(int32_t B);
 int mst_found_finish(const mst_found *found, uint32_t found_cap, const uint32_t *found_count, const uint32_t *nz_count,
                      const double *level_stats, int32_t B, int32_t n_tested, double *pval, double *fit, uint32_t pack_pitch,
                      int32_t *pix_out, uint8_t *lvl_out, double *pv_out, void *scratch_dev, void *summary_host,
-                     int32_t *pix_host, uint8_t *lvl_host, double *pv_host, void *stream);
+                     int32_t *pix_host, uint8_t *lvl_host, double *pv_host, int32_t flags, void *stream);
 
 /* mustache.py:778, multipletests(p, method='fdr_bh') per block, on the device: q[b][i] for the first count[b] records of
  * each block (sort ascending, p * m / rank with NumPy's operation order, suffix minimum, clip at 1, back to record order).

@@ -53,7 +53,7 @@ _SIGNATURES = {
     "mst_scale_space_workspace_bytes": (_u64, [_i32, _i32, ctypes.POINTER(MstLevels)]),
     "mst_found_pvalues": (ctypes.c_int, [_p, _u32, _p, _p, _p, _i32, _i32, _p, _p, _p]),
     "mst_found_summary_bytes": (_u64, [_i32]),
-    "mst_found_finish": (ctypes.c_int, [_p, _u32, _p, _p, _p, _i32, _i32, _p, _p, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "mst_found_finish": (ctypes.c_int, [_p, _u32, _p, _p, _p, _i32, _i32, _p, _p, _u32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "mst_bh_workspace_bytes": (_u64, [_i32, _u32]),
     "mst_bh_fdr": (ctypes.c_int, [_p, _p, _i32, _u32, _p, _p, _u64, _p]),
     "mst_bh_select": (ctypes.c_int, [_p, _p, _p, _i32, _u32, ctypes.c_double, _u32, _p, _p, _p, _p, _p, _u64, _p]),

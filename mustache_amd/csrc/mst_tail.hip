@@ -397,7 +397,7 @@ extern "C" int mst_found_finish(const mst_found *found, uint32_t found_cap, cons
                                 const uint32_t *nz_count, const double *level_stats, int32_t B, int32_t n_tested, double *pval,
                                 double *fit, uint32_t pack_pitch, int32_t *pix_out, uint8_t *lvl_out, double *pv_out,
                                 void *scratch_dev, void *summary_host, int32_t *pix_host, uint8_t *lvl_host, double *pv_host,
-                                void *stream) {
+                                int32_t flags, void *stream) {
     if (!found || !found_count || !nz_count || !level_stats || !pval || !fit || !scratch_dev || !summary_host || B <= 0 ||
         B > 65535 || n_tested <= 0 || n_tested > MST_MAX_TESTED)
         return mst::fail(MST_E_ARG, "mst_found_finish: bad argument");
@@ -428,11 +428,13 @@ extern "C" int mst_found_finish(const mst_found *found, uint32_t found_cap, cons
         }
         return MST_OK;
     };
-    // A call that repeats with every argument unchanged (a caller that keeps its buffers between launches: the benchmark step,
-    // the engine's single-launch path) is captured into a hipGraph the second time it is seen and replayed afterwards: the
-    // seven stream operations above become one launch, and the graph's nodes follow each other without a dispatch gap -- they
-    // are what stands between the fused kernel's end and the host's wake-up.  Per host thread; not on the legacy default
-    // stream (it cannot be captured); not in PROFILE builds.
+    // MST_FLAG_GRAPH: a call that repeats with every argument unchanged (a caller that keeps its buffers between launches: the
+    // engine's single-launch path) is captured into a hipGraph the second time it is seen and replayed afterwards: the seven
+    // stream operations above become one launch, and the graph's nodes follow each other without a dispatch gap -- they are what
+    // stands between the fused kernel's end and the host's wake-up of a SMALL launch (chr21 @ 5 kb: 1.88 -> 1.85 ms per step).
+    // Opt-in because it costs large pipelined launches: with the finish of one group replayed as a graph next to the fused
+    // kernel of the next group, that kernel ran 3 % slower (measured A/B on one box: 17.76 -> 17.19 Gpix/s).  Per host thread;
+    // not on the legacy default stream (it cannot be captured); not in PROFILE builds.
     bool done = false;
 #ifndef MST_PROFILE
     struct FinishGraph {
@@ -455,7 +457,11 @@ extern "C" int mst_found_finish(const mst_found *found, uint32_t found_cap, cons
     };
     static thread_local FinishGraph fcache[6];
     static thread_local unsigned long long fstamp = 0;
-    if (s != nullptr) {
+    static const bool graphs_off = [] {
+        const char *e = getenv("MUSTACHE_NO_GRAPHS");        // diagnostic switch: ordinary stream launches only
+        return e && *e && *e != '0';
+    }();
+    if ((flags & MST_FLAG_GRAPH) && s != nullptr && !graphs_off) {
         int dev = 0;
         MST_HIP(hipGetDevice(&dev));
         std::vector<int64_t> sig;
@@ -517,14 +523,14 @@ extern "C" int mst_found_finish(const mst_found *found, uint32_t found_cap, cons
         if (erc != MST_OK) return erc;
     }
     MST_HIP(hipStreamSynchronize(s));
-    int flags = 0;
-    memcpy(&flags, summary_host, sizeof(int));
-    if (flags & 1)
+    int dflags = 0;
+    memcpy(&dflags, summary_host, sizeof(int));
+    if (dflags & 1)
         return mst::fail(MST_E_OVERFLOW, "found-pixel capacity %u exceeded in at least one block", found_cap);
 #ifdef MST_PROFILE
-    if (getenv("MST_IGNORE_NONFINITE")) flags &= ~2;        // PROFILE builds only: timing ablations produce garbage statistics
+    if (getenv("MST_IGNORE_NONFINITE")) dflags &= ~2;        // PROFILE builds only: timing ablations produce garbage statistics
 #endif
-    if (flags & 2)
+    if (dflags & 2)
         return mst::fail(MST_E_NONFINITE, "non-finite DoG statistics (input block holds NaN/inf)");
     return MST_OK;
 }

@@ -434,7 +434,7 @@ class ScaleSpaceEngine:
             if ev is not None:
                 ev[1].record()
         return dict(args=(c, nz, nz_count, skip_empty, timing, fma, band_src), B=B, CH=CH, found_cap=found_cap, ws=ws,
-                    stats=stats, fit=fit, count=count, found=found, pval=pval, ev=ev, reuse=reuse)
+                    stats=stats, fit=fit, count=count, found=found, pval=pval, ev=ev, reuse=reuse, graph=graph)
 
     def _carve(self, *parts, reuse=None):
         """Device buffers for one launch: parts = (bytes, dtype, shape).  `reuse` (a hashable key, or None): SMALL sets (< 256 MB)
@@ -495,7 +495,8 @@ class ScaleSpaceEngine:
                     _lib.check(self.lib.mst_found_finish(_ptr(st["found"]), cap, _ptr(st["count"]), _ptr(st["args"][2]),
                                                          _ptr(st["stats"]), B, nt, _ptr(st["pval"]), _ptr(st["fit"]), pitch,
                                                          *(vp(t) for t in (dev3 or (None, None, None))), _ptr(scratch),
-                                                         vp(summ), *(vp(t) for t in (host3 or (None, None, None))), _stream()))
+                                                         vp(summ), *(vp(t) for t in (host3 or (None, None, None))),
+                                                         8 if st.get("graph") else 0, _stream()))
                     break
                 except _lib.MstOverflow:
                     c, nz, nz_count, skip_empty, timing, fma, band_src = st["args"]

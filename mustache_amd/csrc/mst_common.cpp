@@ -1,4 +1,6 @@
 #include "mst_common.h"
+#include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 namespace mst {
@@ -167,6 +169,27 @@ hipError_t PinnedList::upload(void *dst, hipStream_t s) {
     if (e != hipSuccess) return e;
     pending[turn] = true;
     return hipSuccess;
+}
+
+namespace {
+char g_notes[64][240];
+unsigned g_note_at = 0;
+}  // namespace
+
+void note(const char *fmt, ...) {
+    static const char *mode = getenv("MUSTACHE_GRAPH_DEBUG");
+    if (!mode) return;
+    char *line = g_notes[g_note_at++ % 64];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(line, sizeof(g_notes[0]), fmt, ap);
+    va_end(ap);
+    if (mode[0] == 'p') fprintf(stderr, "[note] %s\n", line);          // "print": every note at once (changes the timing)
+}
+
+void dump_notes() {
+    const unsigned n = g_note_at < 64 ? g_note_at : 64;
+    for (unsigned i = g_note_at - n; i != g_note_at; ++i) fprintf(stderr, "[note %u] %s\n", i, g_notes[i % 64]);
 }
 
 }  // namespace mst

@@ -61,4 +61,8 @@ struct PinnedList {
     hipError_t upload(void *dst, hipStream_t s);
 };
 
+// diagnostics (MUSTACHE_GRAPH_DEBUG set): a short in-memory ring of notes about recent launches, printed when a call fails
+void note(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+void dump_notes();
+
 }  // namespace mst

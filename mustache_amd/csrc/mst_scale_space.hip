@@ -762,6 +762,16 @@ void build_items(const int64_t *starts, int B, int CH, int dpx, bool share, bool
     if (tiles_total_out) *tiles_total_out = tiles_total;
 }
 
+// the launch's counters to zero.  A kernel, not hipMemsetAsync: the launch can be captured into a hipGraph, and a replayed memset
+// node is not reliable on this ROCm (mst_tail.hip, fit_kernel; LABBOOK.md R4.6)
+__global__ void zero_counts_kernel(uint32_t *found_count, uint32_t *nz_count, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) {
+        found_count[i] = 0;
+        if (nz_count) nz_count[i] = 0;
+    }
+}
+
 // level_stats of blocks without any tested tile: {min, sum} = {inf, 0}, what the reduction of zero tiles yields
 __global__ void fill_stats_kernel(double *level_stats, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -950,7 +960,11 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
 #ifndef MST_PROFILE
     static thread_local GraphEntry gcache[4];
     static thread_local unsigned long long gstamp = 0;
-    if (BAND && (flags & MST_FLAG_GRAPH) && s != nullptr) {
+    static const bool graphs_off = [] {
+        const char *e = getenv("MUSTACHE_NO_GRAPHS");        // diagnostic switch: 1 = no graphs at all, "launch" = none here
+        return e && *e && *e != '0' && *e != 'f';
+    }();
+    if (BAND && (flags & MST_FLAG_GRAPH) && s != nullptr && !graphs_off) {
         int dev = 0;
         MST_HIP(hipGetDevice(&dev));
         std::vector<int64_t> sig;
@@ -965,6 +979,9 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
         GraphEntry *ge = nullptr;
         for (GraphEntry &e : gcache)
             if (e.seen && e.sig == sig && memcmp(&e.lv, lv, sizeof(mst_levels)) == 0) ge = &e;
+        mst::note("scale_space graph B=%d CH=%d n=%lld dpx=%d cap=%u flags=%d band=%p found=%p count=%p stats=%p nz=%p ws=%p -> %s", B, CH,
+                  (long long)src.n, (int)src.dpx, found_cap, flags, (const void *)src.band, (const void *)found, (const void *)found_count,
+                  (const void *)level_stats, (const void *)src.nz_count, workspace, ge && ge->exec ? "REPLAY" : (ge ? "CAPTURE" : "first sight"));
         if (ge && ge->exec) {
             ge->stamp = ++gstamp;
             MST_HIP(hipGraphLaunch(ge->exec, s));
@@ -1061,10 +1078,10 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
     };
     auto enqueue = [&]() -> int {
         MST_HIP(up(d_lv, &h, sizeof(h)));
-        MST_HIP(hipMemsetAsync(found_count, 0, sizeof(uint32_t) * B, s));
+        zero_counts_kernel<<<(B + 255) / 256, 256, 0, s>>>(found_count, BAND ? src.nz_count : nullptr, B);
+        MST_LAUNCH_CHECK();
         if (BAND) {
             MST_HIP(up(d_starts, starts_host, sizeof(int64_t) * B));
-            MST_HIP(hipMemsetAsync(src.nz_count, 0, sizeof(uint32_t) * B, s));
             src.starts = d_starts;
         }
         if (n_items == 0) {          // no tile reaches the band: nothing is tested, nothing is found
@@ -1099,6 +1116,9 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
         MST_LAUNCH_CHECK();
         return MST_OK;
     };
+    if (!(flags & MST_FLAG_GRAPH))
+        mst::note("scale_space plain B=%d CH=%d cap=%u flags=%d found=%p count=%p stats=%p ws=%p items=%d", B, CH, found_cap, flags,
+                  (const void *)found, (const void *)found_count, (const void *)level_stats, workspace, n_items);
     rc = enqueue();
     if (gent) {
         hipGraph_t graph = nullptr;

@@ -12,33 +12,53 @@
 
 namespace {
 
-// {loc, scale} per (block, tested level):  loc = min|D|, scale = mean|D| - loc   (scipy expon.fit,
-// scipy/stats/_continuous_distns.py:2134-2147)
-// (summary: optional device image of mst_found_finish's host summary -- counts and fits are copied into it here, so that ONE
-// device-to-host copy brings everything back)
-__global__ void fit_kernel(const double *__restrict__ level_stats, const uint32_t *__restrict__ nz_count,
-                           int n_tested, double *__restrict__ fit, int *__restrict__ flags,
-                           const uint32_t *__restrict__ found_count, char *__restrict__ summary, int B) {
-    const int b = blockIdx.x, t = threadIdx.x;
-    if (summary && t == 0) {
-        const size_t cw = 8 * (size_t)((B + 1) / 2);
-        reinterpret_cast<uint32_t *>(summary + 16)[b] = found_count[b];
-        reinterpret_cast<uint32_t *>(summary + 16 + cw)[b] = nz_count[b];
+// One workgroup for the whole launch (B * n_tested fits are a few thousand doubles): the fits, the host's summary image and the
+// flags word {1: a block's record count exceeds the capacity, 2: non-finite statistics in a block that tested pixels} -- the
+// word is REDUCED inside the workgroup and stored once, so nothing has to be zeroed beforehand and no atomics are needed.
+// (It used to be a zero-filled word that B workgroups OR-ed into.  Zeroing it with hipMemsetAsync put a memset node into the
+// captured finish graph, and on this ROCm a replayed memset node sometimes writes stale host-heap bytes instead of its
+// pattern: the flags word came back as 0x2, 0x20, 0x402, 0x22ee3402, half a heap pointer ... about once per 30 replays in a
+// long sweep, with everything else in the summary correct -- LABBOOK.md R4.6.  No captured sequence of this library contains a
+// memset any more.)
+__global__ void __launch_bounds__(256)
+fit_kernel(const double *__restrict__ level_stats, const uint32_t *__restrict__ nz_count, int n_tested,
+           double *__restrict__ fit, int *__restrict__ flags, const uint32_t *__restrict__ found_count, uint32_t found_cap,
+           char *__restrict__ summary, int B) {
+    const size_t cw = 8 * (size_t)((B + 1) / 2);
+    int bits = 0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const uint32_t n = found_count[b];
+        if (n > found_cap) bits |= 1;
+        if (summary) {
+            reinterpret_cast<uint32_t *>(summary + 16)[b] = n;
+            reinterpret_cast<uint32_t *>(summary + 16 + cw)[b] = nz_count[b];
+        }
     }
-    if (t >= n_tested) return;
-    const double mn = level_stats[((size_t)b * MST_MAX_TESTED + t) * 2];
-    const double sm = level_stats[((size_t)b * MST_MAX_TESTED + t) * 2 + 1];
-    const double cnt = (double)nz_count[b];
-    const double loc = mn;
-    const double scale = sm / cnt - loc;
-    fit[((size_t)b * MST_MAX_TESTED + t) * 2] = loc;
-    fit[((size_t)b * MST_MAX_TESTED + t) * 2 + 1] = scale;
-    if (summary) {
-        double *sf = reinterpret_cast<double *>(summary + 16 + 2 * 8 * (size_t)((B + 1) / 2));
-        sf[((size_t)b * MST_MAX_TESTED + t) * 2] = loc;
-        sf[((size_t)b * MST_MAX_TESTED + t) * 2 + 1] = scale;
+    double *sf = summary ? reinterpret_cast<double *>(summary + 16 + 2 * cw) : nullptr;
+    for (int i = threadIdx.x; i < B * n_tested; i += blockDim.x) {
+        const int b = i / n_tested, t = i - b * n_tested;
+        const double mn = level_stats[((size_t)b * MST_MAX_TESTED + t) * 2];
+        const double sm = level_stats[((size_t)b * MST_MAX_TESTED + t) * 2 + 1];
+        const uint32_t nz = nz_count[b];
+        const double cnt = (double)nz;
+        const double loc = mn;
+        const double scale = sm / cnt - loc;
+        fit[((size_t)b * MST_MAX_TESTED + t) * 2] = loc;
+        fit[((size_t)b * MST_MAX_TESTED + t) * 2 + 1] = scale;
+        if (sf) {
+            sf[((size_t)b * MST_MAX_TESTED + t) * 2] = loc;
+            sf[((size_t)b * MST_MAX_TESTED + t) * 2 + 1] = scale;
+        }
+        if (nz > 0 && !(isfinite(mn) && isfinite(sm))) bits |= 2;
     }
-    if (nz_count[b] > 0 && !(isfinite(mn) && isfinite(sm))) atomicOr(flags, 2);
+    __shared__ int sbits[256];
+    sbits[threadIdx.x] = bits;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sbits[threadIdx.x] |= sbits[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) flags[threadIdx.x] = threadIdx.x == 0 ? sbits[0] : 0;      // the 16-byte header of the summary
 }
 
 // p = 1 - cdf, cdf = -expm1(-x) for x > 0 else 0 (scipy/stats/_distn_infrastructure.py:2127-2139,
@@ -46,14 +66,11 @@ __global__ void fit_kernel(const double *__restrict__ level_stats, const uint32_
 // roundings (E = exp(-x); E - 1; negate; 1 - .) so tiny p-values land on the same 2^-53 grid points.
 __global__ void __launch_bounds__(256)
 pvalue_kernel(const mst_found *__restrict__ found, uint32_t found_cap, const uint32_t *__restrict__ found_count,
-              const double *__restrict__ fit, double *__restrict__ pval, int *__restrict__ flags,
+              const double *__restrict__ fit, double *__restrict__ pval,
               int32_t *__restrict__ pix_out, uint8_t *__restrict__ lvl_out, double *__restrict__ pv_out, uint32_t pitch) {
     const int b = blockIdx.y;
     const uint32_t n = found_count[b];
-    if (n > found_cap) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flags, 1);
-        return;
-    }
+    if (n > found_cap) return;          // fit_kernel has flagged the overflow: the caller re-runs with more room
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const mst_found rec = found[(size_t)b * found_cap + i];
         const int t = (int)rec.level - 1;
@@ -366,13 +383,11 @@ extern "C" int mst_found_pvalues(const mst_found *found, uint32_t found_cap, con
         return mst::fail(MST_E_ARG, "mst_found_pvalues: bad argument");
     hipStream_t s = mst::as_stream(stream);
     int *d_flags = nullptr;
-    MST_HIP(hipMallocAsync((void **)&d_flags, sizeof(int), s));
-    MST_HIP(hipMemsetAsync(d_flags, 0, sizeof(int), s));
-    fit_kernel<<<B, 64, 0, s>>>(level_stats, nz_count, n_tested, fit, d_flags, nullptr, nullptr, B);
+    MST_HIP(hipMallocAsync((void **)&d_flags, 16, s));
+    fit_kernel<<<1, 256, 0, s>>>(level_stats, nz_count, n_tested, fit, d_flags, found_count, found_cap, nullptr, B);
     MST_LAUNCH_CHECK();
     const int gx = (int)((found_cap + 255) / 256 < 256 ? (found_cap + 255) / 256 : 256);
-    pvalue_kernel<<<dim3(gx > 0 ? gx : 1, B), 256, 0, s>>>(found, found_cap, found_count, fit, pval, d_flags, nullptr, nullptr,
-                                                           nullptr, 0);
+    pvalue_kernel<<<dim3(gx > 0 ? gx : 1, B), 256, 0, s>>>(found, found_cap, found_count, fit, pval, nullptr, nullptr, nullptr, 0);
     MST_LAUNCH_CHECK();
     int flags = 0;
     MST_HIP(hipMemcpyAsync(&flags, d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -409,11 +424,10 @@ extern "C" int mst_found_finish(const mst_found *found, uint32_t found_cap, cons
     char *d_sum = static_cast<char *>(scratch_dev);           // device image of the summary (mst_found_summary_bytes(B))
     int *d_flags = reinterpret_cast<int *>(d_sum);
     auto enqueue = [&]() -> int {
-        MST_HIP(hipMemsetAsync(d_flags, 0, 16, s));
-        fit_kernel<<<B, 64, 0, s>>>(level_stats, nz_count, n_tested, fit, d_flags, found_count, d_sum, B);
+        fit_kernel<<<1, 256, 0, s>>>(level_stats, nz_count, n_tested, fit, d_flags, found_count, found_cap, d_sum, B);
         MST_LAUNCH_CHECK();
         const int gx = (int)((found_cap + 255) / 256 < 256 ? (found_cap + 255) / 256 : 256);
-        pvalue_kernel<<<dim3(gx > 0 ? gx : 1, B), 256, 0, s>>>(found, found_cap, found_count, fit, pval, d_flags,
+        pvalue_kernel<<<dim3(gx > 0 ? gx : 1, B), 256, 0, s>>>(found, found_cap, found_count, fit, pval,
                                                                pack_pitch ? pix_out : nullptr, lvl_out, pv_out, pack_pitch);
         MST_LAUNCH_CHECK();
         // ONE copy for everything the host needs before it can size its downloads: flags, record counts, tested-pixel counts, fits
@@ -429,7 +443,7 @@ extern "C" int mst_found_finish(const mst_found *found, uint32_t found_cap, cons
         return MST_OK;
     };
     // MST_FLAG_GRAPH: a call that repeats with every argument unchanged (a caller that keeps its buffers between launches: the
-    // engine's single-launch path) is captured into a hipGraph the second time it is seen and replayed afterwards: the seven
+    // engine's single-launch path) is captured into a hipGraph the second time it is seen and replayed afterwards: the
     // stream operations above become one launch, and the graph's nodes follow each other without a dispatch gap -- they are what
     // stands between the fused kernel's end and the host's wake-up of a SMALL launch (chr21 @ 5 kb: 1.88 -> 1.85 ms per step).
     // Opt-in because it costs large pipelined launches: with the finish of one group replayed as a graph next to the fused
@@ -458,8 +472,8 @@ extern "C" int mst_found_finish(const mst_found *found, uint32_t found_cap, cons
     static thread_local FinishGraph fcache[6];
     static thread_local unsigned long long fstamp = 0;
     static const bool graphs_off = [] {
-        const char *e = getenv("MUSTACHE_NO_GRAPHS");        // diagnostic switch: ordinary stream launches only
-        return e && *e && *e != '0';
+        const char *e = getenv("MUSTACHE_NO_GRAPHS");        // diagnostic switch: 1 = no graphs at all, "finish" = none here
+        return e && *e && *e != '0' && *e != 'l';
     }();
     if ((flags & MST_FLAG_GRAPH) && s != nullptr && !graphs_off) {
         int dev = 0;
@@ -475,6 +489,9 @@ extern "C" int mst_found_finish(const mst_found *found, uint32_t found_cap, cons
         FinishGraph *g = nullptr;
         for (FinishGraph &e : fcache)
             if (e.seen && e.sig == sig) g = &e;
+        mst::note("found_finish graph B=%d cap=%u pitch=%u found=%p count=%p nz=%p stats=%p fit=%p scratch=%p host=%p -> %s", B, found_cap,
+                  pack_pitch, (const void *)found, (const void *)found_count, (const void *)nz_count, (const void *)level_stats,
+                  (const void *)fit, scratch_dev, summary_host, g && g->exec ? "REPLAY" : (g ? "CAPTURE" : "first sight"));
         if (g && g->exec) {
             g->stamp = ++fstamp;
             MST_HIP(hipGraphLaunch(g->exec, s));
@@ -519,12 +536,39 @@ extern "C" int mst_found_finish(const mst_found *found, uint32_t found_cap, cons
     }
 #endif
     if (!done) {
+        if (!(flags & MST_FLAG_GRAPH))
+            mst::note("found_finish plain B=%d cap=%u pitch=%u found=%p count=%p nz=%p stats=%p scratch=%p", B, found_cap, pack_pitch,
+                      (const void *)found, (const void *)found_count, (const void *)nz_count, (const void *)level_stats, scratch_dev);
         const int erc = enqueue();
         if (erc != MST_OK) return erc;
     }
     MST_HIP(hipStreamSynchronize(s));
     int dflags = 0;
     memcpy(&dflags, summary_host, sizeof(int));
+    mst::note("found_finish summary flags=%d", dflags);
+    if (dflags && getenv("MUSTACHE_GRAPH_DEBUG")) {
+        std::vector<double> hs((size_t)B * MST_MAX_TESTED * 2);
+        std::vector<uint32_t> hn((size_t)B);
+        (void)hipMemcpy(hs.data(), level_stats, hs.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hn.data(), nz_count, hn.size() * 4, hipMemcpyDeviceToHost);
+        unsigned devhdr[4] = {0, 0, 0, 0};
+        (void)hipMemcpy(devhdr, d_sum, 16, hipMemcpyDeviceToHost);
+        const unsigned *hh = static_cast<const unsigned *>(summary_host);
+        fprintf(stderr, "[nonfinite] header host %#x %#x %#x %#x | device now %#x %#x %#x %#x\n", hh[0], hh[1], hh[2], hh[3], devhdr[0],
+                devhdr[1], devhdr[2], devhdr[3]);
+        const char *sh = static_cast<const char *>(summary_host);
+        const size_t cw = 8 * (size_t)((B + 1) / 2);
+        const uint32_t *s_cnt = reinterpret_cast<const uint32_t *>(sh + 16), *s_nz = reinterpret_cast<const uint32_t *>(sh + 16 + cw);
+        const double *s_fit = reinterpret_cast<const double *>(sh + 16 + 2 * cw);
+        for (int b = 0; b < B; ++b) {
+            fprintf(stderr, "[nonfinite] block %d: summary count %u nz %u | memory nz %u\n", b, s_cnt[b], s_nz[b], hn[(size_t)b]);
+            for (int t = 0; t < MST_MAX_TESTED; ++t)
+                fprintf(stderr, "[nonfinite]   level %d: summary loc %g scale %g | memory min %g sum %g\n", t,
+                        s_fit[((size_t)b * MST_MAX_TESTED + t) * 2], s_fit[((size_t)b * MST_MAX_TESTED + t) * 2 + 1],
+                        hs[((size_t)b * MST_MAX_TESTED + t) * 2], hs[((size_t)b * MST_MAX_TESTED + t) * 2 + 1]);
+        }
+        mst::dump_notes();
+    }
     if (dflags & 1)
         return mst::fail(MST_E_OVERFLOW, "found-pixel capacity %u exceeded in at least one block", found_cap);
 #ifdef MST_PROFILE

@@ -197,11 +197,13 @@ def run_pair_layout(pipe, lay, gbands, st, pt, pt2):
     CH, distance_in_px, pairs = lay.CH, lay.dpx, lay.ns
     # per block pair in HBM: D_2 of the difference image for every octave + the two samples' record buffers
     per_pair = len(eng.levels.octave_values) * CH * CH * 8 + 2 * max(4096, CH * CH // 32) * 48
-    bs = max(1, int(pipe.max_batch_bytes // per_pair))
+    # groups of block pairs: two are in flight at a time (the device work of group i + 1 runs under the host tail of group i),
+    # each at least ~256 Mpix per sample so that its launches fill the chip
+    bs = max(1, min(int(pipe.max_batch_bytes // (2 * per_pair)), max(pipe.blocks_per_launch(CH), -(-len(lay.blocks) // 4))))
     out = [[] for _ in pairs]
-    for g0 in range(0, len(lay.blocks), bs):
-        grp = lay.blocks[g0:g0 + bs]
-        batch = eng.run_band_pairs(gbands, lay.N, distance_in_px, [g[3] for g in grp], CH, select_below=pt)
+    groups = [lay.blocks[g0:g0 + bs] for g0 in range(0, len(lay.blocks), bs)]
+    for grp, batch in zip(groups, eng.run_band_pairs_overlapped(gbands, lay.N, distance_in_px,
+                                                                [[g[3] for g in grp] for grp in groups], CH, select_below=pt)):
         P = len(grp)
         tails = _pair_tails(batch, [(j, P + j, g[2]) for j, g in enumerate(grp)], pt, pt2, st, True)
         for j, (c, i, s_loc, _) in enumerate(grp):

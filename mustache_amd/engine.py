@@ -864,6 +864,80 @@ class ScaleSpaceEngine:
         batch.norm_fit = nfit.cpu().numpy()
         return batch
 
+    def run_band_pairs_overlapped(self, bands, n, dpx, groups, CH, skip_empty=True, select_below=None):
+        """run_band_pairs over several groups of block pairs with the device work of group i + 1 queued BEFORE the results of
+        group i are collected: the groups' kernels (both samples' sigma loops + the difference kernel) run back to back on two
+        alternating side streams while the caller's host tail of the previous group -- and its small gathers on the caller's
+        stream -- proceed.  Yields one PairBandBatch per group, identical to run_band_pairs(group)."""
+        if len(groups) <= 1 or select_below is None:
+            for starts in groups:
+                yield self.run_band_pairs(bands, n, dpx, starts, CH, skip_empty=skip_empty, select_below=select_below)
+            return
+        cur = torch.cuda.current_stream(self.device)
+        ready = cur.record_event()
+        streams = device_streams(self.device)[:2]
+        lt = self.levels
+        n_oct, tpo = len(lt.octave_values), lt.s - 1
+        lv = ctypes.byref(self._lv_struct)
+
+        def launch(gi, starts):
+            s = streams[gi % 2]
+            s.wait_event(ready)
+            if gi:
+                s.wait_event(launch.prev_done)                   # one group's kernels at a time
+            P = len(starts)
+            with torch.cuda.stream(s), torch.cuda.device(self.device):
+                cap = self._found_cap.get(CH, max(4096, (CH * CH) // 32))
+                nzcs = [torch.empty(P, dtype=torch.int32, device=self.device) for _ in bands]
+                sts = [self._ss_launch(None, None, nzc, skip_empty, cap, None, False,
+                                       (bd, int(n), int(dpx), [int(v) for v in starts], int(CH)))
+                       for bd, nzc in zip(bands, nzcs)]
+                # the difference kernel needs the bands only: queue it behind the sigma loops right away
+                st_arr = (ctypes.c_int64 * P)(*[int(v) for v in starts])
+                dog = torch.empty((n_oct, P, CH, CH), dtype=torch.float64, device=self.device)
+                nfit = torch.empty((n_oct, P, 2), dtype=torch.float64, device=self.device)
+                mcount = torch.empty(P, dtype=torch.int32, device=self.device)
+                ws_bytes = int(self.lib.mst_diff_dog_workspace_bytes(P, CH, lv))
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+                _lib.check(self.lib.mst_diff_dog_band(_ptr(bands[0]), _ptr(bands[1]), int(n), int(dpx), st_arr, P, CH, lv,
+                                                      _ptr(dog), _ptr(nfit), _ptr(mcount), _ptr(ws), ws_bytes, _stream()))
+                launch.prev_done = s.record_event()
+            return dict(stream=s, starts=starts, cap=cap, nzcs=nzcs, sts=sts, dog=dog, nfit=nfit, keep=(ws, mcount, st_arr))
+
+        def collect(g):
+            P = len(g["starts"])
+            with torch.cuda.stream(g["stream"]), torch.cuda.device(self.device):
+                sts = [self._ss_finish(st) for st in g["sts"]]
+                if {st["found_cap"] for st in sts} != {g["cap"]}:
+                    # a record-capacity overflow re-ran a sample with more room: redo this group the plain way
+                    return self.run_band_pairs(bands, n, dpx, g["starts"], CH, skip_empty=skip_empty, select_below=select_below)
+                cap = g["cap"]
+                found = torch.cat([st["found"] for st in sts])
+                pval = torch.cat([st["pval"] for st in sts])
+                count = torch.cat([st["count"] for st in sts])
+                fit = torch.cat([st["fit"] for st in sts])
+                ppair = torch.empty((2 * P, cap), dtype=torch.float64, device=self.device)
+                for off in (0, P):
+                    _lib.check(self.lib.mst_pair_pvalues_dog(_ptr(found), cap, _ptr(count), _ptr(g["dog"]), _ptr(g["nfit"]), P, CH,
+                                                             n_oct, tpo, off, _ptr(ppair), _stream()))
+                recs, fits = self._download_selected(found, pval, count, fit, self.levels.n_tested, cap, float(select_below),
+                                                     pair=(ppair, P))
+                nz_h = np.concatenate([st["nz_h"] for st in sts])
+                norm_fit = g["nfit"].cpu().numpy()
+            batch = PairBandBatch(self, bands, n, dpx, g["starts"], CH, nz_h, recs, fits)
+            batch.norm_fit = norm_fit
+            return batch
+
+        pending = None
+        for gi, starts in enumerate(groups):
+            g = launch(gi, starts)
+            if pending is not None:
+                yield collect(pending)
+            pending = g
+        yield collect(pending)
+        cur.wait_stream(streams[0])
+        cur.wait_stream(streams[1])
+
     def run_block_pairs(self, c, dpx, intra=True, skip_empty=True):
         """c: [2P, CH, CH] raw blocks (sample 1 first, then sample 2), mutated in place.  BlockBatch over all 2P blocks
         whose records also carry `pair` (the differential p-value)."""

@@ -236,6 +236,14 @@ def test_pair_genome_batched_equals_chromosome_by_chromosome():
     for a, b in zip(alone, together):
         assert [(int(r[0]), int(r[1]), float(r[2]), float(r[3]), int(r[4])) for r in a] == \
                [(int(r[0]), int(r[1]), float(r[2]), float(r[3]), int(r[4])) for r in b]
+    # the same with the block pairs cut into several groups: the device work of group i + 1 is queued before group i is
+    # collected (engine.run_band_pairs_overlapped) -- same rows
+    pipe.blocks_per_launch = lambda CH: 1
+    pairs = [normalized_pair_bands(pipe, (a[0], a[1], a[2].copy()), (b[0], b[1], b[2].copy()), res, dpx) for a, b in chroms]
+    piped = run_pair_genome(pipe, pairs, dpx, 0.8, 0.2, 0.2)
+    for a, b in zip(alone, piped):
+        assert [(int(r[0]), int(r[1]), float(r[2]), float(r[3]), int(r[4])) for r in a] == \
+               [(int(r[0]), int(r[1]), float(r[2]), float(r[3]), int(r[4])) for r in b]
 
 
 def test_diff_cli_from_hic_files_equals_cli_from_text(tmp_path):

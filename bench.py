@@ -293,6 +293,7 @@ def file_leg(w, device, keep=200.0, rank=0, world=1, grouped=False, backend="ncc
         h = HicFile(path)
         t_open = time.time() - t0
         passes = []
+        sparse = None
         for rep in range(6):        # pass 1 pays for fresh pages (reader slabs, pinned buffers, allocator); 2-6 = steady state
             barrier()
             t = [time.time()]
@@ -325,6 +326,8 @@ def file_leg(w, device, keep=200.0, rank=0, world=1, grouped=False, backend="ncc
                            "total_s": round(t[4] - t[0], 4), "loops": len(loops), "records": int(sum(recs)), "n": n,
                            "read_s_per_rank": [round(r, 4) for r in reads], "records_per_rank": [int(r) for r in recs],
                            "hic_blocks_total": pc.blocks_total})
+            if rep == 5 and world == 1:
+                sparse = _sparse_step(w, nb, n, device)
             del pc, band, nb
         h.close()
         best = dict(min(passes[1:], key=lambda p: p["total_s"]))
@@ -344,6 +347,8 @@ def file_leg(w, device, keep=200.0, rank=0, world=1, grouped=False, backend="ncc
         best["file"] = {"format": ".hic v8, float counts, 1000-bin blocks, zlib level 1, KR vector of ones",
                         "records_written": int(nrec), "bytes": int(size), "write_s_untimed": round(t_write, 1),
                         "pixel_kept_with_probability": "min(1, %g / (d + 1))" % keep}
+        if sparse is not None:
+            best["sparse_1kb"] = sparse
         best["host_threads"] = os.cpu_count()
         best["note"] = "synthetic chr1@1kb (thinned with the distance), from the open file to the final loop list on %d GPU(s), " \
                        "rank 0's wall clock between barriers: threaded inflate + record decode into per-thread arenas + copy " \
@@ -357,6 +362,34 @@ def file_leg(w, device, keep=200.0, rank=0, world=1, grouped=False, backend="ncc
         if tmp:                     # rank 0 only; every rank is past the closing barrier of the last pass by now
             import shutil
             shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _sparse_step(w, nb, n, device, steps=3):
+    """The fused step on the THINNED band the file leg read (pixel (i, i + d) kept with probability min(1, 200 / (d + 1)): ~30 %
+    of the band's pixels tested instead of the bench band's ~67 %): the same timed region as `value`, dense and tile list.  What
+    it shows: the kernel's time does not depend on how many pixels are tested (no patch of 32 x 16 pixels is empty at this
+    density, LABBOOK.md R4.1b), only the found-set sizes do."""
+    import copy
+    import torch
+    if n != w.n:
+        return None
+    w2 = copy.copy(w)
+    w2.band, w2.kernel_ms = nb, []
+    out = {"tested_share_of_band": round(float((nb[:w.dpx + 1] > 0).sum().item()) / float((w.dpx + 1) * n), 4)}
+    for key, skip in (("dense", False), ("band_skip", True)):
+        w2.step(skip_empty=skip)
+        torch.cuda.synchronize()
+        w2.kernel_ms.clear()
+        t0 = time.time()
+        for _ in range(steps):
+            found = w2.step(skip_empty=skip)
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / steps
+        kms = sum(a.elapsed_time(b) for a, b in w2.kernel_ms) / steps if w2.kernel_ms else None
+        out[key] = {"value": round(w.total_mpix / dt, 1), "unit": "Mpix/s", "ms_per_step": round(dt * 1e3, 2),
+                    "kernel_ms_per_step": None if kms is None else round(kms, 2)}
+    out["note"] = "the file leg's thinned chr1@1kb band through the same step as `value` (dense) / `band_skip` (tile list)"
+    return out
 
 
 def _dense_raw_block(w, block_index):
@@ -896,6 +929,8 @@ def main():
         # every rank takes part (N > 1: each inflates its share of the file, the shares are exchanged); rank 0 reports
         fl = file_leg(w, device, rank=rank, world=world, grouped=grouped, backend=backend)
         out["end_to_end_from_file"] = fl
+        if "sparse_1kb" in fl:
+            out["sparse_1kb"] = fl.pop("sparse_1kb")
         out["ranks"]["read_s"] = fl["read_s_per_rank"]
     if rank == 0 and world == 1 and not args.no_cpu:
         bi = len(w.start) // 2

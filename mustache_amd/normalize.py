@@ -84,6 +84,7 @@ def read_hic_stream_to_device(hic, chrom, res, norm, dpx, chrom_size_bp, device,
     require_gpu()
     t0 = time.time()
     dist_bytes = 2 if dpx + 1 <= 65535 else 4
+    slab_records = int(os.environ.get("MUSTACHE_HIC_SLAB_RECORDS", "0")) or slab_records
     if n_slabs is None:
         # every worker thread fills one slab at a time; a few more keep uploads in flight while they do
         n_slabs = int(os.environ.get("MUSTACHE_HIC_SLABS", "0")) or min(72, max(8, (threads or _reader_threads()) + 8))

@@ -121,6 +121,28 @@ def make_normalize(ref):
     print("normalize fixtures done")
 
 
+def make_normalize_real(ref):
+    """Branch A of normalize_sparse at the REAL window sizes of BASELINE's configurations: 400 bins (5 kb) and 2000 bins (1 kb)
+    -- normalize_A's window is 40.  Integer counts (what a contact map holds), a thinned stretch (window counts < 30 on the far
+    diagonals) and an empty diagonal; the chromosomes are short and the bands narrow so that the reference's O(n * window)
+    np.convolve calls take seconds and the fixtures stay ~1 MB: the window length is what is under test."""
+    for name, n, dpx, res, seed in (("normalize_C.npz", 2600, 56, 5000, 13), ("normalize_D.npz", 5200, 28, 1000, 14)):
+        x, y, v = synth_coo(n, dpx, depth=60.0, seed=seed)
+        d = y - x
+        v = np.round(v) + 1.0
+        keep = np.ones(len(v), bool)
+        keep &= ~((x >= n // 3) & (x < n // 3 + 3 * (2000000 // res) // 2) & ((x + 7 * d) % 23 != 0))   # ~4 % kept over 1.5 windows
+        keep &= d != 17
+        x, y, v = x[keep], y[keep], v[keep].copy()
+        vin = v.copy()
+        w = ref.normalize_sparse(x, y, v, res, dpx)
+        assert (n - dpx) * res > 2000000 and len(w) > 0
+        np.savez_compressed(os.path.join(HERE, name), x=x.astype(np.int32), y=y.astype(np.int32), v_in=vin.astype(np.uint16),
+                            v_out=v, weights=np.array(w), res=res, dpx=dpx, window=int(2000000 / res))
+        assert np.array_equal(vin, vin.astype(np.uint16))
+        print(name, len(v), "records, window", int(2000000 / res))
+
+
 def make_block(ref, name, n, dpx, seed, start, st, pt, depth=300.0, nloops=None, res=50000):
     x, y, v = synth_coo(n, dpx, depth=depth, seed=seed, nloops=nloops)
     ref.normalize_sparse(x, y, v, res, dpx)
@@ -533,6 +555,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["norm", "blocks", "big", "edges", "tiling", "regulator", "krnorm"]
     if "norm" in which:
         make_normalize(ref)
+    if "normreal" in which:         # real window sizes (400 / 2000 bins); ~1 min in the reference
+        make_normalize_real(ref)
     if "blocks" in which:
         make_block(ref, "block_320", 320, 80, seed=1, start=1600, st=0.8, pt=0.2, nloops=30)
         make_block(ref, "block_512", 512, 128, seed=2, start=0, st=0.7, pt=0.2, depth=200.0, nloops=40)

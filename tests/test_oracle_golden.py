@@ -102,10 +102,12 @@ def test_edge_blocks(golden_dir):
     assert oracle.mustache_block(c2, 0, dpx, OCT, 0.8, 0.1) == [] and len(g["loops2"]) == 0
 
 
-@pytest.mark.parametrize("name", ["normalize_A.npz", "normalize_B.npz"])
+@pytest.mark.parametrize("name", ["normalize_A.npz", "normalize_B.npz", "normalize_C.npz", "normalize_D.npz"])
 def test_normalize(golden_dir, name):
+    """A / B: window of 40 bins / the global branch; C / D: the real windows of BASELINE's configurations (400 bins at 5 kb,
+    2000 bins at 1 kb) on integer counts."""
     g = _load(golden_dir, name)
-    v = g["v_in"].copy()
+    v = g["v_in"].astype(np.float64)
     w = oracle.normalize_sparse(g["x"].astype(np.int64), g["y"].astype(np.int64), v, int(g["res"]), int(g["dpx"]))
     # same NumPy build, same np.convolve -> identical; the tolerance only absorbs BLAS dot-order differences
     # between hosts (SURVEY.md section 7, "Normalisation reproducibility")

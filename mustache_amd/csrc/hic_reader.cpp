@@ -381,7 +381,7 @@ bool use_zlib() {
 }
 
 // one zlib stream -> buf (grown until it fits: the uncompressed size is not stored); returns the byte count.
-// `readable_past`: bytes known to be readable behind comp + comp_size (the decoder prefetches up to 16).
+// `readable_past`: bytes known to be readable behind comp + comp_size (the decoder prefetches up to mst_inflate::kSlack).
 size_t inflate_block(const uint8_t *comp, size_t comp_size, size_t readable_past, std::vector<uint8_t> &buf,
                      std::vector<uint8_t> &pad) {
     if (buf.size() < comp_size * 4 + 4096) buf.resize(comp_size * 4 + 4096);

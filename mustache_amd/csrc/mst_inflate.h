@@ -25,7 +25,9 @@
 namespace mst_inflate {
 
 constexpr int kOk = 0, kCorrupt = -1, kOutputFull = -2;
-constexpr size_t kSlack = 16;            // readable bytes past the input, writable bytes past the output capacity
+// readable bytes past the input, writable bytes past the output capacity.  Input: the overrun test lets `in` stand at most 8
+// bytes past the end, at most two refills (7 bytes each) follow before the next test, and a refill loads 8 bytes: 8 + 14 + 8 = 30.
+constexpr size_t kSlack = 32;
 constexpr size_t kOutMargin = 258 + 8;   // the fast loop wants room for one maximal match + copy overshoot
 
 namespace detail {
@@ -284,7 +286,10 @@ inline int inflate_raw(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, s
             if (nlit > 286 || ndist > 30) return kCorrupt;
             uint8_t cl[19] = {0};
             for (int i = 0; i < nclen; ++i) {
-                if (bitcnt < 3) MST_REFILL();
+                if (bitcnt < 3) {
+                    if (MST_OVERRUN()) return kCorrupt;
+                    MST_REFILL();
+                }
                 cl[kOrder[i]] = (uint8_t)MST_TAKE(3);
             }
             uint32_t cltab[128 + 8];
@@ -374,7 +379,8 @@ inline int inflate_raw(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, s
             const uint8_t *from = out - dist;
             uint8_t *const stop = out + len;
             if (len <= 8 && dist >= len) {         // the common case in row lists: 3-4 bytes from a few records back
-                memcpy(out, from, 8);
+                const uint64_t w8 = load64(from);  // load, then store: source and destination may overlap beyond `len`
+                memcpy(out, &w8, 8);
             } else if (dist >= 8) {
                 do {
                     memcpy(out, from, 8);

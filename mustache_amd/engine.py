@@ -390,8 +390,10 @@ class ScaleSpaceEngine:
         packed = download and select_below is None and not sort
         return self._ss_results(self._ss_finish(st, packed=packed), download, sort, with_value, with_q, select_below)
 
-    def _ss_launch(self, c, nz, nz_count, skip_empty, found_cap, timing, fma, band_src, reuse=None, graph=False):
-        """Allocate the outputs and enqueue the fused kernel on the current stream (no synchronisation).  `reuse`: see _carve."""
+    def _ss_launch(self, c, nz, nz_count, skip_empty, found_cap, timing, fma, band_src, reuse=None, graph=False, out=None):
+        """Allocate the outputs and enqueue the fused kernel on the current stream (no synchronisation).  `reuse`: see _carve.
+        `out`: the caller's own buffers instead (dict ws, stats, fit, count, found, pval -- e.g. one sample's rows of buffers
+        that hold both samples of a two-sample call, so that ONE mst_found_finish serves both launches)."""
         if band_src is not None:
             band, bn, bdpx, bstarts, CH = band_src
             B = len(bstarts)
@@ -412,7 +414,8 @@ class ScaleSpaceEngine:
         with torch.cuda.device(self.device):
             # the six launch buffers (kept between calls for small launches, see _carve)
             T = _lib.MST_MAX_TESTED
-            ws, stats, fit, count, found, pval = self._carve(
+            ws, stats, fit, count, found, pval = (out[k] for k in ("ws", "stats", "fit", "count", "found", "pval")) \
+                if out is not None else self._carve(
                 (ws_bytes, torch.uint8, (ws_bytes,)), (B * T * 16, torch.float64, (B, T, 2)),
                 (B * T * 16, torch.float64, (B, T, 2)), (B * 4, torch.int32, (B,)),
                 (B * found_cap * 16, torch.int64, (B, found_cap, 2)),            # 16-byte records
@@ -463,7 +466,7 @@ class ScaleSpaceEngine:
             buf = self._pin[("summary", B)] = torch.empty(need, dtype=torch.uint8, pin_memory=True)
         return buf
 
-    def _ss_finish(self, st, packed=False):
+    def _ss_finish(self, st, packed=False, relaunch=True):
         """p-values of the found pixels (ONE synchronisation of the launch stream: mst_found_finish brings the overflow flag, the
         record counts, the tested-pixel counts and the fits back in the same round trip); a record-capacity overflow re-runs the
         kernel.  packed=True additionally leaves the records' pixel indices / levels as narrow device arrays (st["pix"], st["lvl"])
@@ -499,6 +502,8 @@ class ScaleSpaceEngine:
                                                          8 if st.get("graph") else 0, _stream()))
                     break
                 except _lib.MstOverflow:
+                    if not relaunch:            # the caller owns the launches (several of them behind this one finish)
+                        raise
                     c, nz, nz_count, skip_empty, timing, fma, band_src = st["args"]
                     cap = st["found_cap"] * 4   # rare: a block with an unusually dense set of local maxima
                     self._found_cap[st["CH"]] = cap
@@ -835,33 +840,66 @@ class ScaleSpaceEngine:
         the differential test's look-ups happen on the device and only the selected records come back, each with `pair`,
         `value` and `v_other` (the partner sample's winning value at that pixel, NaN if it did not find it); without it the
         whole found sets are downloaded, sorted by pixel (the cross-check form)."""
+        P = len(starts)
+        lt = self.levels
+        n_oct, tpo = len(lt.octave_values), lt.s - 1
+        lv = ctypes.byref(self._lv_struct)
+        T, nt = _lib.MST_MAX_TESTED, lt.n_tested
+        starts_i = [int(v) for v in starts]
+        st_arr = (ctypes.c_int64 * P)(*starts_i)
         cap = self._found_cap.get(CH, max(4096, (CH * CH) // 32))
-        while True:
-            # both samples' kernels are queued before either is waited for
-            nzcs = [torch.empty(len(starts), dtype=torch.int32, device=self.device) for _ in bands]
-            sts = [self._ss_launch(None, None, nzc, skip_empty, cap, None, False,
-                                   (bd, int(n), int(dpx), [int(v) for v in starts], int(CH)))
-                   for bd, nzc in zip(bands, nzcs)]
-            sts = [self._ss_finish(st) for st in sts]
-            caps = {st["found_cap"] for st in sts}
-            if caps == {cap}:
-                break
-            cap = max(caps)                      # a record-capacity overflow re-ran one sample with more room: redo both alike
-        found = torch.cat([st["found"] for st in sts])
-        pval = torch.cat([st["pval"] for st in sts])
-        count = torch.cat([st["count"] for st in sts])
-        fit = torch.cat([st["fit"] for st in sts])
-        nzc = torch.cat(nzcs)
-        ppair, nfit = self.pair_pvalues_band(bands[0], bands[1], n, dpx, starts, CH, found, cap, count)
-        if select_below is not None:
-            recs, fits = self._download_selected(found, pval, count, fit, self.levels.n_tested, cap, float(select_below),
-                                                 pair=(ppair, len(starts)))
-        else:
-            recs, fits = self._download(found, pval, count, fit, self.levels.n_tested, sort=True,
-                                        extra={"pair": ppair, "q": self.fdr(pval, count, cap)})
-        batch = PairBandBatch(self, bands, n, dpx, starts, CH, nzc.cpu().numpy().view(np.uint32).astype(np.int64), recs,
-                              fits)
-        batch.norm_fit = nfit.cpu().numpy()
+        ws_bytes = self._ws_bytes.get((P, CH))
+        if ws_bytes is None:
+            ws_bytes = self._ws_bytes[(P, CH)] = int(self.lib.mst_scale_space_workspace_bytes(P, CH, lv))
+        with torch.cuda.device(self.device):
+            dog = None
+            while True:
+                # ONE set of record buffers for both samples (sample 1 in rows [0, P), sample 2 in [P, 2P)): the two fused
+                # launches write their halves, one mst_found_finish (one synchronisation) serves both, and nothing has to be
+                # concatenated afterwards.  Small sets are kept between calls (_carve).
+                found, pval, count, stats, fit, nzc, ws1, ws2 = self._carve(
+                    (2 * P * cap * 16, torch.int64, (2 * P, cap, 2)), (2 * P * cap * 8, torch.float64, (2 * P, cap)),
+                    (2 * P * 4, torch.int32, (2 * P,)), (2 * P * T * 16, torch.float64, (2 * P, T, 2)),
+                    (2 * P * T * 16, torch.float64, (2 * P, T, 2)), (2 * P * 4, torch.int32, (2 * P,)),
+                    (ws_bytes, torch.uint8, (ws_bytes,)), (ws_bytes, torch.uint8, (ws_bytes,)), reuse=("pairs", 0))
+                for k, (bd, ws) in enumerate(zip(bands, (ws1, ws2))):
+                    sl = slice(k * P, (k + 1) * P)
+                    self._ss_launch(None, None, nzc[sl], skip_empty, cap, None, False, (bd, int(n), int(dpx), starts_i, int(CH)),
+                                    out=dict(ws=ws, stats=stats[sl], fit=fit[sl], count=count[sl], found=found[sl], pval=pval[sl]))
+                if dog is None:
+                    # the difference kernel needs the bands only: queued behind the sigma loops, before anything is waited for
+                    dog = torch.empty((n_oct, P, CH, CH), dtype=torch.float64, device=self.device)
+                    nfit = torch.empty((n_oct, P, 2), dtype=torch.float64, device=self.device)
+                    mcount = torch.empty(P, dtype=torch.int32, device=self.device)
+                    dws_bytes = int(self.lib.mst_diff_dog_workspace_bytes(P, CH, lv))
+                    dws = torch.empty(dws_bytes, dtype=torch.uint8, device=self.device)
+                    _lib.check(self.lib.mst_diff_dog_band(_ptr(bands[0]), _ptr(bands[1]), int(n), int(dpx), st_arr, P, CH, lv,
+                                                          _ptr(dog), _ptr(nfit), _ptr(mcount), _ptr(dws), dws_bytes, _stream()))
+                st = dict(args=(None, None, nzc, skip_empty, None, False, None), B=2 * P, CH=CH, found_cap=cap, stats=stats,
+                          fit=fit, count=count, found=found, pval=pval, ev=None, reuse=None, graph=False)
+                try:
+                    st = self._ss_finish(st, relaunch=False)
+                    break
+                except _lib.MstOverflow:        # rare: a block with an unusually dense set of local maxima -- both samples again
+                    cap = cap * 4
+                    self._found_cap[CH] = cap
+            ppair = torch.empty((2 * P, cap), dtype=torch.float64, device=self.device)
+            for off in (0, P):
+                _lib.check(self.lib.mst_pair_pvalues_dog(_ptr(found), cap, _ptr(count), _ptr(dog), _ptr(nfit), P, CH, n_oct, tpo,
+                                                         off, _ptr(ppair), _stream()))
+            nfit_p = self._pinned("pair_nfit", tuple(nfit.shape), torch.float64)      # lands with the downloads' synchronisation
+            nfit_p.copy_(nfit, non_blocking=True)
+            host = (st["count_h"], st["fit_h"])
+            if select_below is not None:
+                recs, fits = self._download_selected(found, pval, count, fit, nt, cap, float(select_below), pair=(ppair, P),
+                                                     host=host)
+            else:
+                recs, fits = self._download(found, pval, count, fit, nt, sort=True,
+                                            extra={"pair": ppair, "q": self.fdr(pval, count, cap)}, host=host)
+            torch.cuda.current_stream().synchronize()
+            norm_fit = nfit_p.numpy().copy()
+        batch = PairBandBatch(self, bands, n, dpx, starts, CH, st["nz_h"], recs, fits)
+        batch.norm_fit = norm_fit
         return batch
 
     def run_band_pairs_overlapped(self, bands, n, dpx, groups, CH, skip_empty=True, select_below=None):

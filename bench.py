@@ -255,6 +255,27 @@ def write_synthetic_hic(path, n, dpx, res, depth, nloops, seed, keep, device, bl
     return write_hic_bulk(path, "chr1", n * res, res, blocks(), block_bins, threads=min(32, os.cpu_count() or 4))
 
 
+def _cfs_throttled_ms():
+    """Milliseconds this container's CPU controller has spent throttled so far (cgroup v2 cpu.stat: throttled_usec; v1:
+    throttled_time in ns); None when neither file can be read."""
+    for path, key, scale in (("/sys/fs/cgroup/cpu.stat", "throttled_usec", 1e-3),
+                             ("/sys/fs/cgroup/cpu/cpu.stat", "throttled_time", 1e-6)):
+        try:
+            for line in open(path):
+                f = line.split()
+                if len(f) == 2 and f[0] == key:
+                    return float(f[1]) * scale
+        except OSError:
+            pass
+    return None
+
+
+def _cpu_seconds():
+    import resource
+    r = resource.getrusage(resource.RUSAGE_SELF)
+    return r.ru_utime + r.ru_stime
+
+
 def file_leg(w, device, keep=200.0, rank=0, world=1, grouped=False, backend="nccl"):
     """file -> loops for a config-4-shaped `.hic` (chr1 at 1 kb), stage by stage, on `world` ranks.  The
     records go from the native reader's per-thread arenas into page-locked buffers (int32 bin, int32 distance, float32 value)
@@ -297,6 +318,7 @@ def file_leg(w, device, keep=200.0, rank=0, world=1, grouped=False, backend="ncc
         for rep in range(6):        # pass 1 pays for fresh pages (reader slabs, pinned buffers, allocator); 2-6 = steady state
             barrier()
             t = [time.time()]
+            cpu0, thr0 = _cpu_seconds(), _cfs_throttled_ms()
             if streamed:
                 # slabs of records go to the device while later blocks are still being inflated: when this returns the
                 # records are in HBM (inflate, decode and PCIe overlapped)
@@ -304,6 +326,7 @@ def file_leg(w, device, keep=200.0, rank=0, world=1, grouped=False, backend="ncc
             else:
                 pc = read_intra_packed(h, "chr1", w.res, "KR", w.dpx, 0, alloc=pinned_packed_alloc, part=(rank, world))
             t.append(time.time())
+            cpu1, thr1 = _cpu_seconds(), _cfs_throttled_ms()
             band = band_from_packed(pc, w.dpx, device)      # world > 1: the shares are exchanged in here
             n = int(band.shape[1])
             torch.cuda.synchronize()
@@ -325,7 +348,11 @@ def file_leg(w, device, keep=200.0, rank=0, world=1, grouped=False, backend="ncc
                            "normalize_s": round(t[3] - t[2], 4), "kernels_and_tail_s": round(t[4] - t[3], 4),
                            "total_s": round(t[4] - t[0], 4), "loops": len(loops), "records": int(sum(recs)), "n": n,
                            "read_s_per_rank": [round(r, 4) for r in reads], "records_per_rank": [int(r) for r in recs],
-                           "hic_blocks_total": pc.blocks_total})
+                           "hic_blocks_total": pc.blocks_total,
+                           # the reader's work in core-seconds, and how long the container's CPU quota held its threads back
+                           # while it ran (cgroup cpu.stat) -- why the same read takes 0.064 s in one pass and 0.11 s in the next
+                           "reader_cpu_s": round(cpu1 - cpu0, 3),
+                           "reader_cfs_throttled_ms": None if thr0 is None or thr1 is None else round(thr1 - thr0, 1)})
             if rep == 5 and world == 1:
                 sparse = _sparse_step(w, nb, n, device)
             del pc, band, nb
@@ -335,6 +362,8 @@ def file_leg(w, device, keep=200.0, rank=0, world=1, grouped=False, backend="ncc
         # against 1.6 granted per 100 ms): the spread over the steady-state passes is part of the result
         best["steady_passes_total_s"] = [p["total_s"] for p in passes[1:]]
         best["steady_passes_reader_s"] = [p["inflate_decode_pack_s"] for p in passes[1:]]
+        best["steady_passes_reader_cpu_s"] = [p["reader_cpu_s"] for p in passes[1:]]
+        best["steady_passes_reader_cfs_throttled_ms"] = [p["reader_cfs_throttled_ms"] for p in passes[1:]]
         best["ranks"] = world
         best["reader"] = ("streamed: own inflate (mst_inflate.h) + row-list decode into page-locked slabs of 10 B records, each "
                           "slab copied to the device while later blocks inflate -- `inflate_decode_pack_s` ends with the records "

@@ -104,6 +104,10 @@ def parse():
                          "what the PMC passes of scripts/profile_bench.sh run")
     ap.add_argument("--small", action="store_true", help="debug: 12 blocks instead of 124")
     ap.add_argument("--with-file", action="store_true", help="keep the from-a-.hic-file leg in a --core run")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak (default) = one whole chromosome per rank, the way a genome is partitioned (chromosomes over "
+                         "ranks, no data-path collective); strong = ONE chromosome's blocks in contiguous ranges over the ranks.  "
+                         "The other mode is measured after the headline and reported beside it (`other_scaling`)")
     a = ap.parse_args()
     if a.core:
         a.no_cpu = True
@@ -141,16 +145,29 @@ def make_band(n, dpx, depth, nloops, seed, res, device, reps=8):
 
 
 class Workload:
-    def __init__(self, name, n, dpx, res, depth, nloops, seed, device, rank, world):
+    def __init__(self, name, n, dpx, res, depth, nloops, seed, device, rank, world, scaling="strong"):
         from mustache_amd.pipeline import ChromosomePipeline, block_tiling
         from mustache_amd.sharding import shard_blocks
         self.name, self.n, self.dpx, self.res = name, n, dpx, res
         self.pipe = ChromosomePipeline((1.6, 3.2), device=device)
         self.band, self.normalize_s = make_band(n, dpx, depth, nloops, seed, res, device)
         self.CH, self.start, self.end = block_tiling(n, dpx)
-        self.mine = shard_blocks(len(self.start), rank, world)
-        self.total_mpix = len(self.start) * self.CH * self.CH / 1e6
+        self.rank, self.world = rank, world
+        self.set_scaling(scaling)
         self.kernel_ms = []
+
+    def set_scaling(self, scaling):
+        """weak: every rank runs ALL blocks of its own copy of the chromosome (N ranks = N chromosomes per step: the partition of
+        a genome run); strong: the blocks of ONE chromosome in contiguous ranges over the ranks.  Identical at one rank."""
+        from mustache_amd.sharding import shard_blocks
+        self.scaling = scaling
+        nb = len(self.start)
+        if scaling == "weak":
+            self.mine = list(range(nb))
+            self.total_mpix = self.world * nb * self.CH * self.CH / 1e6
+        else:
+            self.mine = shard_blocks(nb, self.rank, self.world)
+            self.total_mpix = nb * self.CH * self.CH / 1e6
 
     def step(self, skip_empty=False, download=True, fma=False):
         """rows 2-7 for this rank's blocks; returns the found records per group of blocks.  The blocks go through the fused
@@ -529,8 +546,10 @@ def main():
 
     n = 248957 if not args.small else 4000 + 11 * 2000
     w = Workload("chr1@1kb synthetic (n=%d, dpx=2000, %s blocks of 4000x4000 fp64)", n, 2000, 1000, 400.0,
-                 8000 if not args.small else 800, 1, device, rank, world)
+                 8000 if not args.small else 800, 1, device, rank, world, scaling=args.scaling)
     w.name = w.name % (n, len(w.start))
+    if world > 1 and args.scaling == "weak":
+        w.name = "%d x %s, one chromosome per rank" % (world, w.name)
     w.step(False)          # set-up, untimed: first-touch of the pinned staging buffers and the allocator's block cache
 
     def timed(skip_empty, steps, warmup, fma=False):
@@ -689,9 +708,11 @@ def main():
 
     out = {"metric": "scale-space Mpix/s (sigma-stack+local-max)", "value": round(value, 1), "unit": "Mpix/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": w.name, "blocks": len(w.start), "chunk": w.CH, "distance_px": w.dpx,
-                      "megapixels_per_step": round(w.total_mpix, 1), "sharding": "blocks in contiguous ranges over %d rank(s)" % world,
+                      "megapixels_per_step": round(w.total_mpix, 1), "sharding": ("blocks in contiguous ranges over %d rank(s)" % world) if args.scaling == "strong" else
+                                  ("one whole chromosome (%d blocks) per rank, %d rank(s): chromosomes over ranks, no data-path "
+                                   "collective" % (len(w.start), world)),
                       "timed_region": "normalised band in HBM -> fused kernel (blocks cut, filled and masked in-kernel; "
                                       "sigma loop, sieve, level statistics; a tile that lies inside two overlapping blocks of "
                                       "a launch is computed once and its records and statistics delivered to both -- every "
@@ -700,12 +721,15 @@ def main():
                                       "%d launches per step, the download of one under the kernel of the next" % OVERLAP},
            "ranks": {"ms_per_step_max": round(max(owns) / args.steps * 1e3, 3),
                      "ms_per_step_min": round(min(owns) / args.steps * 1e3, 3),
-                     "blocks_per_rank_max": -(-len(w.start) // world), "blocks_per_rank_min": len(w.start) // world,
-                     "imbalance_bound": round(-(-len(w.start) // world) * world / len(w.start), 4),
-                     "efficiency_bound": round(len(w.start) / (world * -(-len(w.start) // world)), 4),
+                     "blocks_per_rank_max": len(w.start) if args.scaling == "weak" else -(-len(w.start) // world),
+                     "blocks_per_rank_min": len(w.start) if args.scaling == "weak" else len(w.start) // world,
+                     "imbalance_bound": 1.0 if args.scaling == "weak" else round(-(-len(w.start) // world) * world / len(w.start), 4),
+                     "efficiency_bound": 1.0 if args.scaling == "weak" else
+                     round(len(w.start) / (world * -(-len(w.start) // world)), 4),
                      "efficiency_bound_at": {str(k): round(len(w.start) / (k * -(-len(w.start) // k)), 4) for k in (1, 2, 4, 8)},
-                     "note": "contiguous split of the blocks: the slowest rank carries ceil(blocks / ranks) blocks, so "
-                             "the strong-scaling efficiency cannot exceed blocks / (ranks * ceil(blocks / ranks))"},
+                     "note": "strong scaling = contiguous split of the blocks: the slowest rank carries ceil(blocks / ranks) "
+                             "blocks, so its efficiency cannot exceed blocks / (ranks * ceil(blocks / ranks)) "
+                             "(efficiency_bound_at); weak scaling gives every rank the same blocks"},
            "roofline": roof, "tile_sharing": tile_sharing, "band_skip": band_skip, "no_share": no_share, "fma_mode": fma_mode,
            "normalize_ms_untimed": round(w.normalize_s * 1e3, 2),
            # row 1 of SURVEY 8a next to it: 16 B per band sample (8 read + 8 written) over mst_normalize_band (median of 3,
@@ -713,6 +737,22 @@ def main():
            "normalize_roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                   "achieved": round(16.0 * (w.dpx + 2) * w.n / w.normalize_s / 1e9, 1),
                                   "frac": round(16.0 * (w.dpx + 2) * w.n / w.normalize_s / 1e9 / HBM_PEAK_GBS, 4)}}
+
+    if world > 1:
+        # the other partitioning, measured after the headline (every rank takes part): strong = one chromosome's blocks over
+        # the ranks, weak = a whole chromosome per rank.  Same step, same timed region, max over ranks.
+        other = "strong" if args.scaling == "weak" else "weak"
+        w.set_scaling(other)
+        dt_o, _, _, owns_o = timed(False, args.steps, 2)
+        out["other_scaling"] = {"scaling": other, "value": round(w.total_mpix / (dt_o / args.steps), 1), "unit": "Mpix/s",
+                                "ms_per_step": round(dt_o / args.steps * 1e3, 3), "megapixels_per_step": round(w.total_mpix, 1),
+                                "blocks_on_this_rank": len(w.mine),
+                                "ms_per_step_max": round(max(owns_o) / args.steps * 1e3, 3),
+                                "ms_per_step_min": round(min(owns_o) / args.steps * 1e3, 3),
+                                "note": "the same step with the other partitioning: strong = the blocks of ONE chromosome in "
+                                        "contiguous ranges over the ranks (what the CLI does for a single chromosome), weak = one "
+                                        "whole chromosome per rank (what it does for a genome)"}
+        w.set_scaling(args.scaling)
 
     if rank == 0 and world == 1 and not args.core:
         # SURVEY 8d defines the metric's timed region from "normalised COO resident on device", i.e. including row 2's scatter

@@ -28,7 +28,7 @@ def _fragments(err):
 def _check_line(j, n_gpus, steps, warmup):
     assert j["metric"].startswith("scale-space Mpix/s") and j["unit"] == "Mpix/s" and j["higher_is_better"] is True
     assert j["n_gpus"] == n_gpus and j["steps"] == steps and j["warmup"] == warmup
-    assert j["dtype"] == "f64" and j["data"] == "synthetic" and j["scaling"] == "strong" and j["vs_baseline"] is None
+    assert j["dtype"] == "f64" and j["data"] == "synthetic" and j["scaling"] in ("weak", "strong") and j["vs_baseline"] is None
     assert abs(j["value"] - j["config"]["megapixels_per_step"] / (j["ms_per_step"] * 1e-3)) < 1e-3 * j["value"]
     r = j["roofline"]
     assert r["bound"] == "fp64_valu" and r["unit"] == "TFLOP/s" and r["peak"] == 39.3
@@ -71,7 +71,12 @@ def test_bench_two_ranks_gloo_one_device():
     assert r.returncode == 0, r.stderr[-3000:]
     j = _last_json(r.stdout)
     _check_line(j, 2, 2, 1)
-    assert j["ranks"]["blocks_per_rank_max"] == 6 and "2 rank" in j["config"]["sharding"]
+    # default: weak scaling (a whole chromosome per rank: 2 x 12 blocks per step); the block-sharded split is measured beside it
+    assert j["scaling"] == "weak" and j["ranks"]["blocks_per_rank_max"] == 12 and "2 rank" in j["config"]["sharding"]
+    assert abs(j["config"]["megapixels_per_step"] - 2 * 12 * 16.0) < 1e-6
+    o = j["other_scaling"]
+    assert o["scaling"] == "strong" and o["blocks_on_this_rank"] == 6 and abs(o["megapixels_per_step"] - 12 * 16.0) < 1e-6
+    assert o["value"] > 0
     frags = _fragments(r.stderr)
     assert sorted(f["rank"] for f in frags) == [0, 1] and all(f["backend"] == "gloo" for f in frags)
     assert "cpu_baseline" not in j and "chr21_5kb" not in j        # rank-0-at-N=1-only legs stay out of the N > 1 line

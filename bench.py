@@ -815,12 +815,23 @@ def main():
         for _ in range(3):
             w5.step(False)
         torch.cuda.synchronize()
-        t0 = time.time()
-        for _ in range(10):
-            w5.step(False)
-        torch.cuda.synchronize()
-        out["chr21_5kb"] = {"value": round(w5.total_mpix / ((time.time() - t0) / 10), 1), "unit": "Mpix/s",
-                            "blocks": len(w5.start), "chunk": w5.CH}
+
+        def per_call_ms(fn, reps):
+            """each call ends with its results on the host (the calls synchronise themselves): wall time per call"""
+            ts = []
+            for _ in range(reps):
+                t0 = time.time()
+                fn()
+                ts.append((time.time() - t0) * 1e3)
+            torch.cuda.synchronize()
+            return sorted(ts)
+
+        ts5 = per_call_ms(lambda: w5.step(False), 40)
+        out["chr21_5kb"] = {"value": round(w5.total_mpix / (ts5[len(ts5) // 2] * 1e-3), 1), "unit": "Mpix/s",
+                            "blocks": len(w5.start), "chunk": w5.CH,
+                            "ms_per_step": {"median": round(ts5[len(ts5) // 2], 3), "min": round(ts5[0], 3),
+                                            "p90": round(ts5[int(0.9 * len(ts5))], 3), "calls": len(ts5)},
+                            "note": "median of 40 calls (a 1.8 ms step is at the mercy of single host hiccups in a mean of 10)"}
         # two-sample path (SURVEY 8a row 10, diff_mustache.py:260-569) on the same shape: both samples' blocks, the sigma
         # loops of both, the difference image with its own blurs, the pair p-values, BH, records on the host
         from mustache_amd.diff_mustache import _pairs_from_filled
@@ -828,11 +839,9 @@ def main():
         for _ in range(2):
             _pairs_from_filled(w5.pipe.engine, w5.pipe, [w5.band, band_b], w5.n, w5.dpx, w5.start, w5.CH, pt=0.1)
         torch.cuda.synchronize()
-        t0 = time.time()
-        for _ in range(5):
-            _pairs_from_filled(w5.pipe.engine, w5.pipe, [w5.band, band_b], w5.n, w5.dpx, w5.start, w5.CH, pt=0.1)
-        torch.cuda.synchronize()
-        pairs_s = w5.total_mpix * 1e6 / ((time.time() - t0) / 5)
+        tsp = per_call_ms(lambda: _pairs_from_filled(w5.pipe.engine, w5.pipe, [w5.band, band_b], w5.n, w5.dpx, w5.start, w5.CH,
+                                                     pt=0.1), 30)
+        pairs_s = w5.total_mpix * 1e6 / (tsp[len(tsp) // 2] * 1e-3)
         # per pixel pair: both samples' sigma loops (2 x 1152 flops) + the difference image's G_2 and G_3 in both octaves
         # (radii 4, 4, 7, 8: 2 x sum(1 + 3 r) = 146 flops); HBM model of SURVEY 8d: 3 x 384 + 3 x 192 + 2 x 24 = 1776 B per pair
         pair_flops = 2 * FLOPS_PER_PIXEL + 146.0
@@ -841,6 +850,8 @@ def main():
         pair_flops_launched = 2 * FLOPS_PER_PIXEL * frac_tiles + 146.0
         out["diff_chr21_5kb"] = {"value": round(pairs_s / 1e6, 1), "unit": "Mpix-pairs/s",
                                  "block_pairs": len(w5.start), "chunk": w5.CH,
+                                 "ms_per_call": {"median": round(tsp[len(tsp) // 2], 3), "min": round(tsp[0], 3),
+                                                 "p90": round(tsp[int(0.9 * len(tsp))], 3), "calls": len(tsp)},
                                  "roofline": {"bound": "fp64_valu", "flops_per_pixel_pair": pair_flops,
                                               "launched_tile_fraction": round(frac_tiles, 4),
                                               "achieved": round(pairs_s * pair_flops_launched / 1e12, 3),

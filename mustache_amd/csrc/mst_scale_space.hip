@@ -635,7 +635,16 @@ int check_levels(const mst_levels *lv, int *max_radius, int *n_tested) {
 #ifdef MST_EXP_DEFAULT_COLS
 // Experiment (round 4, variant builds): the default radii on a K = 4 tile of MST_EXP_DEFAULT_COLS columns -- 96: 768 threads =
 // 12 waves = THREE per SIMD in one workgroup per CU (<= 168 VGPRs, ~115 KB of LDS); 64: 512 threads, two per SIMD
-using TileDefault = Tile<32, MST_EXP_DEFAULT_COLS, 14, 4, 1, false, true>;
+#ifndef MST_EXP_DEFAULT_K
+#define MST_EXP_DEFAULT_K 4
+#endif
+#ifndef MST_EXP_DEFAULT_ROWS
+#define MST_EXP_DEFAULT_ROWS 32
+#endif
+#ifndef MST_EXP_DEFAULT_TIGHT
+#define MST_EXP_DEFAULT_TIGHT true
+#endif
+using TileDefault = Tile<MST_EXP_DEFAULT_ROWS, MST_EXP_DEFAULT_COLS, 14, MST_EXP_DEFAULT_K, 1, false, MST_EXP_DEFAULT_TIGHT>;
 #else
 using TileDefault = Tile<32, 64, 14>;   // the reference's default octaves (radius <= 14)
 #endif

@@ -12,4 +12,4 @@ mkdir -p ../../scratch_libs build_var_$name
     -fno-honor-nans -mno-amdgpu-ieee $flags -c mst_scale_space.hip -o build_var_$name/ss.o
 objs=$(ls build/*.o | grep -v mst_scale_space)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch_libs/$name.so $objs build_var_$name/ss.o
-python ../../scripts/kernel_resources.py ../../scratch_libs/$name.so "scale_space_kernel" | grep "Tile<32, 64, 14, 8, 1, false>" 
+python ../../scripts/kernel_resources.py ../../scratch_libs/$name.so "scale_space_kernel" | grep "Tile<" | grep -v "28, 4" | head -4

@@ -500,9 +500,14 @@ struct SlabSink {
     void *d;
     int dist_bytes;
     int64_t count, cap, y_limit, ymax;
+    void (*on_full)(SlabSink &, void *) = nullptr;        // streamed read: hand the full slab over and continue in a fresh one
+    void *ctx = nullptr;
     void push(int64_t bx, int64_t by, float c) {
         if (by >= y_limit) return;
-        if (count >= cap) throw FormatError{"a block holds more records than its header says"};
+        if (count >= cap) {
+            if (!on_full) throw FormatError{"a block holds more records than its header says"};
+            on_full(*this, ctx);
+        }
         x[count] = (int32_t)bx;
         v[count] = c;
         if (dist_bytes == 2) ((uint16_t *)d)[count] = (uint16_t)(by - bx);
@@ -1084,24 +1089,52 @@ struct mst_hic_stream {
         cv_ready.notify_all();
     }
 
-    void work() {
-        std::vector<uint8_t> buf, pad;
+    struct Cancelled {};
+
+    // One worker: blocks are decoded straight into the slab it holds; a slab is handed over exactly when it is FULL (in the
+    // middle of a block if need be: a block may hold more records than a slab) and at the end of the work list, so the
+    // consumer sees a steady flow of full slabs however many workers there are.
+    struct Worker {
+        mst_hic_stream *s;
         int32_t cur = -1;
-        SlabSink sink{nullptr, nullptr, nullptr, dist_bytes, 0, 0, y_limit, -1};
-        auto publish = [&]() {
+        SlabSink sink;
+        void publish() {
             if (cur < 0) return;
-            std::lock_guard<std::mutex> lk(mu);
-            counts[(size_t)cur] = sink.count;
-            total += sink.count;
+            std::lock_guard<std::mutex> lk(s->mu);
+            s->counts[(size_t)cur] = sink.count;
+            s->total += sink.count;
             if (sink.count > 0) {
-                ready_q.push_back(cur);
-                cv_ready.notify_one();
+                s->ready_q.push_back(cur);
+                s->cv_ready.notify_one();
             } else {
-                free_q.push_back(cur);
-                cv_free.notify_one();
+                s->free_q.push_back(cur);
+                s->cv_free.notify_one();
             }
             cur = -1;
-        };
+        }
+        void next_slab() {
+            publish();
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->cv_free.wait(lk, [&] { return !s->free_q.empty() || s->failed || s->cancelled; });
+            if (s->failed || s->cancelled) throw Cancelled{};
+            cur = s->free_q.front();
+            s->free_q.pop_front();
+            lk.unlock();
+            uint8_t *m = s->slab(cur);
+            sink.x = reinterpret_cast<int32_t *>(m);
+            sink.v = reinterpret_cast<float *>(m + (size_t)s->cap * 4);
+            sink.d = m + (size_t)s->cap * 8;
+            sink.count = 0;
+            sink.cap = s->cap;
+        }
+        static void full(SlabSink &, void *self) { static_cast<Worker *>(self)->next_slab(); }
+    };
+
+    void work() {
+        std::vector<uint8_t> buf, pad;
+        Worker w{this, -1, SlabSink{nullptr, nullptr, nullptr, dist_bytes, 0, 0, y_limit, -1}};
+        w.sink.on_full = &Worker::full;
+        w.sink.ctx = &w;
         try {
             for (;;) {
                 const size_t i = next.fetch_add(1);
@@ -1117,33 +1150,19 @@ struct mst_hic_stream {
                 int32_t n_rec;
                 memcpy(&n_rec, buf.data(), 4);
                 if (n_rec < 0) throw FormatError{"negative record count in a block"};
-                if ((int64_t)n_rec > cap) throw FormatError{"a block holds more records than a slab (raise slab_records)"};
-                if (cur < 0 || sink.count + n_rec > cap) {
-                    publish();
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv_free.wait(lk, [&] { return !free_q.empty() || failed || cancelled; });
-                    if (failed || cancelled) break;
-                    cur = free_q.front();
-                    free_q.pop_front();
-                    lk.unlock();
-                    uint8_t *m = slab(cur);
-                    sink.x = reinterpret_cast<int32_t *>(m);
-                    sink.v = reinterpret_cast<float *>(m + (size_t)cap * 4);
-                    sink.d = m + (size_t)cap * 8;
-                    sink.count = 0;
-                    sink.cap = cap;
-                }
-                if (!decode_rows_fast(h->version, buf.data(), n_out, sink, use_norm ? &norm_vec : nullptr, max_dist))
-                    decode_records(h->version, buf.data(), n_out, sink, use_norm ? &norm_vec : nullptr, max_dist);
+                if (w.cur < 0) w.next_slab();
+                if (!decode_rows_fast(h->version, buf.data(), n_out, w.sink, use_norm ? &norm_vec : nullptr, max_dist))
+                    decode_records(h->version, buf.data(), n_out, w.sink, use_norm ? &norm_vec : nullptr, max_dist);
             }
-            publish();
+            w.publish();
+        } catch (const Cancelled &) {
         } catch (const FormatError &e) {
             fail_with(e.what);
         } catch (...) {
             fail_with("out of memory");
         }
         std::lock_guard<std::mutex> lk(mu);
-        ymax = sink.ymax > ymax ? sink.ymax : ymax;
+        ymax = w.sink.ymax > ymax ? w.sink.ymax : ymax;
         if (--active == 0) cv_ready.notify_all();
     }
 };

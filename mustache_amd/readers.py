@@ -196,12 +196,7 @@ def read_hic_packed(f, norm_method, CHRM_SIZE, distance_in_bp, chr1, res, part=(
             import torch
             from .normalize import read_hic_stream_to_device
             dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-            try:
-                pc = read_hic_stream_to_device(h, chr1, res, norm, int(distance_in_bp // res), int(CHRM_SIZE), dev, part=part)
-            except Exception as e:          # a block with more records than a slab holds (unusual block sizes): one-shot read
-                if "more records than a slab" not in str(e):
-                    raise
-                pc = read_intra_packed(h, chr1, res, norm, int(distance_in_bp // res), int(CHRM_SIZE), alloc=alloc, part=part)
+            pc = read_hic_stream_to_device(h, chr1, res, norm, int(distance_in_bp // res), int(CHRM_SIZE), dev, part=part)
         else:
             pc = read_intra_packed(h, chr1, res, norm, int(distance_in_bp // res), int(CHRM_SIZE), alloc=alloc, part=part)
     if part[1] > 1:

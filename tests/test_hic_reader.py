@@ -324,35 +324,37 @@ def test_streamed_read_equals_packed_read(tmp_path, version, float_counts, dense
         whole = read_intra_packed(h, "chr1", res, "KR", dpx, (n - 3) * res)
         key_w = whole.x.astype(np.int64) * (1 << 20) + whole.dist
         order_w = np.argsort(key_w)
-        cap, n_slabs = 6000, 5
-        mem = np.zeros(n_slabs * cap * (8 + dist_bytes), np.uint8)
-        got_k, got_v, blocks, top = [], [], 0, 0
-        for part in range(n_parts):
-            st = HicStream(h, "chr1", res, "KR", dpx, (n - 3) * res, mem.ctypes.data, n_slabs, cap, dist_bytes, threads=3,
-                           part=(part, n_parts))
-            while True:
-                r = st.next(50)
-                if r is None:
-                    continue
-                if r is False:
-                    break
-                slab, cnt = r
-                assert 0 < cnt <= cap
-                base = slab * cap * (8 + dist_bytes)
-                sx = mem[base:base + 4 * cnt].view(np.int32).astype(np.int64)
-                sv = mem[base + 4 * cap:base + 4 * cap + 4 * cnt].view(np.float32).copy()
-                sd = mem[base + 8 * cap:base + 8 * cap + dist_bytes * cnt].view(np.uint16 if dist_bytes == 2 else np.int32)
-                got_k.append(sx * (1 << 20) + sd.astype(np.int64))
-                got_v.append(sv)
-                st.release(slab)
-            st.close()
-            blocks += st.blocks_mine
-            top = max(top, st.n)
-            assert st.blocks_total == whole.blocks_total
-        k, v = np.concatenate(got_k), np.concatenate(got_v)
-        o = np.argsort(k)
-        assert blocks == whole.blocks_total and top == whole.n and len(k) == len(key_w) > 10000
-        assert np.array_equal(k[o], key_w[order_w]) and np.array_equal(v[o], whole.v[order_w])
+        # slabs larger than any block, and slabs much smaller than a block (a slab is handed over when it is full, in the
+        # middle of a block if need be): the same record set either way
+        for cap, n_slabs in ((6000, 5), (257, 9)):
+            mem = np.zeros(n_slabs * cap * (8 + dist_bytes), np.uint8)
+            got_k, got_v, blocks, top = [], [], 0, 0
+            for part in range(n_parts):
+                st = HicStream(h, "chr1", res, "KR", dpx, (n - 3) * res, mem.ctypes.data, n_slabs, cap, dist_bytes, threads=3,
+                               part=(part, n_parts))
+                while True:
+                    r = st.next(50)
+                    if r is None:
+                        continue
+                    if r is False:
+                        break
+                    slab, cnt = r
+                    assert 0 < cnt <= cap
+                    base = slab * cap * (8 + dist_bytes)
+                    sx = mem[base:base + 4 * cnt].view(np.int32).astype(np.int64)
+                    sv = mem[base + 4 * cap:base + 4 * cap + 4 * cnt].view(np.float32).copy()
+                    sd = mem[base + 8 * cap:base + 8 * cap + dist_bytes * cnt].view(np.uint16 if dist_bytes == 2 else np.int32)
+                    got_k.append(sx * (1 << 20) + sd.astype(np.int64))
+                    got_v.append(sv)
+                    st.release(slab)
+                st.close()
+                blocks += st.blocks_mine
+                top = max(top, st.n)
+                assert st.blocks_total == whole.blocks_total
+            k, v = np.concatenate(got_k), np.concatenate(got_v)
+            o = np.argsort(k)
+            assert blocks == whole.blocks_total and top == whole.n and len(k) == len(key_w) > 10000
+            assert np.array_equal(k[o], key_w[order_w]) and np.array_equal(v[o], whole.v[order_w])
     # the same one-shot read through zlib (cross-check of the own inflate on real block payloads)
     code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
             "from mustache_amd.hicfile import HicFile, read_intra_packed\n"

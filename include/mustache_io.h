@@ -113,8 +113,8 @@ int64_t mst_hic_decode_intra_packed_part(mst_hic *h, const char *chrom, int32_t 
  * blocks are still being inflated, so that the consumer's host-to-device copies overlap the decode: nothing is staged in the
  * handle, nothing is copied twice, the total count is not needed in advance.  `slab_memory` holds n_slabs slabs of
  * slab_records * (8 + dist_bytes) bytes each, laid out {binX int32 [slab_records], value float32 [slab_records], binY - binX
- * uint16 (dist_bytes = 2; needs 0 <= max_dist_bins <= 65535) or int32 (dist_bytes = 4) [slab_records]}; any slab_records >= 1
- * works (a block may hold more records than a slab).  Worker threads (n_threads <= 0: the default pool; never more than
+ * uint16 (dist_bytes = 2; needs 0 <= max_dist_bins <= 65535) or int32 (dist_bytes = 4) [slab_records]}; any EVEN slab_records
+ * works (a block may hold more records than a slab; even, and slab_memory 4-byte aligned, so that every array is aligned).  Worker threads (n_threads <= 0: the default pool; never more than
  * n_slabs - 1) each fill one slab at a time and hand it over exactly when it is FULL -- in the middle of a block if need be --
  * and at the end of the work list: every delivered slab but each worker's last holds slab_records records, so a consumer can
  * move a full slab with one contiguous copy.

@@ -1171,8 +1171,9 @@ extern "C" int mst_hic_stream_open(mst_hic *h, const char *chrom, int32_t resolu
                                    int64_t chrom_size_bp, int32_t n_threads, int32_t part, int32_t n_parts, void *slab_memory,
                                    int32_t n_slabs, int64_t slab_records, int32_t dist_bytes, mst_hic_stream **out) {
     if (!h || !chrom || !out || resolution <= 0 || n_parts < 1 || part < 0 || part >= n_parts || !slab_memory || n_slabs < 2 ||
-        slab_records < 1 || (dist_bytes != 2 && dist_bytes != 4))
-        return fail(MST_IO_E_ARG, "mst_hic_stream_open: bad argument");
+        slab_records < 2 || (slab_records & 1) || (dist_bytes != 2 && dist_bytes != 4) ||
+        (reinterpret_cast<uintptr_t>(slab_memory) & 3))
+        return fail(MST_IO_E_ARG, "mst_hic_stream_open: bad argument (slab_records must be even, slab_memory 4-byte aligned)");
     if (dist_bytes == 2 && (max_dist_bins < 0 || max_dist_bins > 65535))
         return fail(MST_IO_E_ARG, "mst_hic_stream_open: 16-bit distances need 0 <= max_dist_bins <= 65535");
     *out = nullptr;

@@ -326,7 +326,7 @@ def test_streamed_read_equals_packed_read(tmp_path, version, float_counts, dense
         order_w = np.argsort(key_w)
         # slabs larger than any block, and slabs much smaller than a block (a slab is handed over when it is full, in the
         # middle of a block if need be): the same record set either way
-        for cap, n_slabs in ((6000, 5), (257, 9)):
+        for cap, n_slabs in ((6000, 5), (258, 9)):
             mem = np.zeros(n_slabs * cap * (8 + dist_bytes), np.uint8)
             got_k, got_v, blocks, top = [], [], 0, 0
             for part in range(n_parts):

@@ -85,6 +85,7 @@ def read_hic_stream_to_device(hic, chrom, res, norm, dpx, chrom_size_bp, device,
     t0 = time.time()
     dist_bytes = 2 if dpx + 1 <= 65535 else 4
     slab_records = int(os.environ.get("MUSTACHE_HIC_SLAB_RECORDS", "0")) or slab_records
+    slab_records += slab_records & 1              # even: every array of a slab stays 4-byte aligned
     if not threads:
         threads = max(4, _reader_threads() // max(1, int(part[1])))       # ranks of one node share its cores
     if n_slabs is None:

@@ -206,3 +206,26 @@ def test_baseline_size_block_vs_reference(golden_dir, name):
         assert np.array_equal(pix, f["pixel"].astype(np.int64))
         assert np.array_equal(ss.scale[found], f["sigma_values"][f["sigma_index"]])
         assert np.array_equal(ss.best[found], f["value"])
+
+
+def test_benjamini_hochberg_against_scipy():
+    """statsmodels (the reference's `multipletests(..., 'fdr_bh')`, mustache.py:778) is absent here; SciPy ships an independent
+    implementation of the same procedure (scipy.stats.false_discovery_control, method 'bh').  Both restatements -- the oracle's
+    and the host tail's -- must agree with it on random vectors, ties, ones and very small p-values.  Not bit for bit: SciPy
+    multiplies by m / rank where statsmodels divides by rank / m (one or two ulps apart); the ranking, the running minimum from
+    the right, the clip at 1 and the scatter back are what is being cross-checked."""
+    from scipy.stats import false_discovery_control
+    from mustache_amd.tail import benjamini_hochberg as bh_host
+    from oracle.tail import benjamini_hochberg as bh_oracle
+    rng = np.random.default_rng(11)
+    cases = [rng.uniform(0, 1, 1)]
+    for m in (2, 7, 100, 5000):
+        cases.append(rng.uniform(0, 1, m))
+        cases.append(rng.uniform(0, 1, m) ** 6)                                   # many small values
+        cases.append(np.round(rng.uniform(0, 1, m), 2))                           # ties
+        cases.append(np.where(rng.uniform(0, 1, m) < 0.3, 1.0, rng.uniform(0, 1e-12, m)))     # ones and tiny values
+    for p in cases:
+        want = false_discovery_control(p, method="bh")
+        for bh in (bh_oracle, bh_host):
+            np.testing.assert_allclose(bh(p), want, rtol=1e-14, atol=0)
+    assert bh_oracle(np.zeros(0)).size == 0

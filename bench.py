@@ -4,24 +4,22 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (config.workload): the synthetic HFFc6-like chr1 at 1 kb of SURVEY.md section 8d -- n = 248,957 bins,
-distance limit 2,000 bins, 124 overlapping dense blocks of 4000 x 4000 float64 (1,984 Mpix).  One "step" = one
-pass of rows 2-7 of SURVEY.md section 8a over ALL blocks of the chromosome:
-    normalised band resident in HBM -> fused kernel (dense blocks cut out of the band, filled and masked while the tile is
-    staged; sigma-stack / DoG / 3x3 max / sieve / level statistics) -> p-values of the found pixels -> compacted found
-    records on the host.
-With N ranks the 124 blocks are split into N contiguous ranges (strong scaling, no data-path collective); the step time is the
-MAX over ranks between two barriers.  `value` = 1,984 Mpix / step time, whole job.
+Workload (config.workload): the synthetic HFFc6-like chr1 at 1 kb of SURVEY.md section 8d -- n = 248,957 bins, distance
+limit 2,000 bins, 124 overlapping dense blocks of 4000 x 4000 float64 (1,984 Mpix).  One "step" = one pass of rows 2-7
+of SURVEY.md section 8a over ALL blocks of the chromosome: normalised band resident in HBM -> fused kernel (blocks cut out
+of the band, filled and masked while the tile is staged; sigma-stack / DoG / 3x3 max / sieve / level statistics) ->
+p-values of the found pixels -> compacted found records on the host.
 
-Also reported on the same JSON line:
-  roofline      the fused kernel, timed with HIP events on the launch stream, against the roofline that binds it: the
-                FP64 vector pipe WITHOUT fused multiply-add (bit-exactness with SciPy forbids contraction): 1152
-                algorithmic flops per pixel over 39.3 TFLOP/s.  `hbm_model` keeps the
-                level-streaming traffic model of BASELINE.md (592 B per pixel) next to the HBM traffic the kernel
-                really causes (PMC), because the kernel holds all levels on chip and does not follow that model
-  cpu_baseline  the CPU oracle (SciPy calls, the reference's own arithmetic) on ONE block of the same workload
-  band_skip     the same step with empty tiles skipped (identical results; reported separately, not as `value`)
-  chr21_5kb     the 5 kb shape (6 blocks of 2000 x 2000) for the second half of the metric's name
+N ranks = STRONG scaling, the reference's own partition (one process per block of ONE chromosome, mustache.py:913-937):
+the 124 blocks are split into N contiguous ranges, no data-path collective; the step time is the MAX over ranks between
+two barriers and `value` = 1,984 Mpix / that time, whole job, at every N.  (`--scaling weak` = one whole chromosome per
+rank, the genome partition; the mode that is not the headline is timed in the same run and reported as `other_scaling`.)
+
+On the same JSON line: `roofline` (the fused kernel, HIP events on the launch stream, against the FP64 vector pipe WITHOUT
+FMA -- bit-exactness with SciPy forbids contraction: 1152 flops per pixel over 39.3 TFLOP/s; `hbm_model` = SURVEY 8d's
+592 B / pixel model beside the PMC traffic), `cpu_baseline` (the CPU oracle on one block, 1 core), `band_skip` (empty tiles
+skipped: the product mode) and `tile_sharing` / `no_share` (separate speed-ups), `chr21_5kb` / `diff_chr21_5kb`,
+`end_to_end` / `end_to_end_from_file`, `ranks`.  `--extra` adds the side legs of scripts/bench_extra.py.
 """
 import argparse
 import json
@@ -33,10 +31,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-BYTES_PER_PIXEL = 592.0          # BASELINE.md section 3 / SURVEY.md 8d: level-streaming algorithmic traffic, fp64
+BYTES_PER_PIXEL = 592.0          # level-streaming algorithmic traffic, fp64
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6          # FMA-counted vector FP64 peak (256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
 FLOPS_PER_PIXEL = 1152.0         # 24 blurs x 2 axes x (1 + 3 r) non-fusable flops, sum of r = 184
+PEAK_TF = FP64_PEAK_TFLOPS / 2   # add / mul rate without FMA
+OVERLAP = int(os.environ.get("MST_BENCH_OVERLAP", "4"))   # launches per step (copy/compute overlap), see Workload.step
 
 
 def executed_flops_per_pixel():
@@ -52,41 +52,11 @@ def executed_flops_per_pixel():
     return per_region_px * (32 * 64) / (30.0 * 62.0)
 
 
-def band_tile_fraction(CH, dpx):
-    """Share of a block's tiles that the band-direct kernel launches with empty tiles skipped (those whose owned pixels can
-    reach the tested band 4 <= col - row <= dpx + 1) -- asked of the library itself (mst_scale_space_band_tiles)."""
-    import ctypes
-    from mustache_amd import _lib
-    from mustache_amd.levels import LevelTable
-    lv = LevelTable((1.6, 3.2)).as_struct()
-    total = ctypes.c_int32(0)
-    m = _lib.load().mst_scale_space_band_tiles(int(CH), int(dpx), ctypes.byref(lv), ctypes.byref(total))
-    if m < 0 or total.value <= 0:
-        raise RuntimeError("mst_scale_space_band_tiles failed")
-    return m / float(total.value)
-
-
 def work_items(w, skip_empty, share=True):
-    """(workgroups launched, tiles the blocks would run one by one, tiles computed once for two blocks) summed over the
-    launches of one step of workload w -- asked of the library (mst_scale_space_band_items)."""
-    import ctypes
-    from mustache_amd import _lib
-    lib = _lib.load()
-    lv = ctypes.byref(w.pipe.engine._lv_struct)
-    flags = (1 if skip_empty else 0) | (0 if share else 4)
-    tot = [0, 0, 0]
-    per_launch = []
-    for g in w.groups:
-        st = (ctypes.c_int64 * len(g))(*[int(w.start[i]) for i in g])
-        tiles, shared = ctypes.c_int64(), ctypes.c_int64()
-        m = lib.mst_scale_space_band_items(st, len(g), int(w.CH), int(w.dpx), lv, flags, ctypes.byref(tiles), ctypes.byref(shared))
-        if m < 0:
-            raise RuntimeError("mst_scale_space_band_items failed")
-        tot[0] += m
-        tot[1] += tiles.value
-        tot[2] += shared.value
-        per_launch.append(int(m))
-    return tot[0], tot[1], tot[2], per_launch
+    """(workgroups launched, tiles the blocks would run one by one, tiles computed once for two blocks, workgroups per
+    launch) over the launches of one step of workload w -- asked of the library (engine.band_items)."""
+    per = [w.pipe.engine.band_items([w.start[i] for i in g], w.CH, w.dpx, skip_empty, share) for g in w.groups]
+    return sum(p[0] for p in per), sum(p[1] for p in per), sum(p[2] for p in per), [p[0] for p in per]
 
 
 def parse():
@@ -95,27 +65,16 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-procs", type=int, default=16,
-                    help="CPU leg (c) of BASELINE.md section 3: this many blocks in as many worker processes at once (one "
-                         "process per core, capped at 16 by default; 0 = off)")
     ap.add_argument("--no-file", action="store_true", help="skip the end-to-end-from-a-.hic-file leg")
-    ap.add_argument("--core", action="store_true",
-                    help="headline workload only (plus chr21 / band_skip / fma): no genome, variants, file or CPU legs -- "
-                         "what the PMC passes of scripts/profile_bench.sh run")
+    ap.add_argument("--core", action="store_true", help="no file or CPU legs (what the PMC passes of scripts/profile_bench.sh run)")
+    ap.add_argument("--extra", action="store_true", help="add the side legs of scripts/bench_extra.py (N = 1 only)")
     ap.add_argument("--small", action="store_true", help="debug: 12 blocks instead of 124")
-    ap.add_argument("--with-file", action="store_true", help="keep the from-a-.hic-file leg in a --core run")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N > 1: weak (default) = one whole chromosome per rank, the way a genome is partitioned (chromosomes over "
-                         "ranks, no data-path collective); strong = ONE chromosome's blocks in contiguous ranges over the ranks.  "
-                         "The other mode is measured after the headline and reported beside it (`other_scaling`)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: strong (default, the metric) = ONE chromosome's blocks in contiguous ranges over the ranks; weak "
+                         "= one whole chromosome per rank.  The other mode is timed after the headline (`other_scaling`)")
     a = ap.parse_args()
-    if a.core:
-        a.no_cpu = True
-        a.no_file = not a.with_file
+    a.no_cpu, a.no_file = a.no_cpu or a.core, a.no_file or a.core
     return a
-
-
-OVERLAP = int(os.environ.get("MST_BENCH_OVERLAP", "4"))   # launches per step (copy/compute overlap), see Workload.step
 
 
 def make_band(n, dpx, depth, nloops, seed, res, device, reps=8):
@@ -130,8 +89,8 @@ def make_band(n, dpx, depth, nloops, seed, res, device, reps=8):
         raw[:, i0:i1] = band_counts(n, dpx, depth, nloops, seed, i0=i0, i1=i1, device=device)
     band, _, _ = normalize_band(raw, n, dpx, res)      # untimed: code objects, and the allocator's first 4 GB block
     ms = []
-    # steady state: HIP events around mst_normalize_band (both kernels).  The first calls after the generator run slower (the
-    # clocks and the TLB settle over ~4 calls: 3.2, 3.0, 2.9, 2.8, 2.8 ... ms), so 3 more untimed calls precede the median of 5
+    # steady state: HIP events around mst_normalize_band (both kernels); the clocks and the TLB settle over ~4 calls, so 3
+    # more untimed calls precede the median of 5
     for it in range(reps):
         del band
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -147,7 +106,6 @@ def make_band(n, dpx, depth, nloops, seed, res, device, reps=8):
 class Workload:
     def __init__(self, name, n, dpx, res, depth, nloops, seed, device, rank, world, scaling="strong"):
         from mustache_amd.pipeline import ChromosomePipeline, block_tiling
-        from mustache_amd.sharding import shard_blocks
         self.name, self.n, self.dpx, self.res = name, n, dpx, res
         self.pipe = ChromosomePipeline((1.6, 3.2), device=device)
         self.band, self.normalize_s = make_band(n, dpx, depth, nloops, seed, res, device)
@@ -157,8 +115,8 @@ class Workload:
         self.kernel_ms = []
 
     def set_scaling(self, scaling):
-        """weak: every rank runs ALL blocks of its own copy of the chromosome (N ranks = N chromosomes per step: the partition of
-        a genome run); strong: the blocks of ONE chromosome in contiguous ranges over the ranks.  Identical at one rank."""
+        """strong: the blocks of ONE chromosome in contiguous ranges over the ranks (the metric); weak: every rank runs ALL
+        blocks of its own copy of the chromosome (N chromosomes per step).  Identical at one rank."""
         from mustache_amd.sharding import shard_blocks
         self.scaling = scaling
         nb = len(self.start)
@@ -173,269 +131,147 @@ class Workload:
         """rows 2-7 for this rank's blocks; returns the found records per group of blocks.  The blocks go through the fused
         kernel in OVERLAP consecutive launches on alternating streams, so the p-values and the pinned download of one part
         run under the kernel of the next (same total work; the launches never run concurrently)."""
-        pipe = self.pipe
-        groups = getattr(self, "groups", None) if getattr(self, "_groups_for", None) == (tuple(self.mine), OVERLAP) else None
-        if groups is not None:
-            return list(pipe.engine.sigma_loop_band_overlapped(
-                self.band, self.n, self.dpx, self._group_starts, self.CH, skip_empty=skip_empty,
-                download=download, timing=self.kernel_ms, sort=False, with_value=False, with_q=False, fma=fma))
-        groups = []
-        for batch in pipe.batches(self.mine, self.CH, dense=False):
-            # launches of at least ~120 Mpix: smaller ones pay more in launch tails than the overlap wins back
-            k = max(1, min(OVERLAP, len(batch), int(len(batch) * self.CH * self.CH / 120e6)))
-            # the last launch's post-processing is the only one not hidden under a kernel: make that launch the smallest
-            share = {1: [1.0], 2: [0.6, 0.4], 3: [0.4, 0.35, 0.25], 4: [0.29, 0.29, 0.29, 0.13]}.get(k, [1.0 / k] * k)
-            cuts = [0]
-            for f in share[:-1]:
-                cuts.append(min(len(batch) - 1, max(cuts[-1] + 1, int(round(cuts[-1] + f * len(batch))))))
-            cuts.append(len(batch))
-            groups += [batch[a:b] for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
-        self.groups = groups
-        self._groups_for = (tuple(self.mine), OVERLAP)       # the split of the blocks into launches does not change between steps
-        self._group_starts = [[self.start[i] for i in g] for g in groups]
-        # blocks are windows of the band: cut, filled (mustache.py:703-706) and masked (:699) inside the fused kernel;
-        # records = (pixel, level, p-value); the tail orders them by pixel when it needs look-ups
-        return list(pipe.engine.sigma_loop_band_overlapped(
-            self.band, self.n, self.dpx, [[self.start[i] for i in g] for g in groups], self.CH, skip_empty=skip_empty,
+        if getattr(self, "_groups_for", None) != (tuple(self.mine), OVERLAP):
+            groups = []
+            for batch in self.pipe.batches(self.mine, self.CH, dense=False):
+                # launches of at least ~120 Mpix: smaller ones pay more in launch tails than the overlap wins back
+                k = max(1, min(OVERLAP, len(batch), int(len(batch) * self.CH * self.CH / 120e6)))
+                # the last launch's post-processing is the only one not hidden under a kernel: make that launch the smallest
+                share = {1: [1.0], 2: [0.6, 0.4], 3: [0.4, 0.35, 0.25], 4: [0.29, 0.29, 0.29, 0.13]}.get(k, [1.0 / k] * k)
+                cuts = [0]
+                for f in share[:-1]:
+                    cuts.append(min(len(batch) - 1, max(cuts[-1] + 1, int(round(cuts[-1] + f * len(batch))))))
+                cuts.append(len(batch))
+                groups += [batch[a:b] for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+            self.groups = groups                             # the split of the blocks into launches is fixed between steps
+            self._groups_for = (tuple(self.mine), OVERLAP)
+            self._group_starts = [[self.start[i] for i in g] for g in groups]
+        # blocks are windows of the band: cut, filled (mustache.py:703-706) and masked (:699) inside the fused kernel
+        return list(self.pipe.engine.sigma_loop_band_overlapped(
+            self.band, self.n, self.dpx, self._group_starts, self.CH, skip_empty=skip_empty,
             download=download, timing=self.kernel_ms, sort=False, with_value=False, with_q=False, fma=fma))
 
 
-# hg19 chromosome lengths (chr1..22, X, Y), bp: the shape of BASELINE configs 3 and 5 (whole genome at 5 kb)
-HG19 = [249250621, 243199373, 198022430, 191154276, 180915260, 171115067, 159138663, 146364022, 141213431, 135534747,
-        135006516, 133851895, 115169878, 107349540, 102531392, 90354753, 81195210, 78077248, 59128983, 63025520, 48129895,
-        51304566, 155270560, 59373566]
+class Ctx:
+    """what the legs share: the workload, the ranks, and the timed loop of the contract (barrier + synchronize on both sides,
+    MAX over ranks)"""
 
+    def __init__(self, w, args, device, rank, world, grouped, backend):
+        self.w, self.args, self.device, self.rank, self.world, self.grouped, self.backend = w, args, device, rank, world, grouped, backend
 
-class GenomeWorkload(Workload):
-    """All chromosomes of a synthetic hg19-shaped genome at `res` in ONE band (pipeline.GenomeLayout): the blocks of every
-    chromosome go through the same launches.  Same step() as the single-chromosome workload."""
-
-    def __init__(self, name, res, dpx, depth, seed, device, sizes=HG19, two_samples=False):
+    def barrier(self):
         import torch
-        from mustache_amd.pipeline import ChromosomePipeline, GenomeLayout
-        self.name, self.dpx, self.res = name, dpx, res
-        self.pipe = ChromosomePipeline((1.6, 3.2), device=device)
-        ns = [-(-s // res) for s in sizes]
-        self.layout = lay = GenomeLayout(ns, dpx)
-        bands = [[], []]
-        self.normalize_s = 0.0
-        for c, n in enumerate(ns):
-            for smp in range(2 if two_samples else 1):
-                b, t = make_band(n, dpx, depth * (1.0 if smp == 0 else 0.87), max(30, n // 30), seed + 100 * smp + c, res,
-                                 device, reps=1)
-                bands[smp].append(b)
-                self.normalize_s += t
-        self.band = lay.band(bands[0], device)
-        self.band2 = lay.band(bands[1], device) if two_samples else None
-        del bands
-        torch.cuda.empty_cache()
-        self.n, self.CH = lay.N, lay.CH
-        self.start = [g[3] for g in lay.blocks]
-        self.end = None
-        self.mine = list(range(len(self.start)))
-        self.total_mpix = len(self.start) * self.CH * self.CH / 1e6
-        self.kernel_ms = []
-
-
-def write_synthetic_hic(path, n, dpx, res, depth, nloops, seed, keep, device, block_bins=1000):
-    """A config-4-shaped `.hic` file (one chromosome at `res`, version 8, float counts, KR vector of ones) holding the
-    synthetic chromosome with pixel (i, i + d) kept with probability min(1, keep / (d + 1)) -- generated slab by slab on the
-    GPU, written with the bulk writer of tests/hic_writer.py (test infrastructure; untimed).  Returns the record count."""
-    import torch
-    from mustache_amd.synth import band_counts, _uniform
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from hic_writer import write_hic_bulk
-
-    def blocks():
-        d = torch.arange(dpx + 2, dtype=torch.int64, device=device)[:, None]
-        for bx in range(-(-n // block_bins)):
-            i0, i1 = bx * block_bins, min(n, (bx + 1) * block_bins)
-            i = torch.arange(i0, i1, dtype=torch.int64, device=device)[None, :]
-            val = band_counts(n, dpx, depth, nloops, seed, i0=i0, i1=i1, device=device)
-            # thinning grows with the distance (dense near the diagonal, sparse far out, like a real map at 1 kb): pixel
-            # (i, i + d) is kept with probability min(1, keep / (d + 1))
-            val = torch.where(_uniform(seed + 5, d, i, 9) * (d + 1).to(torch.float64) < keep, val, torch.zeros_like(val))
-            dd, cc = torch.nonzero(val > 0, as_tuple=True)
-            x = cc + i0
-            y = x + dd
-            v = val[dd, cc].to(torch.float32)
-            by = y // block_bins
-            order = torch.argsort((by << 42) | (y << 21) | x)
-            x, y, v, by = x[order].to(torch.int32).cpu().numpy(), y[order].to(torch.int32).cpu().numpy(), \
-                v[order].cpu().numpy(), by[order].cpu().numpy()
-            import numpy as np
-            cuts = np.flatnonzero(np.r_[True, by[1:] != by[:-1]]) if len(by) else np.zeros(0, np.int64)
-            cuts = np.append(cuts, len(by))
-            for a, b in zip(cuts[:-1], cuts[1:]):
-                yield bx, int(by[a]), x[a:b], y[a:b], v[a:b]
-
-    return write_hic_bulk(path, "chr1", n * res, res, blocks(), block_bins, threads=min(32, os.cpu_count() or 4))
-
-
-def _cfs_throttled_ms():
-    """Milliseconds this container's CPU controller has spent throttled so far (cgroup v2 cpu.stat: throttled_usec; v1:
-    throttled_time in ns); None when neither file can be read."""
-    for path, key, scale in (("/sys/fs/cgroup/cpu.stat", "throttled_usec", 1e-3),
-                             ("/sys/fs/cgroup/cpu/cpu.stat", "throttled_time", 1e-6)):
-        try:
-            for line in open(path):
-                f = line.split()
-                if len(f) == 2 and f[0] == key:
-                    return float(f[1]) * scale
-        except OSError:
-            pass
-    return None
-
-
-def _cpu_seconds():
-    import resource
-    r = resource.getrusage(resource.RUSAGE_SELF)
-    return r.ru_utime + r.ru_stime
-
-
-def file_leg(w, device, keep=200.0, rank=0, world=1, grouped=False, backend="nccl"):
-    """file -> loops for a config-4-shaped `.hic` (chr1 at 1 kb), stage by stage, on `world` ranks.  The
-    records go from the native reader's per-thread arenas into page-locked buffers (int32 bin, int32 distance, float32 value)
-    and from there to the device loader -- no int64 / float64 COO triple, no Python de-duplication between inflate and H2D.
-    With N > 1 ranks (one process per GPU) the file is read ONCE between them: rank r inflates share r of the blocks
-    (mst_hic_decode_intra_packed_part), the shares are exchanged (sharding.all_gather_packed: RCCL over xGMI from device
-    memory), every rank builds and normalises the same band, runs its contiguous range of blocks, and the loops are gathered
-    -- the times are rank 0's wall clock between two barriers, the per-rank read times are listed beside them."""
-    import tempfile
-    import torch
-    import torch.distributed as dist
-    from mustache_amd.hicfile import HicFile, read_intra_packed
-    from mustache_amd.normalize import band_from_packed, normalize_band, pinned_packed_alloc, read_hic_stream_to_device
-    streamed = os.environ.get("MUSTACHE_HIC_STREAM", "1") != "0"
-
-    def barrier():
-        if grouped:
+        if self.grouped:
+            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(self, skip_empty, steps, warmup, fma=False):
+        """-> (job seconds = max over ranks, this rank's kernel launch times [ms], last step's records, every rank's own
+        seconds up to its stream-synchronised end, before the closing barrier)"""
+        import torch
+        w = self.w
+        for _ in range(warmup):
+            w.step(skip_empty, fma=fma)
+        w.kernel_ms.clear()
+        self.barrier()
+        t0 = time.time()
+        for _ in range(steps):
+            last = w.step(skip_empty, fma=fma)
+        torch.cuda.synchronize()
+        own = time.time() - t0
+        self.barrier()
+        dt = time.time() - t0
+        owns = [own]
+        if self.grouped:
+            import torch.distributed as dist
+            t = torch.tensor([dt, own], dtype=torch.float64, device=self.device if self.backend == "nccl" else "cpu")
+            allt = [torch.zeros_like(t) for _ in range(self.world)]
+            dist.all_gather(allt, t)
+            dt, owns = max(float(a[0]) for a in allt), [float(a[1]) for a in allt]
+        return dt, [a.elapsed_time(b) for a, b in w.kernel_ms], last, owns
+
+
+def file_leg(cx, keep=200.0, on_band=None):
+    """file -> loops for a config-4-shaped `.hic` (chr1 at 1 kb), stage by stage, on all ranks: the native
+    reader inflates on host threads into page-locked slabs that go to the device while later blocks inflate; with N ranks
+    rank r inflates share r of the blocks, the shares are exchanged (sharding.all_gather_packed: RCCL over xGMI from device
+    memory), every rank builds and normalises the same band, runs its contiguous range of blocks, and the loops are
+    gathered.  Times are rank 0's wall clock between two barriers; pass 1 pays for fresh pages, passes 2-6 are the steady
+    state of a whole-genome run.  `total_s` and the stage times beside it are the MEDIAN steady pass (`best_total_s` beside)."""
+    import shutil
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from mustache_amd.hicfile import HicFile
+    from mustache_amd.normalize import band_from_packed, normalize_band, read_hic_stream_to_device
+    w, rank, world = cx.w, cx.rank, cx.world
     tmp = path = None
-    nrec = size = t_write = 0
+    nrec = size = 0
     try:
         if rank == 0:
             tmp = tempfile.mkdtemp(prefix="mst_bench_")
             path = os.path.join(tmp, "chr1_1kb.hic")
-            t0 = time.time()
-            nrec = write_synthetic_hic(path, w.n, w.dpx, w.res, 400.0, 8000 if w.n > 100000 else 800, 1, keep, device)
-            t_write = time.time() - t0
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from hic_writer import write_synthetic_hic          # test infrastructure; untimed
+            nrec = write_synthetic_hic(path, w.n, w.dpx, w.res, 400.0, 8000 if w.n > 100000 else 800, 1, keep, cx.device)
             size = os.path.getsize(path)
-        if grouped:
+        if cx.grouped:
             box = [path]
             dist.broadcast_object_list(box, src=0)          # one node: /tmp is shared by the ranks
             path = box[0]
-        t0 = time.time()
         h = HicFile(path)
-        t_open = time.time() - t0
         passes = []
-        sparse = None
-        for rep in range(6):        # pass 1 pays for fresh pages (reader slabs, pinned buffers, allocator); 2-6 = steady state
-            barrier()
+        for rep in range(6):
+            cx.barrier()
             t = [time.time()]
-            cpu0, thr0 = _cpu_seconds(), _cfs_throttled_ms()
-            if streamed:
-                # slabs of records go to the device while later blocks are still being inflated: when this returns the
-                # records are in HBM (inflate, decode and PCIe overlapped)
-                pc = read_hic_stream_to_device(h, "chr1", w.res, "KR", w.dpx, 0, device, part=(rank, world))
-            else:
-                pc = read_intra_packed(h, "chr1", w.res, "KR", w.dpx, 0, alloc=pinned_packed_alloc, part=(rank, world))
+            cpu0 = time.process_time()             # user + system seconds of all threads
+            pc = read_hic_stream_to_device(h, "chr1", w.res, "KR", w.dpx, 0, cx.device, part=(rank, world))   # records in HBM
             t.append(time.time())
-            cpu1, thr1 = _cpu_seconds(), _cfs_throttled_ms()
-            band = band_from_packed(pc, w.dpx, device)      # world > 1: the shares are exchanged in here
+            cpu1 = time.process_time()
+            band = band_from_packed(pc, w.dpx, cx.device)      # zero fill + scatter; world > 1: the shares are exchanged in here
             n = int(band.shape[1])
             torch.cuda.synchronize()
             t.append(time.time())
             nb, _, _ = normalize_band(band, n, w.dpx, w.res)
             torch.cuda.synchronize()
             t.append(time.time())
-            tm = {}
-            loops = w.pipe.run_band(nb, n, w.dpx, 0.88, 0.1, timings=tm, distributed=grouped)   # blocks sharded, loops gathered
-            barrier()
+            loops = w.pipe.run_band(nb, n, w.dpx, 0.88, 0.1, timings={}, distributed=cx.grouped)   # blocks sharded, loops gathered
+            cx.barrier()
             t.append(time.time())
-            reads = [t[1] - t[0]]
-            recs = [len(pc)]
-            if grouped:
+            reads, recs = [t[1] - t[0]], [len(pc)]
+            if cx.grouped:
                 box = [None] * world
-                dist.all_gather_object(box, (t[1] - t[0], len(pc), pc.blocks_mine))
+                dist.all_gather_object(box, (t[1] - t[0], len(pc)))
                 reads, recs = [b[0] for b in box], [b[1] for b in box]
-            passes.append({"inflate_decode_pack_s": round(t[1] - t[0], 4), "upload_and_band_scatter_s": round(t[2] - t[1], 4),
-                           "normalize_s": round(t[3] - t[2], 4), "kernels_and_tail_s": round(t[4] - t[3], 4),
-                           "total_s": round(t[4] - t[0], 4), "loops": len(loops), "records": int(sum(recs)), "n": n,
-                           "read_s_per_rank": [round(r, 4) for r in reads], "records_per_rank": [int(r) for r in recs],
-                           "hic_blocks_total": pc.blocks_total,
-                           # the reader's work in core-seconds, and how long the container's CPU quota held its threads back
-                           # while it ran (cgroup cpu.stat) -- why the same read takes 0.064 s in one pass and 0.11 s in the next
+            passes.append({"total_s": round(t[4] - t[0], 4), "reader_s": round(t[1] - t[0], 4),
+                           "band_scatter_s": round(t[2] - t[1], 4), "normalize_s": round(t[3] - t[2], 4),
+                           "kernels_and_tail_s": round(t[4] - t[3], 4),
+                           "reader_plus_upload_s": round(t[2] - t[0], 4), "gpu_step_s": round(t[4] - t[2], 4),
                            "reader_cpu_s": round(cpu1 - cpu0, 3),
-                           "reader_cfs_throttled_ms": None if thr0 is None or thr1 is None else round(thr1 - thr0, 1)})
-            if rep == 5 and world == 1:
-                sparse = _sparse_step(w, nb, n, device)
+                           "loops": len(loops), "records": int(sum(recs)), "n": n, "hic_blocks_total": pc.blocks_total,
+                           "read_s_per_rank": [round(r, 4) for r in reads], "records_per_rank": [int(r) for r in recs]})
+            if rep == 5 and on_band is not None:
+                on_band(nb, n)
             del pc, band, nb
         h.close()
-        best = dict(min(passes[1:], key=lambda p: p["total_s"]))
-        # the reader's time depends on where in the container's CPU-quota period a pass starts (1.7 core-seconds of inflate
-        # against 1.6 granted per 100 ms): the spread over the steady-state passes is part of the result
-        best["steady_passes_total_s"] = [p["total_s"] for p in passes[1:]]
-        best["steady_passes_reader_s"] = [p["inflate_decode_pack_s"] for p in passes[1:]]
-        best["steady_passes_reader_cpu_s"] = [p["reader_cpu_s"] for p in passes[1:]]
-        best["steady_passes_reader_cfs_throttled_ms"] = [p["reader_cfs_throttled_ms"] for p in passes[1:]]
-        best["ranks"] = world
-        best["reader"] = ("streamed: own inflate (mst_inflate.h) + row-list decode into page-locked slabs of 10 B records, each "
-                          "slab copied to the device while later blocks inflate -- `inflate_decode_pack_s` ends with the records "
-                          "in HBM, `upload_and_band_scatter_s` is the zero fill + scatter (+ the exchange between ranks)"
-                          if streamed else "one-shot: inflate + decode into arenas, copy into page-locked arrays, then three uploads")
-        best["open_index_s"] = round(t_open, 4)
-        best["reader_plus_upload_s"] = round(best["inflate_decode_pack_s"] + best["upload_and_band_scatter_s"], 4)
-        best["gpu_step_s"] = round(best["normalize_s"] + best["kernels_and_tail_s"], 4)
-        best["first_pass"] = passes[0]
-        best["file"] = {"format": ".hic v8, float counts, 1000-bin blocks, zlib level 1, KR vector of ones",
-                        "records_written": int(nrec), "bytes": int(size), "write_s_untimed": round(t_write, 1),
-                        "pixel_kept_with_probability": "min(1, %g / (d + 1))" % keep}
-        if sparse is not None:
-            best["sparse_1kb"] = sparse
-        best["host_threads"] = os.cpu_count()
-        best["note"] = "synthetic chr1@1kb (thinned with the distance), from the open file to the final loop list on %d GPU(s), " \
-                       "rank 0's wall clock between barriers: threaded inflate + record decode into per-thread arenas + copy " \
-                       "into page-locked buffers (libmustache_io.so; with N ranks each inflates 1/N of the file's blocks and " \
-                       "the packed records are all-gathered), uploads + mst_band_scatter_packed, mst_normalize_band, fused " \
-                       "kernels on this rank's blocks + device BH / selection / clustering + host tail (product mode) + the " \
-                       "gather of the loops.  Best of passes 2-6 (steady state of a whole-genome run: slabs, pinned buffers " \
-                       "and the device allocator warm; all five listed in steady_passes_*); first_pass beside it" % world
-        return best
+        steady = sorted(passes[1:], key=lambda p: p["total_s"])
+        out = dict(steady[len(steady) // 2])
+        out.update({"best_total_s": steady[0]["total_s"], "first_pass_total_s": passes[0]["total_s"], "ranks": world,
+                    "steady_passes": {k: [p[k] for p in passes[1:]] for k in
+                                      ("total_s", "reader_s", "reader_plus_upload_s", "gpu_step_s", "reader_cpu_s")},
+                    "passes_reader_plus_upload_within_gpu_step": sum(p["reader_plus_upload_s"] <= p["gpu_step_s"] for p in passes[1:]),
+                    "file": {"format": ".hic v8, float counts, 1000-bin blocks, zlib level 1, KR vector of ones",
+                             "records_written": int(nrec), "bytes": int(size),
+                             "pixel_kept_with_probability": "min(1, %g / (d + 1))" % keep},
+                    "host_threads": os.cpu_count(),
+                    "note": "open file -> final loop list on %d GPU(s): reader_s ends with the records in HBM, band_scatter_s = zero "
+                            "fill + scatter (+ the exchange between ranks), then normalisation, fused kernels on this rank's blocks "
+                            "+ device BH / selection / clustering + host tail (product mode) + the gather of the loops" % world})
+        return out
     finally:
         if tmp:                     # rank 0 only; every rank is past the closing barrier of the last pass by now
-            import shutil
             shutil.rmtree(tmp, ignore_errors=True)
-
-
-def _sparse_step(w, nb, n, device, steps=3):
-    """The fused step on the THINNED band the file leg read (pixel (i, i + d) kept with probability min(1, 200 / (d + 1)): ~30 %
-    of the band's pixels tested instead of the bench band's ~67 %): the same timed region as `value`, dense and tile list.  What
-    it shows: the kernel's time does not depend on how many pixels are tested (no patch of 32 x 16 pixels is empty at this
-    density, LABBOOK.md R4.1b), only the found-set sizes do."""
-    import copy
-    import torch
-    if n != w.n:
-        return None
-    w2 = copy.copy(w)
-    w2.band, w2.kernel_ms = nb, []
-    out = {"tested_share_of_band": round(float((nb[:w.dpx + 1] > 0).sum().item()) / float((w.dpx + 1) * n), 4)}
-    for key, skip in (("dense", False), ("band_skip", True)):
-        w2.step(skip_empty=skip)
-        torch.cuda.synchronize()
-        w2.kernel_ms.clear()
-        t0 = time.time()
-        for _ in range(steps):
-            found = w2.step(skip_empty=skip)
-        torch.cuda.synchronize()
-        dt = (time.time() - t0) / steps
-        kms = sum(a.elapsed_time(b) for a, b in w2.kernel_ms) / steps if w2.kernel_ms else None
-        out[key] = {"value": round(w.total_mpix / dt, 1), "unit": "Mpix/s", "ms_per_step": round(dt * 1e3, 2),
-                    "kernel_ms_per_step": None if kms is None else round(kms, 2)}
-    out["note"] = "the file leg's thinned chr1@1kb band through the same step as `value` (dense) / `band_skip` (tile list)"
-    return out
 
 
 def _dense_raw_block(w, block_index):
@@ -452,7 +288,7 @@ def _dense_raw_block(w, block_index):
 
 
 def _oracle_block(args):
-    """one block through the oracle's rows 3-7 (runs in a worker process for the -p 4 leg)"""
+    """one block through the oracle's rows 3-7 (the checker and the CPU baseline; also runs in bench_extra's worker processes)"""
     c, dpx, want_set = args
     import numpy as np
     import oracle
@@ -468,20 +304,33 @@ def _oracle_block(args):
     return dt, int(hit.sum()), int(nz.sum()), (pix, ss.level[hit].astype(np.uint32), ss.best[hit], ss.pval[hit])
 
 
-def cpu_baseline(w, block_index):
-    """The oracle (reference arithmetic: SciPy gaussian_filter / maximum_filter / expm1) on one block, 1 core."""
-    return _oracle_block((_dense_raw_block(w, block_index), w.dpx, True))
+def cpu_baseline(w, value):
+    """The oracle (reference arithmetic: SciPy gaussian_filter / maximum_filter / expm1) on the middle block, 1 core, and the
+    same block's found set from the HIP path, launched with its two neighbours so that it RECEIVES the tiles it shares with
+    the block before it and GIVES those it shares with the block after it: the whole found set is compared."""
+    import numpy as np
+    bi = len(w.start) // 2
+    cpu_s, cpu_found, cpu_nz, (cpix, clvl, cval, cp) = _oracle_block((_dense_raw_block(w, bi), w.dpx, True))
+    g = w.pipe.engine.sigma_loop_band(w.band, w.n, w.dpx, [w.start[bi - 1], w.start[bi], w.start[bi + 1]], w.CH,
+                                      skip_empty=False, with_q=False)[0][1]
+    same = (len(g["pixel"]) == cpu_found and np.array_equal(g["pixel"], cpix) and np.array_equal(g["level"], clvl)
+            and np.array_equal(g["value"], cval))
+    p_err = float(np.max(np.abs(g["pval"] - cp) / np.maximum(cp, 1e-300))) if same and cpu_found else None
+    cpu = {"value": round(w.CH * w.CH / 1e6 / cpu_s, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
+           "sample": "block %d of the same workload (one 4000x4000 block, %.1f s), rows 3-7 of the oracle = the reference's "
+                     "SciPy calls, single process.  NOT in this baseline: the reference's normalize_sparse (row 1) and its "
+                     "tail (rows 8-9); the GPU side of the ratio (`value`) is rows 2-7" % (bi, cpu_s),
+           "found_pixels_cpu": cpu_found, "found_pixels_gpu": len(g["pixel"]),
+           "found_set_pixels_levels_values_identical": bool(same), "pvalue_max_rel_err": p_err,
+           "cpu_model": _cpu_model(), "host_cores": os.cpu_count()}
+    return cpu, round(value / cpu["value"], 1)
 
 
-def cpu_baseline_pool(w, block_indices, procs):
-    """`procs` worker processes over the given blocks (the reference's default parallelism is -p 4, mustache.py:146)."""
-    import multiprocessing as mp
-    blocks = [(_dense_raw_block(w, i), w.dpx, False) for i in block_indices]
-    ctx = mp.get_context("spawn")
-    t0 = time.time()
-    with ctx.Pool(procs) as pool:
-        res = pool.map(_oracle_block, blocks, chunksize=1)
-    return time.time() - t0, res
+def _cpu_model():
+    try:
+        return next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        return "unknown"
 
 
 def _free_port():
@@ -492,9 +341,8 @@ def _free_port():
 
 
 def self_launch(args):
-    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves (one process per GPU,
-    torch.distributed.run on 127.0.0.1 with a port that is free right now) and hand their exit code on.  The driver's own
-    `python -m torch.distributed.run ... bench.py --gpus N` keeps working: it sets WORLD_SIZE, and this is skipped."""
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment (WORLD_SIZE unset): start the N ranks ourselves
+    (torch.distributed.run on 127.0.0.1, a port that is free right now) and hand their exit code on."""
     import subprocess
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -503,29 +351,81 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd))
 
 
+def pmc_traffic(px_computed):
+    """HBM bytes per launch from the latest committed PMC session (profiles/rNN_pmc_traffic.json: FETCH_SIZE x 2 on gfx950 +
+    WRITE_SIZE of the fused kernel, its own rocprofv3 --pmc pass), scaled to this launch's computed pixels."""
+    import glob
+    import re
+    cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))
+                   if re.fullmatch(r"r\d+_pmc_traffic\.json", os.path.basename(f)))
+    try:
+        pj = json.load(open(cands[-1]))
+        bpp = pj.get("bytes_per_computed_pixel", pj["bytes_per_pixel"])
+        return round(bpp * px_computed), "profiles/%s (%s; launch form: %s), %.2f B per computed pixel" % (
+            os.path.basename(cands[-1]), pj.get("command", "?"), pj.get("launch_form", "dense, MST_FLAG_NO_SHARE"), bpp)
+    except Exception:
+        return None, None
+
+
+def small_shape_legs(device):
+    """Second half of the metric's name: chr21 @ 5 kb on 1 GPU (6 blocks of 2000 x 2000, one launch), same timed region; and
+    the two-sample call (diff_mustache.py:260-569) on the same shape.  Each call ends with its results on
+    the host: wall time per call, median of many (a 1.8 ms step is at the mercy of single host hiccups in a mean)."""
+    import torch
+    from mustache_amd.diff_mustache import _pairs_from_filled
+    w5 = Workload("chr21@5kb synthetic", 9630, 400, 5000, 300.0, 300, 0, device, 0, 1)
+    band_b, _ = make_band(9630, 400, 260.0, 300, 7, 5000, device)
+
+    def per_call_ms(fn, reps, warm=3):
+        ts = []
+        for i in range(warm + reps):
+            t0 = time.time()
+            fn()
+            if i >= warm:
+                ts.append((time.time() - t0) * 1e3)
+        torch.cuda.synchronize()
+        ts.sort()
+        return {"median": round(ts[len(ts) // 2], 3), "min": round(ts[0], 3), "p90": round(ts[int(0.9 * len(ts))], 3), "calls": len(ts)}
+
+    one = per_call_ms(lambda: w5.step(False), 40)
+    two = per_call_ms(lambda: _pairs_from_filled(w5.pipe.engine, w5.pipe, [w5.band, band_b], w5.n, w5.dpx, w5.start, w5.CH, pt=0.1), 30)
+    pairs_s = w5.total_mpix * 1e6 / (two["median"] * 1e-3)
+    # per pixel pair: both sigma loops (2 x 1152 flops on the launched share of the tiles) + the difference image's G_2, G_3
+    # in both octaves on every tile (radii 4, 4, 7, 8: 146 flops)
+    frac_tiles = w5.pipe.engine.band_tile_fraction(w5.CH, w5.dpx)
+    tf = pairs_s * (2 * FLOPS_PER_PIXEL * frac_tiles + 146.0) / 1e12
+    return ({"value": round(w5.total_mpix / (one["median"] * 1e-3), 1), "unit": "Mpix/s", "blocks": len(w5.start),
+             "chunk": w5.CH, "ms_per_step": one},
+            {"value": round(pairs_s / 1e6, 1), "unit": "Mpix-pairs/s", "block_pairs": len(w5.start), "chunk": w5.CH,
+             "ms_per_call": two,
+             "roofline": {"bound": "fp64_valu", "launched_tile_fraction": round(frac_tiles, 4), "achieved": round(tf, 3),
+                          "peak": PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_TF, 4),
+                          "note": "whole two-sample call, wall clock (both sigma loops with tile lists, mst_diff_dog_band, pair "
+                                  "p-values, BH + selection + partner look-ups on the device, selected records to the host)"}})
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     import torch
     import torch.distributed as dist
+    from mustache_amd.sharding import shard_blocks
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        # the launcher's environment is what the processes really are: say so and go on rather than fail the run
-        print("bench.py: --gpus %d but WORLD_SIZE=%d: running with %d rank(s)" % (args.gpus, world, world), file=sys.stderr,
-              flush=True)
-    # test hooks (used to exercise the N > 1 control flow on a single-GPU box): a gloo process group and all ranks on GPU 0
+    if world != args.gpus:      # the launcher's environment is what the processes really are: say so and go on
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: running with %d rank(s)" % (args.gpus, world, world), file=sys.stderr, flush=True)
+    # test hooks (the N > 1 control flow on a single-GPU box): a gloo process group and all ranks on GPU 0
     backend = os.environ.get("MST_BENCH_BACKEND", "nccl")
     if os.environ.get("MST_BENCH_ONE_DEVICE"):
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    # MST_BENCH_FORCE_DIST=1: join a process group even with one rank, so that the RCCL calls of the N > 1 path (init with
-    # device_id, barrier, all_gather of the timings) execute on a single-GPU box
+    # MST_BENCH_FORCE_DIST=1: a process group even with one rank, so that the RCCL calls of the N > 1 path run on a 1-GPU box
     force_dist = bool(os.environ.get("MST_BENCH_FORCE_DIST")) and world == 1
-    if world > 1 or force_dist:
+    grouped = world > 1 or force_dist
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
             if world > 1:
@@ -537,52 +437,21 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    grouped = world > 1 or force_dist
-
-    def barrier():
-        if grouped:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     n = 248957 if not args.small else 4000 + 11 * 2000
     w = Workload("chr1@1kb synthetic (n=%d, dpx=2000, %s blocks of 4000x4000 fp64)", n, 2000, 1000, 400.0,
                  8000 if not args.small else 800, 1, device, rank, world, scaling=args.scaling)
-    w.name = w.name % (n, len(w.start))
+    nb = len(w.start)
+    w.name = w.name % (n, nb)
     if world > 1 and args.scaling == "weak":
         w.name = "%d x %s, one chromosome per rank" % (world, w.name)
+    cx = Ctx(w, args, device, rank, world, grouped, backend)
     w.step(False)          # set-up, untimed: first-touch of the pinned staging buffers and the allocator's block cache
 
-    def timed(skip_empty, steps, warmup, fma=False):
-        for _ in range(warmup):
-            w.step(skip_empty, fma=fma)
-        w.kernel_ms.clear()
-        barrier()
-        t0 = time.time()
-        for _ in range(steps):
-            last = w.step(skip_empty, fma=fma)
-        torch.cuda.synchronize()
-        own = [time.time() - t0]
-        barrier()
-        dt = time.time() - t0
-        # per-rank view next to the job time: each rank's own work time (stream-synchronised end of its last step, before
-        # the closing barrier) -- max/min over ranks shows the imbalance of the block split
-        torch.cuda.synchronize()
-        t = torch.tensor([dt, own[0]], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        if grouped:
-            allt = [torch.zeros_like(t) for _ in range(world)]
-            dist.all_gather(allt, t)
-            dt = max(float(a[0]) for a in allt)
-            owns = [float(a[1]) for a in allt]
-        else:
-            owns = [own[0]]
-        kms = [a.elapsed_time(b) for a, b in w.kernel_ms]
-        return dt, kms, last, owns
-
-    dt, kms, last, owns = timed(False, args.steps, args.warmup)
+    dt, kms, last, owns = cx.timed(False, args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
     value = w.total_mpix / (dt / args.steps)
 
-    # roofline of the dominant kernel (rank 0's launches): algorithmic flops per launch / event-timed duration
+    # roofline of the dominant kernel (this rank's launches): algorithmic flops per launch / event-timed duration
     launches_per_step = max(1, len(kms) // args.steps)
     k_ms = sum(kms) / len(kms)
     # every rank's own view on stderr, so that a partial failure of an N > 1 run can be told from the log
@@ -591,210 +460,108 @@ def main():
                                          "kernel_ms_mean": round(k_ms, 3), "job_ms_per_step": round(ms_per_step, 3)}),
           file=sys.stderr, flush=True)
     px_per_launch = len(w.mine) * w.CH * w.CH / launches_per_step
-    # Work really executed: a tile that lies inside two overlapping blocks of a launch is computed ONCE (tile sharing), so the
-    # launch's workgroups cover work_items / tiles of the blocks' pixels.  The roofline prices those only (skipped
-    # work is a separate speed-up, never part of the roofline fraction); the saving is reported as `tile_sharing`.
+    # Work really executed: a tile inside two overlapping blocks of a launch is computed ONCE, so the workgroups cover work_items
+    # / tiles of the blocks' pixels.  The roofline prices those only (skipped work is a separate speed-up).
     wi = work_items(w, False)
-    share_ratio = wi[0] / float(wi[1])
-    px_computed = px_per_launch * share_ratio
+    px_computed = px_per_launch * wi[0] / float(wi[1])
     achieved_tf = px_computed * FLOPS_PER_PIXEL / (k_ms * 1e-3) / 1e12
     credited_tf = px_per_launch * FLOPS_PER_PIXEL / (k_ms * 1e-3) / 1e12
     achieved_gbs = px_per_launch * BYTES_PER_PIXEL / (k_ms * 1e-3) / 1e9
-    peak_tf = FP64_PEAK_TFLOPS / 2
     exec_fpp = executed_flops_per_pixel()
-    roof = {"bound": "fp64_valu", "achieved": round(achieved_tf, 3), "peak": peak_tf, "unit": "TFLOP/s",
-            "frac": round(achieved_tf / peak_tf, 4), "traffic": None,
+    traffic, traffic_source = pmc_traffic(px_computed)
+    roof = {"bound": "fp64_valu", "achieved": round(achieved_tf, 3), "peak": PEAK_TF, "unit": "TFLOP/s",
+            "frac": round(achieved_tf / PEAK_TF, 4), "traffic": traffic, "traffic_source": traffic_source,
             "kernel": "scale_space_kernel<Tile<32,64,14>, band>", "kernel_ms": round(k_ms, 3),
             "launches_per_step": launches_per_step, "kernel_ms_per_step": round(k_ms * launches_per_step, 3),
             "pixels_per_launch": int(px_per_launch), "computed_pixels_per_launch": int(round(px_computed)),
-            "flops_per_pixel": FLOPS_PER_PIXEL,
-            "executed_flops_per_pixel": round(exec_fpp, 1),
-            "executed_frac": round(px_computed * exec_fpp / (k_ms * 1e-3) / 1e12 / peak_tf, 4),
+            "flops_per_pixel": FLOPS_PER_PIXEL, "executed_flops_per_pixel": round(exec_fpp, 1),
+            "executed_frac": round(px_computed * exec_fpp / (k_ms * 1e-3) / 1e12 / PEAK_TF, 4),
             "work_items": wi[0], "tiles": wi[1], "shared_tiles": wi[2], "work_items_per_launch": wi[3],
-            "block_pixel_view": {"achieved": round(credited_tf, 3), "frac": round(credited_tf / peak_tf, 4),
-                                 "note": "the same kernel time with every BLOCK pixel credited (a shared tile counted for both "
-                                         "blocks it is delivered to): the throughput view of `value`, NOT the kernel's efficiency"},
-            "note": "peak = FP64 vector add/mul rate without FMA (78.6 TFLOP/s FMA-counted / 2 at the 2.4 GHz spec clock): "
-                    "the taps cannot be contracted into FMAs if the DoG values are to stay bit-identical to SciPy's.  "
-                    "`achieved` = 1152 algorithmic blur flops per pixel x the pixels of the workgroups that RAN "
-                    "(computed_pixels_per_launch = pixels_per_launch x work_items / tiles) / the launch time from HIP events on "
-                    "the launch stream; `executed_*` adds the halo columns and the ring and subtracts the two repeated levels; "
-                    "max / sieve / statistics instructions are not counted",
+            "block_pixel_view": {"achieved": round(credited_tf, 3), "frac": round(credited_tf / PEAK_TF, 4),
+                                 "note": "every BLOCK pixel credited (a shared tile counted twice): the view of `value`, not efficiency"},
+            "note": "peak = FP64 add/mul rate without FMA (78.6 / 2 at the 2.4 GHz spec clock; contraction would break bit-identity "
+                    "with SciPy).  achieved = 1152 blur flops x the pixels of the workgroups that RAN (pixels_per_launch x work_items "
+                    "/ tiles) / launch time (HIP events on the launch stream); executed_* adds halo columns + ring, drops the two "
+                    "repeated levels; max / sieve / statistics are not counted",
             "hbm_model": {"bound": "hbm", "bytes_per_pixel_model": BYTES_PER_PIXEL, "achieved_equivalent": round(achieved_gbs, 1),
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac_of_model_roofline": round(achieved_gbs / HBM_PEAK_GBS, 4),
-                          "note": "level-streaming model of BASELINE.md (every level written and re-read): the rate the "
-                                  "kernel WOULD need if it followed that model -- it does not, see traffic"}}
-    import glob
-    import re
-    cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))
-                   if re.fullmatch(r"r\d+_pmc_traffic\.json", os.path.basename(f)))
-    pmc = cands[-1] if cands else ""                      # the latest round's profiling session
-    if pmc:
-        try:
-            pj = json.load(open(pmc))
-            # bytes per computed pixel of the launch form that is timed here (dense, tiles shared) when the session measured
-            # that form (`launch_form`), else the session's figure per block pixel
-            bpp = pj.get("bytes_per_computed_pixel", pj["bytes_per_pixel"])
-            roof["traffic"] = round(bpp * px_computed)
-            roof["traffic_source"] = "profiles/%s: FETCH_SIZE (x2, gfx950) + WRITE_SIZE of the fused kernel in that " \
-                                     "round's rocprofv3 --pmc pass (%s; launch form: %s), %.2f B per computed pixel" % (
-                                         os.path.basename(pmc), pj.get("command", "?"),
-                                         pj.get("launch_form", "dense, MST_FLAG_NO_SHARE"), bpp)
-        except Exception:
-            pass
+                          "note": "SURVEY 8d's level-streaming model: the rate the kernel WOULD need if it wrote and re-read every "
+                                  "level -- it holds all levels on chip instead, see traffic"}}
 
-    # the same step with empty tiles skipped (separate speed-up, never folded into `value`)
-    dt_s, kms_s, _, _ = timed(True, max(1, args.steps // 2), 1)
-    band_skip = {"value": round(w.total_mpix / (dt_s / max(1, args.steps // 2)), 1), "unit": "Mpix/s",
-                 "speedup": round((dt / args.steps) / (dt_s / max(1, args.steps // 2)), 3),
-                 "kernel_ms_per_step": round(sum(kms_s) / max(1, args.steps // 2), 3),
-                 "launched_tile_fraction": round(band_tile_fraction(w.CH, w.dpx), 4),
-                 "roofline": {"bound": "fp64_valu", "peak": peak_tf, "unit": "TFLOP/s",
-                              "achieved": round(len(w.mine) * w.CH * w.CH * band_tile_fraction(w.CH, w.dpx) * FLOPS_PER_PIXEL
-                                                / (sum(kms_s) / max(1, args.steps // 2) * 1e-3) / 1e12, 3),
-                              "note": "the product mode's own roofline: 1152 algorithmic flops per pixel of the LAUNCHED "
-                                      "tiles (all of them band tiles: real staging, sieve, statistics) over the kernel time"},
-                 "note": "identical results; only the tiles that can reach the tested band are launched -- `value` counts ALL "
-                         "block pixels (the headline value / roofline are always the dense run); band_skip.roofline prices the "
-                         "launched tiles alone"}
-    wis = work_items(w, True)
-    bs_credit = band_skip["roofline"]["achieved"]
-    band_skip["roofline"].update({"achieved": round(bs_credit * wis[0] / wis[1], 3), "frac": round(bs_credit * wis[0] / wis[1] / peak_tf, 4),
-                                  "work_items": wis[0], "tiles": wis[1], "shared_tiles": wis[2], "work_items_per_launch": wis[3],
-                                  "block_pixel_view": {"achieved": round(bs_credit, 3), "frac": round(bs_credit / peak_tf, 4)},
-                                  "note": "the product mode's own roofline: 1152 algorithmic flops per pixel of the band tiles "
-                                          "the workgroups really computed (launched_tile_fraction x block pixels x work_items / "
-                                          "tiles; all of them band tiles: real staging, sieve, statistics) over the kernel "
-                                          "time; block_pixel_view credits a shared tile to both of its blocks"})
-
-    # the same two steps with every tile computed once PER BLOCK on the block's own lattice (MST_FLAG_NO_SHARE, the form of
-    # rounds 1 and 2): identical records; this is the figure that measures the kernel itself
-    w.pipe.engine.share_tiles = False
-    dt_n, kms_n, _, _ = timed(False, max(1, args.steps // 2), 1)
-    dt_ns, kms_ns, _, _ = timed(True, max(1, args.steps // 2), 1)
-    w.pipe.engine.share_tiles = True
+    # the same step with empty tiles skipped (the product mode: identical results, a separate speed-up, never `value`)
     hs = max(1, args.steps // 2)
+    frac = w.pipe.engine.band_tile_fraction(w.CH, w.dpx)
+    dt_s, kms_s, _, _ = cx.timed(True, hs, 1)
+    wis = work_items(w, True)
+    bs_credit = len(w.mine) * w.CH * w.CH * frac * FLOPS_PER_PIXEL / (sum(kms_s) / hs * 1e-3) / 1e12
+    band_skip = {"value": round(w.total_mpix / (dt_s / hs), 1), "unit": "Mpix/s", "speedup": round((dt / args.steps) / (dt_s / hs), 3),
+                 "kernel_ms_per_step": round(sum(kms_s) / hs, 3), "launched_tile_fraction": round(frac, 4),
+                 "roofline": {"bound": "fp64_valu", "peak": PEAK_TF, "unit": "TFLOP/s",
+                              "achieved": round(bs_credit * wis[0] / wis[1], 3), "frac": round(bs_credit * wis[0] / wis[1] / PEAK_TF, 4),
+                              "work_items": wis[0], "tiles": wis[1], "shared_tiles": wis[2], "work_items_per_launch": wis[3],
+                              "block_pixel_view": {"achieved": round(bs_credit, 3), "frac": round(bs_credit / PEAK_TF, 4)},
+                              "note": "1152 flops per pixel of the band tiles the workgroups really computed over the kernel time"},
+                 "note": "only the tiles that can reach the tested band are launched; `value` / `roofline` are always the dense run"}
+
+    # both again with every tile computed once PER BLOCK (MST_FLAG_NO_SHARE): identical records; the kernel's own rate
+    w.pipe.engine.share_tiles = False
+    dt_n, kms_n, _, _ = cx.timed(False, hs, 1)
+    dt_ns, kms_ns, _, _ = cx.timed(True, hs, 1)
+    w.pipe.engine.share_tiles = True
     kn, kns = sum(kms_n) / hs, sum(kms_ns) / hs
     tf_n = len(w.mine) * w.CH * w.CH * FLOPS_PER_PIXEL / (kn * 1e-3) / 1e12
-    tf_ns = len(w.mine) * w.CH * w.CH * band_tile_fraction(w.CH, w.dpx) * FLOPS_PER_PIXEL / (kns * 1e-3) / 1e12
+    tf_ns = len(w.mine) * w.CH * w.CH * frac * FLOPS_PER_PIXEL / (kns * 1e-3) / 1e12
     no_share = {"value": round(w.total_mpix / (dt_n / hs), 1), "unit": "Mpix/s", "kernel_ms_per_step": round(kn, 3),
-                "roofline": {"bound": "fp64_valu", "achieved": round(tf_n, 3), "peak": peak_tf, "unit": "TFLOP/s",
-                             "frac": round(tf_n / peak_tf, 4)},
-                "band_skip": {"value": round(w.total_mpix / (dt_ns / hs), 1), "unit": "Mpix/s",
-                              "kernel_ms_per_step": round(kns, 3),
-                              "roofline": {"bound": "fp64_valu", "achieved": round(tf_ns, 3), "peak": peak_tf,
-                                           "unit": "TFLOP/s", "frac": round(tf_ns / peak_tf, 4)}},
-                "work_items_per_launch": {"dense": work_items(w, False, share=False)[3],
-                                          "band_skip": work_items(w, True, share=False)[3]},
-                "note": "MST_FLAG_NO_SHARE: every workgroup's flops are algorithmic flops of one block -- the kernel's own "
-                        "efficiency, comparable with the roofline figures of rounds 1 and 2"}
-
-    # tile sharing as what it is: skipped work, reported as its own speed-up (like band_skip), not as kernel efficiency
-    tile_sharing = {"speedup": round(value / no_share["value"], 4),
-                    "kernel_speedup": round(kn / (k_ms * launches_per_step), 4),
+                "roofline": {"bound": "fp64_valu", "achieved": round(tf_n, 3), "peak": PEAK_TF, "unit": "TFLOP/s", "frac": round(tf_n / PEAK_TF, 4)},
+                "band_skip": {"value": round(w.total_mpix / (dt_ns / hs), 1), "unit": "Mpix/s", "kernel_ms_per_step": round(kns, 3),
+                              "roofline": {"bound": "fp64_valu", "achieved": round(tf_ns, 3), "peak": PEAK_TF, "unit": "TFLOP/s",
+                                           "frac": round(tf_ns / PEAK_TF, 4)}},
+                "note": "MST_FLAG_NO_SHARE: every workgroup's flops are algorithmic flops of one block -- the kernel's own efficiency"}
+    tile_sharing = {"speedup": round(value / no_share["value"], 4), "kernel_speedup": round(kn / (k_ms * launches_per_step), 4),
                     "band_skip_speedup": round(band_skip["value"] / no_share["band_skip"]["value"], 4),
                     "work_items": wi[0], "tiles": wi[1], "shared_tiles": wi[2],
-                    "note": "consecutive blocks overlap by half their edge at 1 kb (mustache.py:899-908); a tile that lies inside "
-                            "two blocks of a launch with its whole blur halo is computed once and its records / statistics are "
-                            "delivered to both (identical bits: tests, and the CPU leg below compares a whole block's found "
-                            "set).  `value` is the step WITH sharing; no_share re-runs it with every tile once per block"}
+                    "note": "blocks overlap by half their edge at 1 kb (mustache.py:899-908); a tile inside two blocks of a launch is "
+                            "computed once, its records / statistics delivered to both.  `value` is WITH sharing, no_share without"}
 
-    # opt-in relaxed arithmetic (fused multiply-add per tap pair): DoG no longer bit-identical (~1e-16 relative, north_star
-    # allows 1e-5), found set unchanged on every case tested.  Reported separately; `value` is always the exact mode.
-    dt_f, kms_f, _, _ = timed(False, max(1, args.steps // 2), 1, fma=True)
-    fma_mode = {"value": round(w.total_mpix / (dt_f / max(1, args.steps // 2)), 1), "unit": "Mpix/s",
-                "kernel_ms_per_step": round(sum(kms_f) / max(1, args.steps // 2), 3),
-                "note": "MST_FLAG_FMA, dense; not bit-exact DoG, therefore never the headline value"}
-
+    strong = args.scaling == "strong"
+    ranges = [shard_blocks(nb, r, world) for r in range(world)]
+    per_rank = [len(r) for r in ranges] if strong else [nb] * world
     out = {"metric": "scale-space Mpix/s (sigma-stack+local-max)", "value": round(value, 1), "unit": "Mpix/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": w.name, "blocks": len(w.start), "chunk": w.CH, "distance_px": w.dpx,
-                      "megapixels_per_step": round(w.total_mpix, 1), "sharding": ("blocks in contiguous ranges over %d rank(s)" % world) if args.scaling == "strong" else
-                                  ("one whole chromosome (%d blocks) per rank, %d rank(s): chromosomes over ranks, no data-path "
-                                   "collective" % (len(w.start), world)),
-                      "timed_region": "normalised band in HBM -> fused kernel (blocks cut, filled and masked in-kernel; "
-                                      "sigma loop, sieve, level statistics; a tile that lies inside two overlapping blocks of "
-                                      "a launch is computed once and its records and statistics delivered to both -- every "
-                                      "block still receives its complete found set, tested-pixel count and level statistics) "
-                                      "-> p-values -> found records of all 124 blocks on host; "
-                                      "%d launches per step, the download of one under the kernel of the next" % OVERLAP},
-           "ranks": {"ms_per_step_max": round(max(owns) / args.steps * 1e3, 3),
-                     "ms_per_step_min": round(min(owns) / args.steps * 1e3, 3),
-                     "blocks_per_rank_max": len(w.start) if args.scaling == "weak" else -(-len(w.start) // world),
-                     "blocks_per_rank_min": len(w.start) if args.scaling == "weak" else len(w.start) // world,
-                     "imbalance_bound": 1.0 if args.scaling == "weak" else round(-(-len(w.start) // world) * world / len(w.start), 4),
-                     "efficiency_bound": 1.0 if args.scaling == "weak" else
-                     round(len(w.start) / (world * -(-len(w.start) // world)), 4),
-                     "efficiency_bound_at": {str(k): round(len(w.start) / (k * -(-len(w.start) // k)), 4) for k in (1, 2, 4, 8)},
-                     "note": "strong scaling = contiguous split of the blocks: the slowest rank carries ceil(blocks / ranks) "
-                             "blocks, so its efficiency cannot exceed blocks / (ranks * ceil(blocks / ranks)) "
-                             "(efficiency_bound_at); weak scaling gives every rank the same blocks"},
-           "roofline": roof, "tile_sharing": tile_sharing, "band_skip": band_skip, "no_share": no_share, "fma_mode": fma_mode,
-           "normalize_ms_untimed": round(w.normalize_s * 1e3, 2),
-           # row 1 of SURVEY 8a next to it: 16 B per band sample (8 read + 8 written) over mst_normalize_band (median of 3,
-           # HIP events: the per-diagonal statistics pass + the window pass; the statistics pass reads the band once more)
-           "normalize_roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                                  "achieved": round(16.0 * (w.dpx + 2) * w.n / w.normalize_s / 1e9, 1),
-                                  "frac": round(16.0 * (w.dpx + 2) * w.n / w.normalize_s / 1e9 / HBM_PEAK_GBS, 4)}}
+           "config": {"workload": w.name, "blocks": nb, "chunk": w.CH, "distance_px": w.dpx,
+                      "megapixels_per_step": round(w.total_mpix, 1), "partition": "blocks" if strong else "chromosomes",
+                      "sharding": ("the %d blocks of ONE chromosome in contiguous ranges over %d rank(s): %s" % (
+                          nb, world, ", ".join("rank %d = [%d, %d)" % (r, b[0], b[-1] + 1) for r, b in enumerate(ranges) if b)))
+                      if strong else ("one whole chromosome (%d blocks) per rank, %d rank(s)" % (nb, world)),
+                      "timed_region": "normalised band in HBM -> fused kernel (blocks cut, filled, masked in-kernel; sigma loop, sieve, "
+                                      "level statistics) -> p-values -> found records of every block on the host; %d launches per "
+                                      "step, the download of one under the kernel of the next" % OVERLAP},
+           "ranks": {"ms_per_step_max": round(max(owns) / args.steps * 1e3, 3), "ms_per_step_min": round(min(owns) / args.steps * 1e3, 3),
+                     "blocks_per_rank_max": max(per_rank), "blocks_per_rank_min": min(per_rank),
+                     "imbalance_bound": round(max(per_rank) * world / float(sum(per_rank)), 4),
+                     "efficiency_bound": round(sum(per_rank) / float(world * max(per_rank)), 4),
+                     "efficiency_bound_at": {str(k): round(nb / (k * -(-nb // k)), 4) for k in (1, 2, 4, 8)},
+                     "note": "contiguous split: the slowest rank carries ceil(blocks / ranks) blocks -> efficiency_bound_at"},
+           "roofline": roof, "tile_sharing": tile_sharing, "band_skip": band_skip, "no_share": no_share,
+           "normalize_ms_untimed": round(w.normalize_s * 1e3, 2)}
 
     if world > 1:
-        # the other partitioning, measured after the headline (every rank takes part): strong = one chromosome's blocks over
-        # the ranks, weak = a whole chromosome per rank.  Same step, same timed region, max over ranks.
-        other = "strong" if args.scaling == "weak" else "weak"
+        # the other partitioning, timed after the headline (every rank takes part): same step, same timed region, max over ranks
+        other = "weak" if strong else "strong"
         w.set_scaling(other)
-        dt_o, _, _, owns_o = timed(False, args.steps, 2)
+        dt_o, _, _, owns_o = cx.timed(False, args.steps, 2)
         out["other_scaling"] = {"scaling": other, "value": round(w.total_mpix / (dt_o / args.steps), 1), "unit": "Mpix/s",
                                 "ms_per_step": round(dt_o / args.steps * 1e3, 3), "megapixels_per_step": round(w.total_mpix, 1),
                                 "blocks_on_this_rank": len(w.mine),
                                 "ms_per_step_max": round(max(owns_o) / args.steps * 1e3, 3),
                                 "ms_per_step_min": round(min(owns_o) / args.steps * 1e3, 3),
-                                "note": "the same step with the other partitioning: strong = the blocks of ONE chromosome in "
-                                        "contiguous ranges over the ranks (what the CLI does for a single chromosome), weak = one "
-                                        "whole chromosome per rank (what it does for a genome)"}
+                                "note": "weak = a whole chromosome per rank (a genome run); strong = ONE chromosome's blocks over the ranks"}
         w.set_scaling(args.scaling)
 
-    if rank == 0 and world == 1 and not args.core:
-        # SURVEY 8d defines the metric's timed region from "normalised COO resident on device", i.e. including row 2's scatter
-        # (mustache.py:919-924, `cc[xc, yc] = vc`).  Here normalisation runs on the band, so the step above starts one stage
-        # later; this leg times that stage for the same chromosome -- the normalised band's non-zero samples as an int64 /
-        # int64 / float64 COO on the device -> mst_band_from_coo (zero fill + scatter) -- and adds it to the step
-        from mustache_amd.normalize import band_from_coo
-        xs, ys, vs = [], [], []
-        cols = 1 << 15
-        for i0 in range(0, w.n, cols):
-            sl = w.band[:, i0:i0 + cols]
-            dd, cc = torch.nonzero(sl, as_tuple=True)
-            xs.append(cc + i0)
-            ys.append(cc + i0 + dd)
-            vs.append(sl[dd, cc])
-            del dd, cc, sl
-        cx, cy, cv = torch.cat(xs), torch.cat(ys), torch.cat(vs)
-        del xs, ys, vs
-        sc_ms = []
-        for it in range(4):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            rebuilt = band_from_coo(cx, cy, cv, w.n, w.dpx)
-            e1.record()
-            torch.cuda.synchronize()
-            sc_ms.append(e0.elapsed_time(e1))
-            if it == 0:
-                same_band = bool(torch.equal(rebuilt, w.band))
-            del rebuilt
-        sc = sorted(sc_ms[1:])[1] * 1e-3
-        out["row2_scatter"] = {"records": int(cv.numel()), "ms": round(sc * 1e3, 3), "band_rebuilt_identical": same_band,
-                               "GB/s": round((24.0 * cv.numel() + 8.0 * w.band.numel()) / sc / 1e9, 1),
-                               "value_from_coo": round(w.total_mpix / (dt / args.steps + sc), 1), "unit": "Mpix/s",
-                               "note": "mst_band_from_coo on the chromosome's normalised COO (int64 x, int64 y, float64 v on the "
-                                       "device; 24 B read per record + the 8 B/sample zero fill of the band), median of 3, HIP "
-                                       "events; value_from_coo = megapixels / (step + this) = the metric with SURVEY 8d's timed "
-                                       "region 'normalised COO resident on device -> found records on host'"}
-        del cx, cy, cv
-        torch.cuda.empty_cache()
-    if rank == 0 and world == 1:
-        # informational: the whole per-chromosome run from the normalised band (rows 2-9, empty tiles skipped as the
-        # pipeline does by default), next to the untimed normalisation -- NOT part of `value`
+    solo = rank == 0 and world == 1
+    if solo:
+        # informational: the whole per-chromosome run from the normalised band (rows 2-9, product mode) -- NOT part of `value`
         w.pipe.run_band(w.band, w.n, w.dpx, 0.88, 0.1, distributed=False)      # first call: staging buffers, allocator
         runs = []
         for _ in range(3):
@@ -806,271 +573,26 @@ def main():
             runs.append((time.time() - t0, tm.get("tail_s", 0.0)))
         runs.sort()
         out["end_to_end"] = {"rows_2_to_9_s": round(runs[1][0], 3), "normalize_s": round(w.normalize_s, 3),
-                             "tail_s": round(runs[1][1], 3), "loops": len(loops),
-                             "all_runs_s": [round(r[0], 3) for r in runs],
+                             "tail_s": round(runs[1][1], 3), "loops": len(loops), "all_runs_s": [round(r[0], 3) for r in runs],
                              "note": "synthetic chr1@1kb from the normalised band to the final loop list, 1 GPU (median of 3)"}
-    if rank == 0 and world == 1:
-        # second half of the metric's name: chr21 @ 5 kb on 1 GPU (6 blocks of 2000 x 2000), same timed region
-        w5 = Workload("chr21@5kb synthetic", 9630, 400, 5000, 300.0, 300, 0, device, 0, 1)
-        for _ in range(3):
-            w5.step(False)
-        torch.cuda.synchronize()
-
-        def per_call_ms(fn, reps):
-            """each call ends with its results on the host (the calls synchronise themselves): wall time per call"""
-            ts = []
-            for _ in range(reps):
-                t0 = time.time()
-                fn()
-                ts.append((time.time() - t0) * 1e3)
-            torch.cuda.synchronize()
-            return sorted(ts)
-
-        ts5 = per_call_ms(lambda: w5.step(False), 40)
-        out["chr21_5kb"] = {"value": round(w5.total_mpix / (ts5[len(ts5) // 2] * 1e-3), 1), "unit": "Mpix/s",
-                            "blocks": len(w5.start), "chunk": w5.CH,
-                            "ms_per_step": {"median": round(ts5[len(ts5) // 2], 3), "min": round(ts5[0], 3),
-                                            "p90": round(ts5[int(0.9 * len(ts5))], 3), "calls": len(ts5)},
-                            "note": "median of 40 calls (a 1.8 ms step is at the mercy of single host hiccups in a mean of 10)"}
-        # two-sample path (SURVEY 8a row 10, diff_mustache.py:260-569) on the same shape: both samples' blocks, the sigma
-        # loops of both, the difference image with its own blurs, the pair p-values, BH, records on the host
-        from mustache_amd.diff_mustache import _pairs_from_filled
-        band_b, _ = make_band(9630, 400, 260.0, 300, 7, 5000, device)
-        for _ in range(2):
-            _pairs_from_filled(w5.pipe.engine, w5.pipe, [w5.band, band_b], w5.n, w5.dpx, w5.start, w5.CH, pt=0.1)
-        torch.cuda.synchronize()
-        tsp = per_call_ms(lambda: _pairs_from_filled(w5.pipe.engine, w5.pipe, [w5.band, band_b], w5.n, w5.dpx, w5.start, w5.CH,
-                                                     pt=0.1), 30)
-        pairs_s = w5.total_mpix * 1e6 / (tsp[len(tsp) // 2] * 1e-3)
-        # per pixel pair: both samples' sigma loops (2 x 1152 flops) + the difference image's G_2 and G_3 in both octaves
-        # (radii 4, 4, 7, 8: 2 x sum(1 + 3 r) = 146 flops); HBM model of SURVEY 8d: 3 x 384 + 3 x 192 + 2 x 24 = 1776 B per pair
-        pair_flops = 2 * FLOPS_PER_PIXEL + 146.0
-        frac_tiles = band_tile_fraction(w5.CH, w5.dpx)
-        # the two sigma loops skip the tiles that cannot reach the band, mst_diff_dog_band launches every tile
-        pair_flops_launched = 2 * FLOPS_PER_PIXEL * frac_tiles + 146.0
-        out["diff_chr21_5kb"] = {"value": round(pairs_s / 1e6, 1), "unit": "Mpix-pairs/s",
-                                 "block_pairs": len(w5.start), "chunk": w5.CH,
-                                 "ms_per_call": {"median": round(tsp[len(tsp) // 2], 3), "min": round(tsp[0], 3),
-                                                 "p90": round(tsp[int(0.9 * len(tsp))], 3), "calls": len(tsp)},
-                                 "roofline": {"bound": "fp64_valu", "flops_per_pixel_pair": pair_flops,
-                                              "launched_tile_fraction": round(frac_tiles, 4),
-                                              "achieved": round(pairs_s * pair_flops_launched / 1e12, 3),
-                                              "peak": FP64_PEAK_TFLOPS / 2, "unit": "TFLOP/s",
-                                              "frac": round(pairs_s * pair_flops_launched / 1e12 / (FP64_PEAK_TFLOPS / 2), 4),
-                                              "hbm_model": {"bytes_per_pixel_pair_model": 1776.0,
-                                                            "achieved_equivalent": round(pairs_s * 1776.0 / 1e9, 1),
-                                                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                            "frac_of_model_roofline": round(pairs_s * 1776.0 / 1e9 / HBM_PEAK_GBS, 4)},
-                                              "note": "whole two-sample call (both sigma loops band-direct, mst_diff_dog_band, pair "
-                                                      "p-values, BH + selection q < 0.1 + partner look-ups on the device, selected "
-                                                      "records to the host), wall clock.  Empty tiles are skipped, so `achieved` "
-                                                      "counts only the launched share of the sigma loops' tiles (launched_tile_fraction "
-                                                      "x 2304 + 146 flops per pixel pair): at this size (6 block pairs, 2.2 ms) the call "
-                                                      "is launch- and latency-bound, not FP64-bound -- see diff_genome_5kb"},
-                                 "note": "two-sample caller, rows 3-7 for both samples + difference image + pair p-values"}
-        del w5, band_b
-    if rank == 0 and world == 1 and not args.core:
-        # BASELINE configs 3 and 5: a whole hg19-shaped genome at 5 kb (24 chromosomes, ~390 blocks of 2000 x 2000) with all
-        # chromosomes side by side in one band (pipeline.GenomeLayout) -- every launch carries blocks of many chromosomes
-        wg = GenomeWorkload("hg19-shaped genome @5kb synthetic", 5000, 400, 300.0, 1000, device, two_samples=True)
-        gsteps = 3
-        for _ in range(2):
-            wg.step(False)
-        wg.kernel_ms.clear()
-        torch.cuda.synchronize()
-        t0 = time.time()
-        for _ in range(gsteps):
-            wg.step(False)
-        torch.cuda.synchronize()
-        g_dt = (time.time() - t0) / gsteps
-        g_kms = sum(a.elapsed_time(b) for a, b in wg.kernel_ms) / gsteps
-        wg.step(True)
-        wg.kernel_ms.clear()
-        torch.cuda.synchronize()
-        t0 = time.time()
-        for _ in range(gsteps):
-            wg.step(True)
-        torch.cuda.synchronize()
-        g_dt_s = (time.time() - t0) / gsteps
-        g_kms_s = sum(a.elapsed_time(b) for a, b in wg.kernel_ms) / gsteps
-        g_frac = band_tile_fraction(wg.CH, wg.dpx)
-        g_tf = wg.total_mpix * 1e6 * FLOPS_PER_PIXEL / (g_kms * 1e-3) / 1e12
-        g_tf_s = wg.total_mpix * 1e6 * g_frac * FLOPS_PER_PIXEL / (g_kms_s * 1e-3) / 1e12
-        wg.pipe.run_layout(wg.layout, wg.band, 0.88, 0.1)
-        gruns = []
-        for _ in range(3):
-            tmg = {}
-            torch.cuda.synchronize()
-            t0 = time.time()
-            gl = wg.pipe.run_layout(wg.layout, wg.band, 0.88, 0.1, timings=tmg)
-            torch.cuda.synchronize()
-            gruns.append((time.time() - t0, tmg))
-        gruns.sort(key=lambda r: r[0])
-        g_e2e, tmg = gruns[1]
-        out["genome_5kb"] = {"value": round(wg.total_mpix / g_dt, 1), "unit": "Mpix/s", "chromosomes": len(HG19),
-                             "blocks": len(wg.start), "chunk": wg.CH, "band_columns": wg.n,
-                             "megapixels_per_step": round(wg.total_mpix, 1), "ms_per_step": round(g_dt * 1e3, 3),
-                             "vs_chr1_1kb_value": round(wg.total_mpix / g_dt / value, 4),
-                             "vs_chr1_1kb_no_share_value": round(wg.total_mpix / g_dt / no_share["value"], 4),
-                             "roofline": {"bound": "fp64_valu", "achieved": round(g_tf, 3), "peak": peak_tf, "unit": "TFLOP/s",
-                                          "frac": round(g_tf / peak_tf, 4), "kernel_ms_per_step": round(g_kms, 3)},
-                             "band_skip": {"value": round(wg.total_mpix / g_dt_s, 1), "unit": "Mpix/s",
-                                           "launched_tile_fraction": round(g_frac, 4),
-                                           "roofline": {"bound": "fp64_valu", "achieved": round(g_tf_s, 3), "peak": peak_tf,
-                                                        "unit": "TFLOP/s", "frac": round(g_tf_s / peak_tf, 4),
-                                                        "kernel_ms_per_step": round(g_kms_s, 3)}},
-                             "end_to_end": {"rows_2_to_9_s": round(g_e2e, 3), "tail_s": round(tmg.get("tail_s", 0.0), 3),
-                                            "launches": tmg.get("launches"), "loops": sum(len(o) for o in gl),
-                                            "normalize_s_all_chromosomes": round(wg.normalize_s, 4)},
-                             "note": "same timed region as `value` (dense step: fused kernel, p-values, found records to the "
-                                     "host), all chromosomes' blocks batched into the same launches; band_skip / end_to_end = "
-                                     "the product mode (tile lists; + BH, selection, filters, clustering, overlap masks).  At 5 kb "
-                                     "blocks of 2000 overlap by 400 bins only, so tile sharing saves ~4 % here against ~22-30 % at "
-                                     "1 kb: vs_chr1_1kb_no_share_value is the like-for-like ratio (launch-boundness), "
-                                     "vs_chr1_1kb_value includes the 1 kb run's sharing"}
-        # two-sample whole genome (config 5): every block pair of every chromosome in ONE run_band_pairs call
-        eng = wg.pipe.engine
-        for _ in range(2):
-            eng.run_band_pairs([wg.band, wg.band2], wg.n, wg.dpx, wg.start, wg.CH, select_below=0.1)
-        torch.cuda.synchronize()
-        t0 = time.time()
-        for _ in range(gsteps):
-            eng.run_band_pairs([wg.band, wg.band2], wg.n, wg.dpx, wg.start, wg.CH, select_below=0.1)
-        torch.cuda.synchronize()
-        gp_s = wg.total_mpix * 1e6 / ((time.time() - t0) / gsteps)
-        from mustache_amd.diff_mustache import run_pair_layout
-        run_pair_layout(wg.pipe, wg.layout, [wg.band, wg.band2], 0.88, 0.1, 0.1)
-        pruns = []
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t0 = time.time()
-            rows = run_pair_layout(wg.pipe, wg.layout, [wg.band, wg.band2], 0.88, 0.1, 0.1)
-            torch.cuda.synchronize()
-            pruns.append(time.time() - t0)
-        gp_e2e = sorted(pruns)[1]
-        gp_flops = 2 * FLOPS_PER_PIXEL * g_frac + 146.0
-        out["diff_genome_5kb"] = {"value": round(gp_s / 1e6, 1), "unit": "Mpix-pairs/s", "block_pairs": len(wg.start),
-                                  "chunk": wg.CH, "chromosomes": len(HG19),
-                                  "end_to_end": {"rows_2_to_9_both_samples_s": round(gp_e2e, 3),
-                                                 "tagged_rows": sum(len(o) for o in rows),
-                                                 "note": "run_pair_layout: the device part above + the batched host tail "
-                                                         "(filters, device clustering, differential test, overlap masks)"},
-                                  "roofline": {"bound": "fp64_valu", "flops_per_pixel_pair_launched": round(gp_flops, 1),
-                                               "launched_tile_fraction": round(g_frac, 4),
-                                               "achieved": round(gp_s * gp_flops / 1e12, 3), "peak": peak_tf,
-                                               "unit": "TFLOP/s", "frac": round(gp_s * gp_flops / 1e12 / peak_tf, 4)},
-                                  "note": "two-sample caller over the whole genome in one call (both sigma loops with tile "
-                                          "lists, mst_diff_dog_band over all tiles, pair p-values, BH + selection + partner "
-                                          "look-ups on the device, selected records to the host), wall clock"}
-        del wg, eng
-        torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and not args.core:
-        # instantiations outside the headline configuration, so that their cost is on the line: the wide-radius tile that
-        # serves -sz / -oc (blur radius 15..28) and the normalisation kernel for windows beyond 8400 bins (< 238 bp)
-        from mustache_amd.pipeline import ChromosomePipeline, block_tiling
-        from mustache_amd.normalize import normalize_band
-        from mustache_amd.synth import band_counts
-        var = {}
-        nv = 4000 + 5 * 2000
-        bandv, _ = make_band(nv, 2000, 400.0, 500, 3, 1000, device, reps=1)
-        CHv, startv, _ = block_tiling(nv, 2000)
-        for label, octs in (("octaves_3.2_6.4", (3.2, 6.4)), ("octaves_1.6_3.2_6.4", (1.6, 3.2, 6.4))):
-            eng = ChromosomePipeline(octs, device=device).engine
-            r = {}
-            for mode, skip in (("dense", False), ("band_skip", True)):
-                tms = []
-                for it in range(3):
-                    tm = []
-                    eng.sigma_loop_band(bandv, nv, 2000, startv, CHv, skip_empty=skip, download=False, timing=tm)
-                    torch.cuda.synchronize()
-                    tms.append(tm[0][0].elapsed_time(tm[0][1]))
-                r[mode] = round(len(startv) * CHv * CHv / 1e6 / (sorted(tms)[1] * 1e-3), 1)
-            var[label] = dict(r, unit="Mpix/s", kernel="scale_space_kernel<Tile<32,64,28,4>, band> (512 threads, one workgroup per CU)", blocks=len(startv),
-                              chunk=CHv, max_radius=int(max(eng.levels.radius)))
-            del eng
-        del bandv
-        nw, resw = 60000, 222                                   # window int(2e6 / 222) = 9009 bins
-        raww = band_counts(nw, 2000, 30.0, 100, 5, device=device)
-        tms = []
-        for it in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            normalize_band(raww, nw, 2000, resw)
-            e1.record()
-            torch.cuda.synchronize()
-            tms.append(e0.elapsed_time(e1))
-        var["normalize_window_9009"] = {"ms": round(sorted(tms)[1], 3), "samples": nw * 2002,
-                                        "GB/s_on_16B_per_sample": round(16.0 * nw * 2002 / (sorted(tms)[1] * 1e-3) / 1e9, 1),
-                                        "kernel": "normalize_walk_kernel<1024,16> (128-VGPR cap, spills: correctness-only "
-                                                  "path for resolutions below ~238 bp)"}
-        del raww
-        out["variants"] = var
+        out["chr21_5kb"], out["diff_chr21_5kb"] = small_shape_legs(device)
+    extra = None
+    if args.extra and solo:
+        extra = __import__("scripts.bench_extra", fromlist=["Extra"]).Extra(sys.modules[__name__], cx, out, value, no_share)
+        extra.before_file_leg()
     if not args.no_file:
         # every rank takes part (N > 1: each inflates its share of the file, the shares are exchanged); rank 0 reports
-        fl = file_leg(w, device, rank=rank, world=world, grouped=grouped, backend=backend)
-        out["end_to_end_from_file"] = fl
-        if "sparse_1kb" in fl:
-            out["sparse_1kb"] = fl.pop("sparse_1kb")
+        out["end_to_end_from_file"] = fl = file_leg(cx, on_band=extra.sparse_step if extra else None)
         out["ranks"]["read_s"] = fl["read_s_per_rank"]
-    if rank == 0 and world == 1 and not args.no_cpu:
-        bi = len(w.start) // 2
-        import numpy as np
-        cpu_s, cpu_found, cpu_nz, (cpix, clvl, cval, cp) = cpu_baseline(w, bi)
-        # the same block through the HIP path, launched with its two neighbours so that it RECEIVES the tiles it shares with
-        # the block before it and GIVES those it shares with the block after it; records ordered by pixel: the checker
-        # compares the whole found set
-        g = w.pipe.engine.sigma_loop_band(w.band, w.n, w.dpx, [w.start[bi - 1], w.start[bi], w.start[bi + 1]], w.CH,
-                                          skip_empty=False, with_q=False)[0][1]
-        found_gpu = len(g["pixel"])
-        same = (found_gpu == cpu_found and np.array_equal(g["pixel"], cpix) and np.array_equal(g["level"], clvl)
-                and np.array_equal(g["value"], cval))
-        p_err = float(np.max(np.abs(g["pval"] - cp) / np.maximum(cp, 1e-300))) if same and found_gpu else None
-        out["cpu_baseline"] = {"value": round(w.CH * w.CH / 1e6 / cpu_s, 4), "unit": "Mpix/s", "cores": 1,
-                               "kind": "port",
-                               "sample": "block %d of the same workload (one 4000x4000 block, %.1f s), rows 3-7 of the "
-                                         "oracle = the reference's SciPy calls, single process; the GPU records compared with it "
-                                         "come from a 3-block launch in which this block shares tiles with both neighbours.  "
-                                         "NOT in this baseline: the reference's normalize_sparse (row 1, ~35 min for this "
-                                         "shape, SURVEY section 6) and its tail -- BH, the 16 M-key argsort, the per-candidate "
-                                         "filter loop, clustering (rows 8-9); the GPU side of the ratio (`value`) is rows 2-7, so "
-                                         "the quoted speed-ups are for rows 3-7 only and conservative for the whole run"
-                                         % (bi, cpu_s),
-                               "found_pixels_cpu": cpu_found, "found_pixels_gpu": found_gpu,
-                               "found_set_pixels_levels_values_identical": bool(same), "pvalue_max_rel_err": p_err,
-                               "cpu_model": _cpu_model(), "host_cores": os.cpu_count()}
-        out["speedup_vs_cpu_1core"] = round(value / out["cpu_baseline"]["value"], 1)
-        # BASELINE.md section 3: (b) the reference's default -p 4 over a stated subset of >= 8 blocks, scaled linearly
-        sub = [(bi + j) % len(w.start) for j in range(-4, 5) if j]
-        wall4, _ = cpu_baseline_pool(w, sub, 4)
-        out["cpu_baseline_p4"] = {"value": round(len(sub) * w.CH * w.CH / 1e6 / wall4, 4), "unit": "Mpix/s", "cores": 4,
-                                  "kind": "port", "sample": "%d of the workload's %d blocks (a stated subset, scaled linearly) "
-                                  "in 4 worker processes, two rounds (the reference's default -p 4), wall %.1f s incl. "
-                                  "process start-up" % (len(sub), len(w.start), wall4)}
-        out["speedup_vs_cpu_p4"] = round(value / out["cpu_baseline_p4"]["value"], 1)
-        # (c) one process per core, capped (--cpu-procs, default 16; 0 switches the leg off)
-        P = min(args.cpu_procs, len(w.start), os.cpu_count() or 1)
-        if P > 0:
-            wallp, _ = cpu_baseline_pool(w, [(bi + j) % len(w.start) for j in range(P)], P)
-            out["cpu_baseline_node"] = {"value": round(P * w.CH * w.CH / 1e6 / wallp, 3), "unit": "Mpix/s", "cores": P,
-                                        "kind": "port", "host_cores": os.cpu_count(),
-                                        "sample": "%d blocks of the same workload in %d worker processes at once (capped; "
-                                        "--cpu-procs raises it), wall %.1f s incl. process start-up" % (P, P, wallp)}
-            out["speedup_vs_cpu_node"] = round(value / out["cpu_baseline_node"]["value"], 1)
+    if solo and not args.no_cpu:
+        out["cpu_baseline"], out["speedup_vs_cpu_1core"] = cpu_baseline(w, value)
+        if extra:
+            extra.cpu_pools()
     if rank == 0:
         print(json.dumps(out))
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def _cpu_model():
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except Exception:
-        pass
-    return "unknown"
 
 
 if __name__ == "__main__":

@@ -337,6 +337,27 @@ class ScaleSpaceEngine:
         self._pin = {}
         self._pin_flip = 0
 
+    # ---- host queries of the launch geometry (no GPU work) --------------------------------------------------------
+    def band_tile_fraction(self, CH, dpx):
+        """Share of a block's tiles launched with empty tiles skipped: those whose owned pixels can reach the tested band
+        4 <= col - row <= dpx + 1 (mst_scale_space_band_tiles)."""
+        total = ctypes.c_int32(0)
+        m = self.lib.mst_scale_space_band_tiles(int(CH), int(dpx), ctypes.byref(self._lv_struct), ctypes.byref(total))
+        if m < 0:
+            _lib.check(m)
+        return m / float(total.value)
+
+    def band_items(self, starts, CH, dpx, skip_empty=False, share=True):
+        """(workgroups one launch over the blocks at `starts` runs, tiles the blocks would run one by one, tiles computed once
+        for two blocks) -- mst_scale_space_band_items, the work list the band-direct kernel is launched with."""
+        st = (ctypes.c_int64 * len(starts))(*[int(a) for a in starts])
+        tiles, shared = ctypes.c_int64(), ctypes.c_int64()
+        m = self.lib.mst_scale_space_band_items(st, len(starts), int(CH), int(dpx), ctypes.byref(self._lv_struct),
+                                                (1 if skip_empty else 0) | (0 if share else 4), ctypes.byref(tiles), ctypes.byref(shared))
+        if m < 0:
+            _lib.check(m)
+        return int(m), int(tiles.value), int(shared.value)
+
     # ---- row 2: COO -> dense blocks ---------------------------------------------------------------------------
     def scatter_blocks(self, x, y, v, starts, CH):
         """x, y int64 / v float64 device tensors (upper-triangular COO, bin units) -> [B, CH, CH] float64."""

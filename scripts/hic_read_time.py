@@ -10,14 +10,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ctypes          # noqa: E402
 import torch           # noqa: E402
-import bench           # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import hic_writer      # noqa: E402
 from mustache_amd.hicfile import HicFile, _check     # noqa: E402
 from mustache_amd.normalize import pinned_packed_alloc   # noqa: E402
 
 path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/chr1_1kb.hic"
 if not os.path.exists(path):
     t0 = time.time()
-    n = bench.write_synthetic_hic(path, 248957, 2000, 1000, 400.0, 8000, 1, 200.0, torch.device("cuda:0"))
+    n = hic_writer.write_synthetic_hic(path, 248957, 2000, 1000, 400.0, 8000, 1, 200.0, torch.device("cuda:0"))
     print("wrote %d records, %d bytes in %.1f s" % (n, os.path.getsize(path), time.time() - t0), flush=True)
 print("cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)), flush=True)
 try:

@@ -7,10 +7,12 @@ sys.path.insert(0, ROOT)
 
 def main():
     import torch
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
     import bench
+    import bench_extra
     from mustache_amd.diff_mustache import run_pair_layout
     dev = torch.device("cuda:0")
-    wg = bench.GenomeWorkload("hg19-shaped genome @5kb synthetic", 5000, 400, 300.0, 1000, dev, two_samples=True)
+    wg = bench_extra.genome_workload(bench, "hg19-shaped genome @5kb synthetic", 5000, 400, 300.0, 1000, dev, two_samples=True)
     for _ in range(2):
         run_pair_layout(wg.pipe, wg.layout, [wg.band, wg.band2], 0.88, 0.1, 0.1)
     torch.cuda.synchronize()

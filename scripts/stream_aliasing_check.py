@@ -8,7 +8,9 @@ kernels then waited behind the next launch's fused kernel.  engine.device_stream
 removed the dependence; this script is the check."""
 import sys, time, torch
 sys.path.insert(0, '.')
+sys.path.insert(0, 'scripts')
 import bench
+import bench_extra
 dev = torch.device('cuda:0')
 def instrument(eng):
     acc = {}
@@ -33,10 +35,10 @@ def run(wg, tag):
           {k: round(v / 5 * 1e3, 2) for k, v in acc.items()}, flush=True)
 which = sys.argv[1]
 if which == "fresh":
-    wg = bench.GenomeWorkload("g", 5000, 400, 300.0, 1000, dev, two_samples=False)
+    wg = bench_extra.genome_workload(bench, "g", 5000, 400, 300.0, 1000, dev, two_samples=False)
     run(wg, "fresh")
 else:
     w = bench.Workload("c", 248957, 2000, 1000, 400.0, 8000, 1, dev, 0, 1)
     for _ in range(2): w.step(False)
-    wg = bench.GenomeWorkload("g", 5000, 400, 300.0, 1000, dev, two_samples=False)
+    wg = bench_extra.genome_workload(bench, "g", 5000, 400, 300.0, 1000, dev, two_samples=False)
     run(wg, "after chr1")

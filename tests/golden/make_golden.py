@@ -283,10 +283,12 @@ def make_tiling(ref):
     print("tiling done", [(r[0], r[1], len(r[2])) for r in rec])
 
 
-def make_regulator(ref):
-    """End to end through the reference's text reader, normalisation, tiling and block loop (3 blocks)."""
-    n, dpx, res = 4200, 200, 10000
-    x, y, v = synth_coo(n, dpx, depth=300.0, seed=31)
+def make_regulator(ref, name="regulator_3blocks", n=4200, dpx=200, res=10000, seed=31, nloops=None):
+    """End to end through the reference's text reader, normalisation, tiling and block loop (3 blocks).
+    `regulator_1kb_4blocks` (n=9000, res=1000, dpx=2000): the HEADLINE geometry -- 4000^2 blocks at stride 2000 (half
+    overlap), a right-aligned last block [5000, 9000) whose mask_size (3000) exceeds dpx (mustache.py:909-910, :948-953),
+    and normalize_sparse at its real 2000-bin window (:628-669).  ~10 min in the reference."""
+    x, y, v = synth_coo(n, dpx, depth=300.0, seed=seed, nloops=nloops)
     # raw integer-ish counts and a bias file, as a 3-column RAWobserved-style text + KRnorm-style vector
     rng = np.random.default_rng(9)
     bias = rng.uniform(0.5, 1.5, n)
@@ -312,7 +314,8 @@ def make_regulator(ref):
     rx, ry, rv = np.asarray(rx), np.asarray(ry), np.asarray(rv)
     la = loops_array(loops)
     la = la[np.lexsort((la[:, 1], la[:, 0]))]
-    np.savez_compressed(os.path.join(HERE, "regulator_3blocks.npz"), n=n, dpx=dpx, res=res, seed=31, depth=300.0,
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), n=n, dpx=dpx, res=res, seed=seed, depth=300.0,
+                        nloops=-1 if nloops is None else nloops,
                         bias=bias, in_checksum=float(v.sum()), in_nnz=len(v),
                         read_nnz=len(rv), read_vsum=float(rv.sum()), read_xsum=int(rx.sum()), read_ysum=int(ry.sum()),
                         loops=la)
@@ -573,5 +576,7 @@ if __name__ == "__main__":
         make_tiling(ref)
     if "regulator" in which:
         make_regulator(ref)
+    if "regulator1kb" in which:     # headline geometry (not in the default list: ~10 min, ~2 GB)
+        make_regulator(ref, "regulator_1kb_4blocks", n=9000, dpx=2000, res=1000, seed=32, nloops=400)
     if "krnorm" in which:
         make_krnorm(ref)

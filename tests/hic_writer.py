@@ -238,3 +238,35 @@ def write_hic_bulk(path, chrom, length, res, blocks, block_bin_count, norm_ones=
         fh.seek(8)
         fh.write(struct.pack("<q", master_at))
     return total
+
+
+def write_synthetic_hic(path, n, dpx, res, depth, nloops, seed, keep, device, block_bins=1000):
+    """A config-4-shaped `.hic` file (one chromosome at `res`, version 8, float counts, KR vector of ones) holding the
+    synthetic chromosome with pixel (i, i + d) kept with probability min(1, keep / (d + 1)) -- generated slab by slab on the
+    GPU, written with write_hic_bulk (bench.py's file leg; test infrastructure, untimed).  Returns the record count."""
+    import os
+    import torch
+    from mustache_amd.synth import band_counts, _uniform
+
+    def blocks():
+        d = torch.arange(dpx + 2, dtype=torch.int64, device=device)[:, None]
+        for bx in range(-(-n // block_bins)):
+            i0, i1 = bx * block_bins, min(n, (bx + 1) * block_bins)
+            i = torch.arange(i0, i1, dtype=torch.int64, device=device)[None, :]
+            val = band_counts(n, dpx, depth, nloops, seed, i0=i0, i1=i1, device=device)
+            # thinning grows with the distance (dense near the diagonal, sparse far out, like a real map at 1 kb)
+            val = torch.where(_uniform(seed + 5, d, i, 9) * (d + 1).to(torch.float64) < keep, val, torch.zeros_like(val))
+            dd, cc = torch.nonzero(val > 0, as_tuple=True)
+            x = cc + i0
+            y = x + dd
+            v = val[dd, cc].to(torch.float32)
+            by = y // block_bins
+            order = torch.argsort((by << 42) | (y << 21) | x)
+            x, y, v, by = x[order].to(torch.int32).cpu().numpy(), y[order].to(torch.int32).cpu().numpy(), \
+                v[order].cpu().numpy(), by[order].cpu().numpy()
+            cuts = np.flatnonzero(np.r_[True, by[1:] != by[:-1]]) if len(by) else np.zeros(0, np.int64)
+            cuts = np.append(cuts, len(by))
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                yield bx, int(by[a]), x[a:b], y[a:b], v[a:b]
+
+    return write_hic_bulk(path, "chr1", n * res, res, blocks(), block_bins, threads=min(32, os.cpu_count() or 4))

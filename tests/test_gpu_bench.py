@@ -28,7 +28,7 @@ def _fragments(err):
 def _check_line(j, n_gpus, steps, warmup):
     assert j["metric"].startswith("scale-space Mpix/s") and j["unit"] == "Mpix/s" and j["higher_is_better"] is True
     assert j["n_gpus"] == n_gpus and j["steps"] == steps and j["warmup"] == warmup
-    assert j["dtype"] == "f64" and j["data"] == "synthetic" and j["scaling"] in ("weak", "strong") and j["vs_baseline"] is None
+    assert j["dtype"] == "f64" and j["data"] == "synthetic" and j["scaling"] == "strong" and j["vs_baseline"] is None
     assert abs(j["value"] - j["config"]["megapixels_per_step"] / (j["ms_per_step"] * 1e-3)) < 1e-3 * j["value"]
     r = j["roofline"]
     assert r["bound"] == "fp64_valu" and r["unit"] == "TFLOP/s" and r["peak"] == 39.3
@@ -47,13 +47,28 @@ def _check_line(j, n_gpus, steps, warmup):
     assert 0.0 < rk["efficiency_bound"] <= 1.0 and set(rk["efficiency_bound_at"]) == {"1", "2", "4", "8"}
 
 
+KEPT = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "ranks", "roofline", "tile_sharing", "band_skip", "no_share", "normalize_ms_untimed",
+        "end_to_end", "chr21_5kb", "diff_chr21_5kb"}
+
+
 def test_bench_one_rank_small():
+    """the driver's line (no flags but the size): exactly the kept legs; then the same with --extra: the side legs beside them"""
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--small", "--no-cpu",
                         "--no-file"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _last_json(r.stdout)
     _check_line(j, 1, 2, 1)
+    assert set(j) == KEPT, sorted(set(j) ^ KEPT)
+    assert j["scaling"] == "strong" and j["config"]["partition"] == "blocks" and "rank 0 = [0, 12)" in j["config"]["sharding"]
     assert j["band_skip"]["value"] > j["value"] and j["chr21_5kb"]["value"] > 0 and j["end_to_end"]["loops"] > 0
+    assert j["diff_chr21_5kb"]["value"] > 0 and j["diff_chr21_5kb"]["ms_per_call"]["calls"] == 30
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--small", "--no-cpu",
+                        "--no-file", "--extra"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    _check_line(j, 1, 2, 1)
+    assert set(j) - KEPT == {"fma_mode", "normalize_roofline", "row2_scatter", "genome_5kb", "diff_genome_5kb", "variants"}
     assert abs(j["band_skip"]["roofline"]["frac"] - j["band_skip"]["roofline"]["achieved"] / 39.3) < 1e-3
     assert j["band_skip"]["roofline"]["block_pixel_view"]["frac"] >= j["band_skip"]["roofline"]["frac"]
     assert j["row2_scatter"]["band_rebuilt_identical"] is True and 0 < j["row2_scatter"]["value_from_coo"] < j["value"]
@@ -71,11 +86,14 @@ def test_bench_two_ranks_gloo_one_device():
     assert r.returncode == 0, r.stderr[-3000:]
     j = _last_json(r.stdout)
     _check_line(j, 2, 2, 1)
-    # default: weak scaling (a whole chromosome per rank: 2 x 12 blocks per step); the block-sharded split is measured beside it
-    assert j["scaling"] == "weak" and j["ranks"]["blocks_per_rank_max"] == 12 and "2 rank" in j["config"]["sharding"]
-    assert abs(j["config"]["megapixels_per_step"] - 2 * 12 * 16.0) < 1e-6
+    # default = the metric: STRONG scaling, ONE chromosome's 12 blocks in two contiguous ranges, the same megapixels per step
+    # as at N = 1 (mustache.py:913-937: one process per block of one chromosome); the genome partition is timed beside it
+    assert j["scaling"] == "strong" and j["config"]["partition"] == "blocks"
+    assert j["ranks"]["blocks_per_rank_max"] == 6 and j["ranks"]["blocks_per_rank_min"] == 6
+    assert "rank 0 = [0, 6), rank 1 = [6, 12)" in j["config"]["sharding"]
+    assert abs(j["config"]["megapixels_per_step"] - 12 * 16.0) < 1e-6
     o = j["other_scaling"]
-    assert o["scaling"] == "strong" and o["blocks_on_this_rank"] == 6 and abs(o["megapixels_per_step"] - 12 * 16.0) < 1e-6
+    assert o["scaling"] == "weak" and o["blocks_on_this_rank"] == 12 and abs(o["megapixels_per_step"] - 2 * 12 * 16.0) < 1e-6
     assert o["value"] > 0
     frags = _fragments(r.stderr)
     assert sorted(f["rank"] for f in frags) == [0, 1] and all(f["backend"] == "gloo" for f in frags)
@@ -98,7 +116,7 @@ def test_bench_two_ranks_self_launched_with_file_leg():
     assert all(c > 0 for c in f["records_per_rank"]) and sum(f["records_per_rank"]) == f["records"]
     assert abs(f["records_per_rank"][0] - f["records_per_rank"][1]) < 0.2 * f["records"]      # shares of the blocks, balanced
     one = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "1", "--warmup", "0", "--small", "--no-cpu",
-                          "--core", "--with-file"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+                          ], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert one.returncode == 0, one.stderr[-3000:]
     f1 = _last_json(one.stdout)["end_to_end_from_file"]
     assert f1["ranks"] == 1 and f1["records"] == f["records"] and f1["loops"] == f["loops"] > 0 and f1["n"] == f["n"]

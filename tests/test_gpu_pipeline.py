@@ -96,6 +96,53 @@ def test_regulator_three_blocks_vs_reference(golden_dir, tmp_path):
     np.testing.assert_allclose(got[:, 2], exp[:, 2], rtol=1e-6)
 
 
+def test_regulator_1kb_headline_geometry_vs_reference(golden_dir, tmp_path):
+    """The reference's own regulator() (mustache.py:853-960) at the HEADLINE geometry -- res 1 kb, distance limit 2000 bins,
+    4000 x 4000 blocks at stride 2000 (half overlap), a right-aligned last block [5000, 9000) whose mask_size 3000 exceeds the
+    limit (:909-910, :948-953), normalize_sparse at its real 2000-bin window (:628-669) -- against this library from the SAME
+    text + bias files: the CLI (product mode: tile list + tiles shared between overlapping blocks), and the pipeline in every
+    combination of dense / tile list and shared / per-block tiles.  1084 loops: coordinates and scales bit-identical."""
+    import pandas as pd
+    from mustache_amd.mustache import main, read_pd
+    from mustache_amd.pipeline import ChromosomePipeline
+    from mustache_amd.synth import synth_coo
+    g = _load(golden_dir, "regulator_1kb_4blocks.npz")
+    n, dpx, res = int(g["n"]), int(g["dpx"]), int(g["res"])
+    x, y, v = synth_coo(n, dpx, depth=float(g["depth"]), seed=int(g["seed"]), nloops=int(g["nloops"]))
+    assert len(v) == int(g["in_nnz"]) and v.sum() == float(g["in_checksum"]), "synthetic generator drifted"
+    fpath, bpath = str(tmp_path / "chrS.RAWobserved"), str(tmp_path / "chrS.KRnorm")
+    # 9.8 M rows: pandas writes the shortest round-trip repr of each float64, as the generator's '%r' did
+    pd.DataFrame({"a": x * res, "b": y * res, "c": v}).to_csv(fpath, sep="\t", header=False, index=False)
+    with open(bpath, "w") as f:
+        for b in g["bias"]:
+            f.write("%r\n" % float(b) if not np.isnan(b) else "NaN\n")
+    exp = g["loops"]
+
+    def check(loops, what):
+        got = np.array(sorted([[float(a), float(b), q, s] for a, b, q, s in loops]))
+        assert got.shape == exp.shape, (what, got.shape, exp.shape)
+        assert np.array_equal(got[:, :2], exp[:, :2]), what + ": loop coordinates must match the reference exactly"
+        assert np.array_equal(got[:, 3], exp[:, 3]), what
+        np.testing.assert_allclose(got[:, 2], exp[:, 2], rtol=1e-6, err_msg=what)
+
+    out = str(tmp_path / "out.tsv")
+    main(["-f", fpath, "-b", bpath, "-ch", "S", "-r", "1kb", "-pt", "0.1", "-st", "0.8", "-o", out, "-d", str(dpx * res)])
+    rows = [l.split("\t") for l in open(out).read().strip().split("\n")[1:]]
+    check([(int(r[1]) // res, int(r[4]) // res, float(r[6]), float(r[7])) for r in rows], "CLI")
+    rx, ry, rv = read_pd(fpath, dpx * res, bpath, "S", res)
+    assert len(rv) == int(g["read_nnz"]) and int(np.sum(rx)) == int(g["read_xsum"]) and int(np.sum(ry)) == int(g["read_ysum"])
+    rx, ry, rv = np.asarray(rx), np.asarray(ry), np.asarray(rv)
+    pipe = ChromosomePipeline(OCT)
+    try:
+        for share in (True, False):
+            pipe.engine.share_tiles = share
+            for skip in (True, False):
+                check(pipe.run(rx, ry, rv.copy(), res, dpx, 0.8, 0.1, skip_empty=skip),
+                      "pipeline share=%s tile_list=%s" % (share, skip))
+    finally:
+        pipe.engine.share_tiles = True
+
+
 def test_cli_writes_reference_tsv(golden_dir, tmp_path):
     from mustache_amd.mustache import main
     g = _load(golden_dir, "regulator_3blocks.npz")

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MST_ABI_VERSION 2
+#define MST_ABI_VERSION 3
 
 #define MST_OK 0
 #define MST_E_ARG (-1)      /* bad argument (null pointer, size, unsupported radius ...) */
@@ -218,6 +218,22 @@ int mst_band_from_packed(const int32_t *x, const int32_t *dist, const float *v, 
  * per record across PCIe; needs dpx + 1 <= 65535).  Slabs may be scattered in any order: a matrix holds every pixel once. */
 int mst_band_scatter_packed(const int32_t *x, const void *dist, int32_t dist_bytes, const float *v, int64_t nnz, int64_t n,
                             int32_t dpx, double *band, void *stream);
+
+/* The device half of the RAW `.hic` read (include/mustache_io.h, mst_hic_rawstream_*): the rows of inflated blocks, record
+ * bytes exactly as the file stores them, decoded, normalised, filtered and scattered by one kernel -- what hic-straw's
+ * readBlock() and the record loop of read_hic_file() do on the host (mustache.py:328-333, :340-389), followed by
+ * `cc[xc, yc] = vc` (:919-924).  payload: dev bytes of one slab (2-byte aligned); rows: dev [n_rows] mst_hic_row
+ * (include/mustache_hicrow.h; offsets relative to `payload`); norm: dev [n_norm] float64 normalisation vector or NULL (no
+ * division); per record: binX <= binY ordered, dropped when binY - binX > max_dist (< 0: no limit), when either bin lies
+ * outside the vector, when value = (float)(count / (norm[binX] * norm[binY])) is NaN or <= 0, or when binY >= y_limit
+ * (<= 0: no limit); kept: band[(binY - binX) * n + binX] = (double)value.  NO clearing -- the caller zero-fills `band`
+ * ([dpx + 2][n]) once and may scatter slabs in any order.  stats: dev uint64 [4], accumulated with atomics (the caller zeroes
+ * them): [0] max binY + 1 over the kept records, [1] kept records, [2] records the band cannot hold (binY >= n or distance >
+ * dpx + 1: never written), [3] verify mismatches.  verify != 0: nothing is written; every record that would be kept is read
+ * back and counted in stats[3] when its pixel holds another value (two records sharing a pixel: malformed input). */
+int mst_band_scatter_hic_rows(const void *payload, const void *rows, int32_t n_rows, const double *norm, int64_t n_norm,
+                              int64_t max_dist, int64_t y_limit, int64_t n, int32_t dpx, double *band, uint64_t *stats,
+                              int32_t verify, void *stream);
 
 /* Read-back check of packed scatters: *mismatches (dev uint64, zeroed by the caller) += the number of records whose pixel
  * does not hold their value afterwards -- a pixel written by two records with different values (malformed input; the

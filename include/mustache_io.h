@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MST_IO_ABI_VERSION 2
+#define MST_IO_ABI_VERSION 3
 #define MST_IO_OK 0
 #define MST_IO_E_ARG (-1)     /* bad argument */
 #define MST_IO_E_FILE (-2)    /* cannot open / map the file */
@@ -132,6 +132,35 @@ int mst_hic_stream_open(mst_hic *h, const char *chrom, int32_t resolution, const
 int mst_hic_stream_next(mst_hic_stream *s, int32_t timeout_ms, int32_t *slab, int64_t *count);
 int mst_hic_stream_release(mst_hic_stream *s, int32_t slab);
 int mst_hic_stream_close(mst_hic_stream *s, int64_t *n_bins, int64_t *total, int32_t *blocks_total, int32_t *blocks_mine);
+
+/* ---- streaming RAW read: the host only inflates, a kernel decodes the rows ------------------------------------------------
+ * For versions 7-9.  Worker threads inflate the chromosome's near-diagonal blocks (share `part` of `n_parts`, the split of
+ * mst_hic_decode_intra_packed_part) and copy the record bytes of every row AS THE FILE STORES THEM (6 bytes per record in the
+ * usual float-count file; a decoded packed record is 10) into caller-owned (page-locked) slabs of `slab_bytes` bytes each:
+ * payload from byte 0 upwards, one `mst_hic_row` entry per row (include/mustache_hicrow.h) from the slab's end downwards -- entry k at
+ * slab + slab_bytes - 16 (k + 1), so the directory of a delivered slab is the `rows` entries ending at the slab's end.  No
+ * host thread looks at a record: columns, counts, the division by the normalisation vector, the distance / NaN / sign /
+ * chromosome-size filters and the scatter into the band are mst_band_scatter_hic_rows (include/mustache_hip.h).  A slab is
+ * handed over when the next row would not fit (a block may continue in the next slab at any row) and at the end of the work
+ * list.  slab_bytes: a multiple of 16 in [4096, 2^32]; slab_memory 16-byte aligned; a single row must fit a slab.
+ *   mst_hic_rawstream_info     the chromosome's normalisation vector (host doubles, valid until close; *norm_values = NULL and
+ *                              *norm_count = -1 for norm "NONE": the caller uploads it once for the kernel) and its length in
+ *                              base pairs from the file's header (every bin lies below ceil(length / resolution))
+ *   mst_hic_rawstream_next     1 = *slab delivered with *payload_bytes of records and *rows directory entries, 2 = nothing
+ *                              ready within timeout_ms, 0 = everything delivered, < 0 = error
+ *   mst_hic_rawstream_release  gives a slab back to the workers (after the consumer's copies out of it have completed)
+ *   mst_hic_rawstream_close    joins the workers, frees the stream; totals of rows / payload bytes delivered, block counts
+ * Version 6 files (plain records, no rows) are refused at open with MST_IO_E_FORMAT: use mst_hic_stream_open. */
+#include "mustache_hicrow.h"
+typedef struct mst_hic_rawstream mst_hic_rawstream;
+int mst_hic_rawstream_open(mst_hic *h, const char *chrom, int32_t resolution, const char *norm, int64_t max_dist_bins,
+                           int32_t n_threads, int32_t part, int32_t n_parts, void *slab_memory, int32_t n_slabs,
+                           int64_t slab_bytes, mst_hic_rawstream **out);
+int mst_hic_rawstream_info(mst_hic_rawstream *s, const double **norm_values, int64_t *norm_count, int64_t *chrom_length_bp);
+int mst_hic_rawstream_next(mst_hic_rawstream *s, int32_t timeout_ms, int32_t *slab, int64_t *payload_bytes, int32_t *rows);
+int mst_hic_rawstream_release(mst_hic_rawstream *s, int32_t slab);
+int mst_hic_rawstream_close(mst_hic_rawstream *s, int64_t *rows_total, int64_t *bytes_total, int32_t *blocks_total,
+                            int32_t *blocks_mine);
 
 /* ---- text contact maps ------------------------------------------------------------------------------------------------
  * The parse step of read_pd() (reference mustache/mustache.py:254-258): `pd.read_csv(f, sep=sep, header=None)` followed

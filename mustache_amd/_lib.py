@@ -6,7 +6,7 @@ import os
 MST_MAX_LEVELS = 64
 MST_MAX_RADIUS = 32
 MST_MAX_TESTED = 48
-MST_ABI_VERSION = 2
+MST_ABI_VERSION = 3
 
 MST_OK, MST_E_ARG, MST_E_HIP, MST_E_OVERFLOW, MST_E_NONFINITE = 0, -1, -2, -3, -4
 
@@ -67,6 +67,7 @@ _SIGNATURES = {
     "mst_band_from_packed": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
     "mst_band_scatter_packed": (ctypes.c_int, [_p, _p, _i32, _p, _i64, _i64, _i32, _p, _p]),
     "mst_band_verify_packed": (ctypes.c_int, [_p, _p, _i32, _p, _i64, _i64, _i32, _p, _p, _p]),
+    "mst_band_scatter_hic_rows": (ctypes.c_int, [_p, _p, _i32, _p, _i64, _i64, _i64, _i64, _i32, _p, _p, _i32, _p]),
     "mst_band_to_coo": (ctypes.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p]),
     "mst_normalize_band": (ctypes.c_int, [_p, _p, _i64, _i32, _i32, _i32, _p, _p]),
     "mst_blocks_from_band": (ctypes.c_int, [_p, _i64, _i32, ctypes.POINTER(_i64), _i32, _i32, _p, _p, _p, _p]),

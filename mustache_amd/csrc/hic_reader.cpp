@@ -894,6 +894,25 @@ static int intra_todo(mst_hic *h, const char *chrom, int32_t resolution, const c
     return MST_IO_OK;
 }
 
+// Part `part` of `n_parts` of a chromosome's block list (one process per GPU, each rank inflates its share): a contiguous run
+// of the near-diagonal blocks in file index order, cut so that the parts hold equal shares of the COMPRESSED bytes (block i
+// belongs to the part its byte midpoint falls into) -- every block belongs to exactly one part, whatever n_parts is.  The ONE
+// definition every reader uses: ranks that disagreed on it would drop or double-decode blocks without any error.
+static void split_todo(std::vector<const BlockRef *> &todo, int32_t part, int32_t n_parts) {
+    if (n_parts <= 1) return;
+    double total = 0.0, run = 0.0;
+    for (const BlockRef *b : todo) total += (double)b->size;
+    std::vector<const BlockRef *> own;
+    for (const BlockRef *b : todo) {
+        const double mid = run + 0.5 * (double)b->size;
+        run += (double)b->size;
+        int p = total > 0.0 ? (int)(mid / total * (double)n_parts) : 0;
+        p = p < 0 ? 0 : (p >= n_parts ? n_parts - 1 : p);
+        if (p == part) own.push_back(b);
+    }
+    todo.swap(own);
+}
+
 extern "C" int64_t mst_hic_decode_intra_packed(mst_hic *h, const char *chrom, int32_t resolution, const char *norm,
                                                int64_t max_dist_bins, int64_t chrom_size_bp, int32_t n_threads,
                                                int64_t *n_bins) {
@@ -917,24 +936,7 @@ extern "C" int64_t mst_hic_decode_intra_packed_part(mst_hic *h, const char *chro
         const int rc = intra_todo(h, chrom, resolution, norm, max_dist_bins, todo, z, norm_vec, &use_norm);
         if (rc != MST_IO_OK) return rc;
         if (blocks_total) *blocks_total = (int32_t)todo.size();
-        if (n_parts > 1) {
-            // part p of n: a contiguous run of the near-diagonal blocks in file index order, cut so that the parts hold
-            // equal shares of the COMPRESSED bytes (block i belongs to the part its byte midpoint falls into) -- every
-            // block is decoded by exactly one part, whatever n is
-            std::vector<double> mid(todo.size());
-            double run = 0.0;
-            for (size_t i = 0; i < todo.size(); ++i) {
-                mid[i] = run + 0.5 * (double)todo[i]->size;
-                run += (double)todo[i]->size;
-            }
-            std::vector<const BlockRef *> own;
-            for (size_t i = 0; i < todo.size(); ++i) {
-                int p = run > 0.0 ? (int)(mid[i] / run * (double)n_parts) : 0;
-                p = p < 0 ? 0 : (p >= n_parts ? n_parts - 1 : p);
-                if (p == part) own.push_back(todo[i]);
-            }
-            todo.swap(own);
-        }
+        split_todo(todo, part, n_parts);
         if (blocks_mine) *blocks_mine = (int32_t)todo.size();
         int nt = n_threads > 0 ? n_threads : default_threads();
         if (nt < 1) nt = 1;
@@ -1189,21 +1191,7 @@ extern "C" int mst_hic_stream_open(mst_hic *h, const char *chrom, int32_t resolu
         }
         // todo points into `zoom.blocks`, which intra_todo filled inside s->zoom: the pointers stay valid with the stream
         s->blocks_total = (int32_t)todo.size();
-        if (n_parts > 1) {
-            std::vector<double> mid(todo.size());
-            double run = 0.0;
-            for (size_t i = 0; i < todo.size(); ++i) {
-                mid[i] = run + 0.5 * (double)todo[i]->size;
-                run += (double)todo[i]->size;
-            }
-            std::vector<const BlockRef *> own;
-            for (size_t i = 0; i < todo.size(); ++i) {
-                int p = run > 0.0 ? (int)(mid[i] / run * (double)n_parts) : 0;
-                p = p < 0 ? 0 : (p >= n_parts ? n_parts - 1 : p);
-                if (p == part) own.push_back(todo[i]);
-            }
-            todo.swap(own);
-        }
+        split_todo(todo, part, n_parts);
         s->todo.swap(todo);
         s->max_dist = max_dist_bins;
         s->y_limit = chrom_size_bp > 0 ? (chrom_size_bp + resolution - 1) / resolution : INT64_MAX;
@@ -1268,6 +1256,270 @@ extern "C" int mst_hic_stream_close(mst_hic_stream *s, int64_t *n_bins, int64_t 
     else if (s->ymax >= INT32_MAX) rc = fail(MST_IO_E_FORMAT, "bin index %lld does not fit 32 bits", (long long)s->ymax);
     if (n_bins) *n_bins = s->ymax + 1;
     if (total) *total = s->total;
+    if (blocks_total) *blocks_total = s->blocks_total;
+    if (blocks_mine) *blocks_mine = (int32_t)s->todo.size();
+    delete s;
+    return rc;
+}
+
+// ---- streaming RAW read: the host only inflates ----------------------------------------------------------------------------
+// Worker threads inflate the chromosome's near-diagonal blocks (this part's share of them) and copy the RECORD BYTES of every
+// row, exactly as the file stores them (2 or 4 bytes of column + 2 or 4 bytes of count: 6 bytes per record in the usual
+// float-count file, against the 10 of a decoded packed record), into caller-owned slabs, with one 16-byte directory entry per
+// row {byte offset, binY, binXOffset, record count | layout flags}.  The rows are decoded -- columns, counts, normalisation
+// vector, distance / NaN / sign filters, scatter into the band -- by a kernel (mst_band_scatter_hic_rows in
+// libmustache_hip.so), so no host thread touches a record.  Slab layout: payload from byte 0 upwards, directory entries from
+// the slab's end downwards (entry k at slab_bytes - 16 (k + 1)); a slab is handed over when the next row would not fit.
+// A block may be split between slabs at any row.  v6 blocks (plain records, no rows) are not served: MST_IO_E_FORMAT at open.
+struct mst_hic_rawstream {
+    mst_hic *h = nullptr;
+    std::vector<const BlockRef *> todo;
+    ZoomData zoom;
+    std::vector<double> norm_vec;
+    bool use_norm = false;
+    uint8_t *base = nullptr;
+    int32_t n_slabs = 0;
+    int64_t slab_bytes = 0;
+    std::vector<int64_t> pay_bytes;
+    std::vector<int32_t> row_count;
+    std::mutex mu;
+    std::condition_variable cv_free, cv_ready;
+    std::deque<int32_t> free_q, ready_q;
+    std::vector<std::thread> workers;
+    std::atomic<size_t> next{0};
+    int active = 0;
+    bool failed = false, cancelled = false;
+    std::string error;
+    int64_t rows_total = 0, bytes_total = 0, chrom_length = 0;
+    int32_t blocks_total = 0;
+
+    struct Cancelled {};
+
+    void fail_with(const char *what) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failed) error = what;
+        failed = true;
+        cv_free.notify_all();
+        cv_ready.notify_all();
+    }
+
+    struct Worker {
+        mst_hic_rawstream *s;
+        int32_t cur = -1;
+        uint8_t *m = nullptr;
+        int64_t pay = 0;
+        int32_t rows = 0;
+        void publish() {
+            if (cur < 0) return;
+            std::lock_guard<std::mutex> lk(s->mu);
+            s->pay_bytes[(size_t)cur] = pay;
+            s->row_count[(size_t)cur] = rows;
+            s->rows_total += rows;
+            s->bytes_total += pay;
+            if (rows > 0) {
+                s->ready_q.push_back(cur);
+                s->cv_ready.notify_one();
+            } else {
+                s->free_q.push_back(cur);
+                s->cv_free.notify_one();
+            }
+            cur = -1;
+        }
+        void next_slab() {
+            publish();
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->cv_free.wait(lk, [&] { return !s->free_q.empty() || s->failed || s->cancelled; });
+            if (s->failed || s->cancelled) throw Cancelled{};
+            cur = s->free_q.front();
+            s->free_q.pop_front();
+            lk.unlock();
+            m = s->base + (size_t)cur * (size_t)s->slab_bytes;
+            pay = 0;
+            rows = 0;
+        }
+        // one row: `count` records of `rec` bytes at p (columns + counts, or counts alone for a dense grid's row)
+        void put_row(const uint8_t *p, int64_t count, int64_t rec, int64_t y, int32_t x_off, uint32_t flags) {
+            if (count <= 0) return;
+            if (y < INT32_MIN || y > INT32_MAX) throw FormatError{"bin index does not fit 32 bits"};
+            if (count >= ((int64_t)1 << 28)) throw FormatError{"a row holds more records than a slab"};
+            const int64_t need = count * rec;
+            if (cur < 0 || pay + need + 16 * ((int64_t)rows + 1) > s->slab_bytes) {
+                if (need + 16 > s->slab_bytes) throw FormatError{"a row holds more records than a slab"};
+                next_slab();
+            }
+            memcpy(m + pay, p, (size_t)need);
+            mst_hic_row e{(uint32_t)pay, (int32_t)y, x_off, (uint32_t)count | flags};
+            memcpy(m + s->slab_bytes - 16 * ((int64_t)rows + 1), &e, 16);
+            pay += need + (need & 1);                 // (rec is even for every layout; kept even for the 16-bit loads)
+            ++rows;
+        }
+    };
+
+    // header + rows of one inflated block (the walk of decode_records, without touching a record)
+    void put_block(Worker &w, const uint8_t *data, size_t n) {
+        Cursor c(data, n);
+        if (c.get<int32_t>() < 0) throw FormatError{"negative record count in a block"};
+        const int32_t x_off = c.get<int32_t>();
+        const int32_t y_off = c.get<int32_t>();
+        const bool short_counts = c.get<uint8_t>() == 0;
+        bool short_x = true, short_y = true;
+        if (h->version > 8) {
+            short_x = c.get<uint8_t>() == 0;
+            short_y = c.get<uint8_t>() == 0;
+        }
+        const uint8_t type = c.get<uint8_t>();
+        const uint32_t fc = short_counts ? MST_HIC_ROW_SHORT_COUNTS : 0u;
+        if (type == 1) {
+            const int64_t rec = (short_x ? 2 : 4) + (short_counts ? 2 : 4);
+            const int32_t rows = short_y ? (int32_t)c.get<int16_t>() : c.get<int32_t>();
+            for (int32_t r = 0; r < rows; ++r) {
+                const int32_t y = short_y ? (int32_t)c.get<int16_t>() : c.get<int32_t>();
+                int32_t cols = short_x ? (int32_t)c.get<int16_t>() : c.get<int32_t>();
+                if (cols < 0) cols = 0;                           // the decoder's loop runs zero times as well
+                const uint8_t *p = c.p;
+                c.skip((uint64_t)cols * (uint64_t)rec);
+                w.put_row(p, cols, rec, (int64_t)y_off + y, x_off, fc | (short_x ? 0u : MST_HIC_ROW_INT_COLUMNS));
+            }
+        } else if (type == 2) {
+            const int32_t n_pts = c.get<int32_t>();
+            const int32_t wd = (int32_t)c.get<int16_t>();
+            if (wd <= 0) throw FormatError{"dense block of width 0"};
+            const int64_t rec = short_counts ? 2 : 4;
+            for (int64_t i = 0; i < n_pts; i += wd) {
+                const int64_t cnt = n_pts - i < wd ? n_pts - i : wd;
+                const uint8_t *p = c.p;
+                c.skip((uint64_t)cnt * (uint64_t)rec);
+                w.put_row(p, cnt, rec, (int64_t)y_off + i / wd, x_off, fc | MST_HIC_ROW_DENSE);
+            }
+        } else {
+            throw FormatError{"unknown block type"};
+        }
+    }
+
+    void work() {
+        std::vector<uint8_t> buf, pad;
+        Worker w{this};
+        try {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= todo.size()) break;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (failed || cancelled) break;
+                }
+                const BlockRef *b = todo[i];
+                const size_t n_out = inflate_block(h->map + b->pos, (size_t)b->size, h->size - (size_t)b->pos - (size_t)b->size,
+                                                   buf, pad);
+                put_block(w, buf.data(), n_out);
+            }
+            w.publish();
+        } catch (const Cancelled &) {
+        } catch (const FormatError &e) {
+            fail_with(e.what);
+        } catch (...) {
+            fail_with("out of memory");
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        if (--active == 0) cv_ready.notify_all();
+    }
+};
+
+extern "C" int mst_hic_rawstream_open(mst_hic *h, const char *chrom, int32_t resolution, const char *norm, int64_t max_dist_bins,
+                                      int32_t n_threads, int32_t part, int32_t n_parts, void *slab_memory, int32_t n_slabs,
+                                      int64_t slab_bytes, mst_hic_rawstream **out) {
+    if (!h || !chrom || !out || resolution <= 0 || n_parts < 1 || part < 0 || part >= n_parts || !slab_memory || n_slabs < 2 ||
+        slab_bytes < 4096 || (slab_bytes & 15) || slab_bytes > ((int64_t)1 << 32) || (reinterpret_cast<uintptr_t>(slab_memory) & 15))
+        return fail(MST_IO_E_ARG, "mst_hic_rawstream_open: bad argument (slab_bytes: a multiple of 16 in [4096, 2^32]; "
+                                  "slab_memory 16-byte aligned)");
+    *out = nullptr;
+    if (h->version < 7)
+        return fail(MST_IO_E_FORMAT, "mst_hic_rawstream_open: version %d blocks are plain records, not rows: use mst_hic_stream_open",
+                    h->version);
+    mst_hic_rawstream *s = nullptr;
+    try {
+        s = new mst_hic_rawstream();
+        s->h = h;
+        std::vector<const BlockRef *> todo;
+        const int rc = intra_todo(h, chrom, resolution, norm, max_dist_bins, todo, s->zoom, s->norm_vec, &s->use_norm);
+        if (rc != MST_IO_OK) {
+            delete s;
+            return rc;
+        }
+        s->blocks_total = (int32_t)todo.size();
+        s->chrom_length = h->chroms[(size_t)find_chromosome(h, chrom)].length;
+        split_todo(todo, part, n_parts);
+        s->todo.swap(todo);
+        s->base = static_cast<uint8_t *>(slab_memory);
+        s->n_slabs = n_slabs;
+        s->slab_bytes = slab_bytes;
+        s->pay_bytes.assign((size_t)n_slabs, 0);
+        s->row_count.assign((size_t)n_slabs, 0);
+        for (int32_t i = 0; i < n_slabs; ++i) s->free_q.push_back(i);
+        int nt = n_threads > 0 ? n_threads : default_threads();
+        if (nt < 1) nt = 1;
+        if ((size_t)nt > s->todo.size()) nt = s->todo.empty() ? 1 : (int)s->todo.size();
+        if (nt > n_slabs - 1) nt = n_slabs - 1;                 // every worker holds a slab; one more keeps the consumer fed
+        s->active = nt;
+        for (int t = 0; t < nt; ++t) s->workers.emplace_back([s] { s->work(); });
+        *out = s;
+        return MST_IO_OK;
+    } catch (const FormatError &e) {
+        delete s;
+        return fail(MST_IO_E_FORMAT, "%s", e.what);
+    } catch (...) {
+        delete s;
+        return fail(MST_IO_E_FORMAT, "unreadable file (out of memory?)");
+    }
+}
+
+extern "C" int mst_hic_rawstream_info(mst_hic_rawstream *s, const double **norm_values, int64_t *norm_count,
+                                      int64_t *chrom_length_bp) {
+    if (!s || !norm_values || !norm_count || !chrom_length_bp) return fail(MST_IO_E_ARG, "mst_hic_rawstream_info: bad argument");
+    *norm_values = s->use_norm ? s->norm_vec.data() : nullptr;
+    *norm_count = s->use_norm ? (int64_t)s->norm_vec.size() : -1;
+    *chrom_length_bp = s->chrom_length;
+    return MST_IO_OK;
+}
+
+extern "C" int mst_hic_rawstream_next(mst_hic_rawstream *s, int32_t timeout_ms, int32_t *slab, int64_t *payload_bytes,
+                                      int32_t *rows) {
+    if (!s || !slab || !payload_bytes || !rows) return fail(MST_IO_E_ARG, "mst_hic_rawstream_next: bad argument");
+    std::unique_lock<std::mutex> lk(s->mu);
+    auto ready = [&] { return !s->ready_q.empty() || s->failed || s->active == 0; };
+    if (timeout_ms < 0) s->cv_ready.wait(lk, ready);
+    else if (!s->cv_ready.wait_for(lk, std::chrono::milliseconds(timeout_ms), ready)) return 2;      // nothing yet
+    if (s->failed) return fail(MST_IO_E_ZLIB, "block decode failed: %s", s->error.c_str());
+    if (!s->ready_q.empty()) {
+        *slab = s->ready_q.front();
+        s->ready_q.pop_front();
+        *payload_bytes = s->pay_bytes[(size_t)*slab];
+        *rows = s->row_count[(size_t)*slab];
+        return 1;
+    }
+    return 0;                                                                                         // all delivered
+}
+
+extern "C" int mst_hic_rawstream_release(mst_hic_rawstream *s, int32_t slab) {
+    if (!s || slab < 0 || slab >= s->n_slabs) return fail(MST_IO_E_ARG, "mst_hic_rawstream_release: bad argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->free_q.push_back(slab);
+    s->cv_free.notify_one();
+    return MST_IO_OK;
+}
+
+extern "C" int mst_hic_rawstream_close(mst_hic_rawstream *s, int64_t *rows_total, int64_t *bytes_total, int32_t *blocks_total,
+                                       int32_t *blocks_mine) {
+    if (!s) return MST_IO_OK;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->cancelled = true;
+        s->cv_free.notify_all();
+    }
+    for (auto &t : s->workers) t.join();
+    int rc = MST_IO_OK;
+    if (s->failed) rc = fail(MST_IO_E_ZLIB, "block decode failed: %s", s->error.c_str());
+    if (rows_total) *rows_total = s->rows_total;
+    if (bytes_total) *bytes_total = s->bytes_total;
     if (blocks_total) *blocks_total = s->blocks_total;
     if (blocks_mine) *blocks_mine = (int32_t)s->todo.size();
     delete s;

@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
-MST_IO_ABI_VERSION = 2          # include/mustache_io.h
+MST_IO_ABI_VERSION = 3          # include/mustache_io.h
 
 
 class HicError(RuntimeError):
@@ -55,6 +55,14 @@ _SIGNATURES = {
     "mst_hic_stream_release": (ctypes.c_int, [_P, ctypes.c_int32]),
     "mst_hic_stream_close": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                             ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "mst_hic_rawstream_open": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int32,
+                                              ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(_P)]),
+    "mst_hic_rawstream_info": (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "mst_hic_rawstream_next": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64),
+                                              ctypes.POINTER(ctypes.c_int32)]),
+    "mst_hic_rawstream_release": (ctypes.c_int, [_P, ctypes.c_int32]),
+    "mst_hic_rawstream_close": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                               ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "mst_text_read_contacts": (ctypes.c_int64, [ctypes.c_char_p, ctypes.c_char, ctypes.c_char_p, ctypes.c_int32,
                                                 ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_P), ctypes.POINTER(_P),
                                                 ctypes.POINTER(_P)]),
@@ -186,6 +194,55 @@ class HicStream:
     __del__ = close
 
 
+class HicRawStream:
+    """mst_hic_rawstream_*: the RAW rows of one chromosome's near-diagonal blocks (or of share `part` of them) delivered slab by
+    slab into caller-owned memory while later blocks are still being inflated -- record bytes as the file stores them plus one
+    16-byte directory entry per row (include/mustache_hicrow.h); the rows are decoded on the GPU (mst_band_scatter_hic_rows).
+    `memory_ptr` points to n_slabs * slab_bytes bytes (page-locked).  Versions 7-9 only."""
+
+    def __init__(self, hic, chrom, resolution, norm, max_dist_bins, memory_ptr, n_slabs, slab_bytes, threads=0, part=(0, 1)):
+        self._lib, self._hic = hic._lib, hic
+        self._s = _P()
+        self.slab_bytes, self.n_slabs = int(slab_bytes), int(n_slabs)
+        _check(self._lib, self._lib.mst_hic_rawstream_open(hic._h, str(chrom).encode(), int(resolution), str(norm).encode(),
+                                                           int(max_dist_bins), int(threads), int(part[0]), int(part[1]),
+                                                           _P(memory_ptr), int(n_slabs), int(slab_bytes), ctypes.byref(self._s)))
+        self.rows_total = self.bytes_total = self.blocks_total = self.blocks_mine = None
+
+    def info(self):
+        """(the chromosome's normalisation vector as a float64 array (a copy) or None for norm NONE, its length in bp)"""
+        v, n, length = _P(), ctypes.c_int64(), ctypes.c_int64()
+        _check(self._lib, self._lib.mst_hic_rawstream_info(self._s, ctypes.byref(v), ctypes.byref(n), ctypes.byref(length)))
+        if n.value < 0:
+            return None, int(length.value)
+        if n.value == 0:
+            return np.zeros(0, np.float64), int(length.value)
+        return np.ctypeslib.as_array(ctypes.cast(v, ctypes.POINTER(ctypes.c_double)), shape=(n.value,)).copy(), int(length.value)
+
+    def next(self, timeout_ms=-1):
+        """(slab index, payload bytes, rows) of a filled slab; None when nothing was ready within timeout_ms; False at the end."""
+        slab, nbytes, rows = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int32()
+        rc = _check(self._lib, self._lib.mst_hic_rawstream_next(self._s, int(timeout_ms), ctypes.byref(slab), ctypes.byref(nbytes),
+                                                                ctypes.byref(rows)))
+        if rc == 1:
+            return int(slab.value), int(nbytes.value), int(rows.value)
+        return None if rc == 2 else False
+
+    def release(self, slab):
+        _check(self._lib, self._lib.mst_hic_rawstream_release(self._s, int(slab)))
+
+    def close(self):
+        if self._s:
+            rt, bt_, bt, bm = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+            s, self._s = self._s, _P()
+            _check(self._lib, self._lib.mst_hic_rawstream_close(s, ctypes.byref(rt), ctypes.byref(bt_), ctypes.byref(bt),
+                                                                ctypes.byref(bm)))
+            self.rows_total, self.bytes_total = int(rt.value), int(bt_.value)
+            self.blocks_total, self.blocks_mine = int(bt.value), int(bm.value)
+
+    __del__ = close
+
+
 class PackedContacts:
     """Records of one chromosome as the native reader hands them to the GPU loader (mst_band_from_packed): x = binX (int32),
     dist = binY - binX (int32), v = straw's float32 value; `n` = max(binY) + 1 (mustache.py:894), `res` the resolution.
@@ -204,12 +261,26 @@ class PackedContacts:
         # streamed reads (normalize.read_hic_stream_to_device): the records already sit in device memory as a list of
         # (x int32, dist uint16 | int32, v float32, count) tensors, one per slab; x / dist / v above are then None
         self.device_parts = None
+        # raw streamed reads (normalize.read_hic_stream_to_device, `.hic` v7-9): the rows were decoded ON THE DEVICE straight
+        # into `device_band` ([dpx + 2][n_alloc] float64, this rank's share scattered, `band_stats` = the kernel's uint64 [4]
+        # counters); `raw_parts` = the device copies of the slabs (payload bytes, row directory, rows), kept only when other
+        # ranks need them (n_parts > 1) or a read-back check was asked for; `raw_ctx` = what the kernel call needs again
+        self.device_band = self.band_stats = self.raw_parts = self.raw_ctx = None
 
     def __len__(self):
         return self.count
 
     def coo(self):
         """(x, y, v) as the reference's int64 / float64 COO (copies) -- for callers that want the classic triple."""
+        if self.device_band is not None:
+            import torch
+            if self.n_parts > 1:
+                raise RuntimeError("coo() of one rank's share of a raw streamed read: call normalize.band_from_packed first")
+            d, x = torch.nonzero(self.device_band[:, :self.n], as_tuple=True)
+            v = self.device_band[d, x]
+            order = torch.argsort(x * (self.device_band.shape[0]) + d)
+            x, d, v = x[order].cpu().numpy(), d[order].cpu().numpy(), v[order].cpu().numpy()
+            return x, x + d, v
         if self.device_parts is not None:
             x = np.concatenate([p[0][:p[3]].cpu().numpy() for p in self.device_parts] or [np.zeros(0, np.int32)]).astype(np.int64)
             d = np.concatenate([p[1][:p[3]].cpu().numpy() for p in self.device_parts] or [np.zeros(0, np.int32)]).astype(np.int64)

@@ -58,41 +58,66 @@ def pinned_packed_alloc(count):
 
 
 _SLAB_POOL = {}
+_SLAB_POOL_CAP = 512 << 20          # page-locked bytes the streamed reads may keep (MUSTACHE_HIC_POOL_MB overrides)
 
 
-def _slab_pool(n_slabs, slab_records, dist_bytes):
-    """Page-locked slab memory for the streaming `.hic` read, kept for the life of the process (a whole-genome run reuses it
-    chromosome after chromosome; pinning fresh pages costs ~0.3 s per GB)."""
-    key = (int(n_slabs), int(slab_records), int(dist_bytes))
-    buf = _SLAB_POOL.get(key)
-    if buf is None:
+def _slab_pool(nbytes):
+    """Page-locked slab memory for the streaming `.hic` reads, kept until release_slab_pool() (a whole-genome run reuses it
+    chromosome after chromosome; pinning fresh pages costs ~0.3 s per GB).  One buffer, grown when a read asks for more."""
+    buf = _SLAB_POOL.get("buf")
+    if buf is None or buf.numel() < nbytes:
         _SLAB_POOL.clear()
-        buf = _SLAB_POOL[key] = torch.empty(key[0] * key[1] * (8 + key[2]), dtype=torch.uint8, pin_memory=True)
+        buf = _SLAB_POOL["buf"] = torch.empty(int(nbytes), dtype=torch.uint8, pin_memory=True)
     return buf
 
 
+def release_slab_pool():
+    """give the page-locked slab memory back (readers.close_hic_handle calls this when the last `.hic` file is closed)"""
+    _SLAB_POOL.clear()
+
+
+def _slab_count(threads, slab_bytes):
+    """every worker thread fills one slab at a time; as many again (+ 8) keep uploads in flight while they do -- within the
+    pool's cap, but never fewer than the workers + 2"""
+    import os
+    env = int(os.environ.get("MUSTACHE_HIC_SLABS", "0"))
+    if env:
+        return env
+    cap = int(os.environ.get("MUSTACHE_HIC_POOL_MB", "0")) << 20 or _SLAB_POOL_CAP
+    return max(8, min(256, 2 * threads + 8, max(threads + 2, cap // slab_bytes)))
+
+
 def read_hic_stream_to_device(hic, chrom, res, norm, dpx, chrom_size_bp, device, part=(0, 1), threads=0,
-                              slab_records=1 << 19, n_slabs=None):
-    """hicfile.HicFile -> hicfile.PackedContacts whose records already sit in DEVICE memory (pc.device_parts): the native
-    reader's worker threads inflate and decode into page-locked slabs (binX int32, value float32, distance uint16: 10 bytes per
-    record) and every slab is copied to the device on a side stream as soon as it is full -- the PCIe transfer runs under the
-    inflate of the later blocks instead of after it.  part = (rank, ranks): this rank's share of the blocks only.
-    band_from_packed() takes the result (and exchanges the shares between the ranks first when there are several)."""
+                              slab_records=1 << 19, n_slabs=None, raw=None, keep_raw=False):
+    """hicfile.HicFile -> hicfile.PackedContacts whose contacts already sit in DEVICE memory when this returns; the PCIe
+    transfer runs under the inflate of the later blocks instead of after it.  part = (rank, ranks): this rank's share of the
+    blocks only.  band_from_packed() takes the result (and exchanges the shares between the ranks first when there are several).
+
+    raw (default: `.hic` versions 7-9 unless MUSTACHE_HIC_RAW=0): the host ONLY INFLATES -- worker threads copy each row's record
+    bytes as the file stores them (6 bytes per record) into page-locked slabs with a 16-byte directory entry per row
+    (mst_hic_rawstream_*), every slab goes to the device on the copy stream and mst_band_scatter_hic_rows decodes the rows,
+    divides by the normalisation vector, filters and scatters straight into the band (pc.device_band) right behind the copy.
+    Otherwise (v6 files, raw=False): the workers decode into slabs of packed records (binX int32, value float32, distance
+    uint16: 10 bytes per record, pc.device_parts) and band_from_packed scatters them."""
     import os
     import time
     from .hicfile import HicStream, PackedContacts
     require_gpu()
+    if raw is None:
+        raw = hic.version >= 7 and os.environ.get("MUSTACHE_HIC_RAW", "1") != "0"
+    if not threads:
+        threads = max(4, _reader_threads() // max(1, int(part[1])))       # ranks of one node share its cores
+    if raw:
+        return _read_hic_raw_to_band(hic, chrom, res, norm, dpx, chrom_size_bp, device, part, threads, slab_records, n_slabs,
+                                     keep_raw)
     t0 = time.time()
     dist_bytes = 2 if dpx + 1 <= 65535 else 4
     slab_records = int(os.environ.get("MUSTACHE_HIC_SLAB_RECORDS", "0")) or slab_records
     slab_records += slab_records & 1              # even: every array of a slab stays 4-byte aligned
-    if not threads:
-        threads = max(4, _reader_threads() // max(1, int(part[1])))       # ranks of one node share its cores
-    if n_slabs is None:
-        # every worker thread fills one slab at a time; as many again keep uploads in flight while they do
-        n_slabs = int(os.environ.get("MUSTACHE_HIC_SLABS", "0")) or min(256, max(8, 2 * threads + 8))
-    pool = _slab_pool(n_slabs, slab_records, dist_bytes)
     slab_bytes = slab_records * (8 + dist_bytes)
+    if n_slabs is None:
+        n_slabs = _slab_count(threads, slab_bytes)
+    pool = _slab_pool(n_slabs * slab_bytes)
     ddt = torch.uint16 if dist_bytes == 2 else torch.int32
     st = HicStream(hic, chrom, res, norm, int(dpx), int(chrom_size_bp), pool.data_ptr(), n_slabs, slab_records, dist_bytes,
                    threads=threads, part=part)
@@ -138,6 +163,86 @@ def read_hic_stream_to_device(hic, chrom, res, norm, dpx, chrom_size_bp, device,
     return pc
 
 
+def _scatter_rows(lib, pay, rows, n_rows, ctx, band, stats, stream, verify=0):
+    _lib.check(lib.mst_band_scatter_hic_rows(_ptr(pay), _ptr(rows), int(n_rows), _ptr(ctx["norm"]) if ctx["norm"] is not None else None,
+                                             ctx["n_norm"], ctx["max_dist"], ctx["y_limit"], ctx["n_alloc"], ctx["dpx"], _ptr(band),
+                                             _ptr(stats), int(verify), stream))
+
+
+def _read_hic_raw_to_band(hic, chrom, res, norm, dpx, chrom_size_bp, device, part, threads, slab_records, n_slabs, keep_raw):
+    """the raw form of read_hic_stream_to_device (see there).  The band is allocated for every bin the chromosome can hold --
+    ceil(length / res) from the file's header, or the caller's smaller size -- and trimmed by band_from_packed to the
+    reference's n = max(binY) + 1 over the records that survive the filters (mustache.py:894), which only the kernel knows."""
+    import os
+    import time
+    from .engine import device_streams
+    from .hicfile import HicRawStream, PackedContacts
+    lib = require_gpu()
+    t0 = time.time()
+    device = torch.device(device)
+    slab_bytes = int(os.environ.get("MUSTACHE_HIC_SLAB_BYTES", "0")) or 10 * int(os.environ.get("MUSTACHE_HIC_SLAB_RECORDS", "0")) \
+        or 10 * int(slab_records)
+    slab_bytes = max(4096, (slab_bytes + 15) // 16 * 16)
+    if n_slabs is None:
+        n_slabs = _slab_count(threads, slab_bytes)
+    pool = _slab_pool(n_slabs * slab_bytes)
+    st = HicRawStream(hic, chrom, res, norm, int(dpx), pool.data_ptr(), n_slabs, slab_bytes, threads=threads, part=part)
+    side = device_streams(device)[2]                        # the process's one copy stream of this device
+    keep = keep_raw or part[1] > 1 or bool(os.environ.get("MUSTACHE_CHECK_PACKED"))
+    parts, pending = [], []
+    try:
+        normv, length = st.info()
+        y_limit = -(-int(chrom_size_bp) // int(res)) if chrom_size_bp and chrom_size_bp > 0 else 0
+        n_alloc = max(1, -(-int(length) // int(res)))
+        if y_limit:
+            n_alloc = max(1, min(n_alloc, y_limit))
+        with torch.cuda.stream(side):
+            band = torch.zeros((dpx + 2, n_alloc), dtype=torch.float64, device=device)
+            stats = torch.zeros(4, dtype=torch.int64, device=device)
+            ctx = {"norm": None if normv is None else torch.from_numpy(normv).to(device), "n_norm": -1 if normv is None else len(normv),
+                   "max_dist": int(dpx), "y_limit": y_limit, "n_alloc": n_alloc, "dpx": int(dpx)}
+        while True:
+            got = st.next(2 if pending else -1)
+            while pending and pending[0][0].query():          # slabs whose copies have completed go back to the workers
+                st.release(pending.pop(0)[1])
+            if got is None:
+                continue
+            if got is False:
+                break
+            slab, nbytes, rows = got
+            base = slab * slab_bytes
+            with torch.cuda.stream(side), torch.cuda.device(device):
+                if slab_bytes - nbytes - 16 * rows <= slab_bytes // 16:
+                    dv = pool[base:base + slab_bytes].to(device, non_blocking=True)       # a full slab goes over in ONE copy
+                    pay, dr = dv[:nbytes], dv[slab_bytes - 16 * rows:]
+                else:
+                    pay = pool[base:base + nbytes].to(device, non_blocking=True)
+                    dr = pool[base + slab_bytes - 16 * rows:base + slab_bytes].to(device, non_blocking=True)
+                ev = side.record_event()
+                _scatter_rows(lib, pay, dr, rows, ctx, band, stats, side.cuda_stream)
+            if keep:
+                parts.append((pay, dr, rows))
+            pending.append((ev, slab))
+        side.synchronize()
+    finally:
+        st.close()
+    ymax1, kept, beyond, _ = (int(a) for a in stats.cpu().numpy())
+    if beyond:
+        import warnings
+        warnings.warn("%s: %d record(s) lie beyond the chromosome length the file's header gives (%d bp): reading it again through "
+                      "the host decoder" % (chrom, beyond, length))
+        del band, parts
+        return read_hic_stream_to_device(hic, chrom, res, norm, dpx, chrom_size_bp, device, part=part, threads=threads,
+                                         slab_records=slab_records, raw=False)
+    pc = PackedContacts(None, None, None, ymax1, res, part=part[0], n_parts=part[1], blocks_total=st.blocks_total,
+                        blocks_mine=st.blocks_mine, count=kept)
+    pc.device_band, pc.band_stats, pc.raw_parts, pc.raw_ctx = band, stats, parts if keep else None, ctx
+    pc.raw_ctx["reread"] = lambda: read_hic_stream_to_device(hic, chrom, res, norm, dpx, chrom_size_bp, device, part=(0, 1),
+                                                             threads=threads, slab_records=slab_records, raw=False)
+    pc.read_s = time.time() - t0
+    return pc
+
+
 def _reader_threads():
     """The native reader's default worker count: the hardware threads, at most 128, and at most FOUR times the container's CPU
     quota when there is one.  (Measured on the 16-CPU-quota GPU box, 1.8 core-seconds of inflate per read: 32 threads 0.086 s
@@ -171,6 +276,8 @@ def band_from_packed(pc, dpx, device, check=None):
     lib = require_gpu()
     if check is None:
         check = bool(os.environ.get("MUSTACHE_CHECK_PACKED"))
+    if getattr(pc, "device_band", None) is not None:
+        return _band_from_raw(lib, pc, dpx, device, check)
     dev_parts = getattr(pc, "device_parts", None)
     if getattr(pc, "n_parts", 1) > 1:
         from .sharding import all_gather_packed
@@ -210,7 +317,59 @@ def band_from_packed(pc, dpx, device, check=None):
                 vs = np.concatenate([p[2][:p[3]].cpu().numpy().astype(np.float64) for p in parts])
                 del band
                 return band_from_host_coo(xs, xs + ds, vs, n, dpx, device)
+    if dev_parts is not None:
+        # the slabs were allocated on the copy stream and have just been read by kernels queued on THIS stream: tell the
+        # allocator, or a caller that drops `pc` while those kernels wait behind earlier work hands the blocks back to the copy
+        # stream's pool and the next chromosome's slabs (the reader thread runs ahead) overwrite records not yet scattered
+        cur = torch.cuda.current_stream(device)
+        for part in dev_parts:
+            for t in part[:3]:
+                t.record_stream(cur)
     return band
+
+
+def _band_from_raw(lib, pc, dpx, device, check):
+    """band_from_packed for a raw streamed read (read_hic_stream_to_device, `.hic` v7-9): this rank's rows are in the band
+    already (scattered by the kernel behind each slab's copy).  With several ranks the RAW slabs are exchanged
+    (sharding.all_gather_raw: 6 bytes per record over xGMI) and every rank decodes the other ranks' rows into its own band --
+    the same band on every rank, the 1-rank run's bit for bit.  Then the band is trimmed to n = max(binY) + 1 over the kept
+    records (mustache.py:894).  `check`: every record is read back (two records with different values sharing a pixel = a
+    malformed file); on a mismatch the chromosome is read again through the host decoder, whose loader applies the
+    reference's last-entry-wins rule."""
+    band, stats, ctx = pc.device_band, pc.band_stats, pc.raw_ctx
+    if check and pc.raw_parts is None:                   # the slabs were not kept: the check runs on a second read
+        return band_from_packed(ctx["reread"](), dpx, device, check=True)
+    cur = torch.cuda.current_stream(device)
+    # allocated and filled on the copy stream (synchronised before the read returned), used on this one from here on
+    for t in [band, stats] + ([ctx["norm"]] if ctx["norm"] is not None else []) + [t for p in (pc.raw_parts or []) for t in p[:2]]:
+        t.record_stream(cur)
+    parts = pc.raw_parts or []
+    with torch.cuda.device(device):
+        if pc.n_parts > 1 and not getattr(pc, "_exchanged", False):
+            from .sharding import all_gather_raw
+            rank, others = all_gather_raw(parts, device)
+            for r, plist in enumerate(others):
+                if r != rank:
+                    for pay, dr, rows in plist:
+                        _scatter_rows(lib, pay, dr, rows, ctx, band, stats, _stream())
+            pc._exchanged = True
+            pc.raw_parts = parts = [p for plist in others for p in plist]
+        if check:
+            for pay, dr, rows in parts:
+                _scatter_rows(lib, pay, dr, rows, ctx, band, stats, _stream(), verify=1)
+        ymax1, kept, beyond, bad = (int(a) for a in stats.cpu().numpy())
+    if beyond:
+        raise RuntimeError("records beyond the chromosome length of the file's header in another rank's share")
+    if check and bad:
+        import warnings
+        warnings.warn("%d record(s) of the .hic file share a pixel with another value: reading the chromosome again through the host "
+                      "decoder" % bad)
+        del band
+        again = ctx["reread"]()
+        return band_from_packed(again, dpx, device, check=True)
+    pc.n_all = pc.n = n = ymax1 if kept else 0
+    pc.count_all = kept
+    return band if n == band.shape[1] else band[:, :n].contiguous()
 
 
 def band_to_coo(band, x, y, v_out, n, dpx):

@@ -100,6 +100,53 @@ def all_gather_packed(x, dist_, v, n, device, group=None):
     return parts, n_all
 
 
+def all_gather_raw(parts, device, group=None):
+    """The raw form of all_gather_packed (normalize.read_hic_stream_to_device, `.hic` v7-9): every rank holds the RAW slabs of
+    its share of a chromosome's blocks -- parts = [(payload uint8 device tensor, row directory uint8 device tensor (16 bytes
+    per row, include/mustache_hicrow.h), rows)] -- and receives every rank's: (rank, slabs) with slabs[r] = rank r's list in
+    the same form (device tensors; slabs[rank] = `parts` itself).  Two collectives: all_gather of (slab count, blob bytes),
+    then all_gather of one padded byte blob per rank {int64 [slabs][2] (payload bytes, rows), then per slab its payload padded
+    to 16 bytes and its directory} -- 6 bytes per record over RCCL / xGMI from device memory (gloo: from host memory)."""
+    rank, ws = world()
+    on_dev = dist.get_backend(group) == "nccl"
+    where = device if on_dev else "cpu"
+    pad16 = lambda b: -(-int(b) // 16) * 16
+    k = len(parts)
+    sizes = [(int(p[0].numel()), int(p[2])) for p in parts]
+    nbytes = 16 * k + sum(pad16(b) + 16 * r for b, r in sizes)
+    meta = torch.tensor([k, nbytes], dtype=torch.int64, device=where)
+    metas = [torch.zeros_like(meta) for _ in range(ws)]
+    dist.all_gather(metas, meta, group=group)
+    ks = [int(m[0].item()) for m in metas]
+    mx = max(max(int(m[1].item()) for m in metas), 16)
+    blob = torch.zeros(mx, dtype=torch.uint8, device=where)
+    if k:
+        blob[:16 * k].copy_(torch.tensor(sizes, dtype=torch.int64).view(torch.uint8).reshape(-1), non_blocking=on_dev)
+    off = 16 * k
+    for (pay, dr, rows), (b, r) in zip(parts, sizes):
+        blob[off:off + b].copy_(pay.reshape(-1), non_blocking=on_dev)
+        off += pad16(b)
+        blob[off:off + 16 * r].copy_(dr.reshape(-1)[:16 * r], non_blocking=on_dev)
+        off += 16 * r
+    got = [torch.empty_like(blob) for _ in range(ws)]
+    dist.all_gather(got, blob, group=group)
+    out = []
+    for r in range(ws):
+        if r == rank:
+            out.append(list(parts))
+            continue
+        g = got[r] if on_dev else got[r].to(device)
+        table = g[:16 * ks[r]].cpu().view(torch.int64).reshape(-1, 2).tolist() if ks[r] else []
+        off, lst = 16 * ks[r], []
+        for b, rows in table:
+            pay = g[off:off + b]
+            off += pad16(b)
+            lst.append((pay, g[off:off + 16 * rows], int(rows)))
+            off += 16 * rows
+        out.append(lst)
+    return rank, out
+
+
 def gather_loops(loops, device=None, group=None):
     """All ranks pass their list of [x, y, fdr, sigma]; every rank gets the concatenation in rank order
     (rank 0 writes the TSV).  Two collectives: all_gather of the counts, all_gather of the padded records."""

@@ -511,7 +511,7 @@ def test_two_rank_cli_equals_one_process(golden_dir, tmp_path):
             assert sum(int(s[1]) for s in shares) == int(shares[0][2]) and all(int(s[1]) > 0 for s in shares)
 
 
-def _band_digest_worker(rank, ws, port, hic, res, dpx, q):
+def _band_digest_worker(rank, ws, port, hic, res, dpx, q, mode="packed"):
     import hashlib
     import torch
     import torch.distributed as dist
@@ -523,7 +523,12 @@ def _band_digest_worker(rank, ws, port, hic, res, dpx, q):
     from mustache_amd.pipeline import ChromosomePipeline
     pipe = ChromosomePipeline(OCT)
     with HicFile(hic) as h:
-        pc = read_intra_packed(h, "chrB", res, "NONE", dpx, 0, alloc=pinned_packed_alloc, part=(rank, ws))
+        if mode == "packed":
+            pc = read_intra_packed(h, "chrB", res, "NONE", dpx, 0, alloc=pinned_packed_alloc, part=(rank, ws))
+        else:       # streamed: raw rows decoded on the device (the default for v7-9) or packed records from the host decoder
+            from mustache_amd.normalize import read_hic_stream_to_device
+            pc = read_hic_stream_to_device(h, "chrB", res, "NONE", dpx, 0, torch.device("cuda", 0), part=(rank, ws), threads=3,
+                                           slab_records=8192, raw=mode == "raw")
     band, n = pipe.normalized_band_packed(pc, dpx)
     loops = pipe.run_band(band, n, dpx, 0.7, 0.2, distributed=True)
     q.put((rank, n, len(pc), pc.blocks_mine, pc.blocks_total, hashlib.sha256(band.cpu().numpy().tobytes()).hexdigest(),
@@ -532,8 +537,10 @@ def _band_digest_worker(rank, ws, port, hic, res, dpx, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_shared_decode_gives_the_one_rank_band_bit_for_bit(tmp_path):
-    """Two processes on this box's one GPU (gloo): each decodes ITS share of the `.hic` blocks, the shares are exchanged
+@pytest.mark.parametrize("mode", ["packed", "raw", "stream"])
+def test_two_rank_shared_decode_gives_the_one_rank_band_bit_for_bit(tmp_path, mode):
+    """(mode: one-shot packed read / streamed raw rows, exchanged as raw slabs and decoded on the device / streamed packed records)
+    Two processes on this box's one GPU (gloo): each decodes ITS share of the `.hic` blocks, the shares are exchanged
     (sharding.all_gather_packed) and every rank scatters + normalises the same record set -- the normalised band's sha-256 is
     the same on both ranks and equal to the 1-rank band's, and so are the loops."""
     import hashlib
@@ -563,7 +570,7 @@ def test_two_rank_shared_decode_gives_the_one_rank_band_bit_for_bit(tmp_path):
     sk.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_band_digest_worker, args=(r, 2, port, hic, res, dpx, q)) for r in range(2)]
+    procs = [ctx.Process(target=_band_digest_worker, args=(r, 2, port, hic, res, dpx, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=600) for _ in range(2))
@@ -825,10 +832,13 @@ def test_shared_tiles_equal_tiles_computed_per_block(n, dpx, res, octs):
            [(int(a), int(b), s_) for a, b, _, s_ in sorted(loops_plain, key=key)]
 
 
-def test_streamed_hic_read_gives_the_one_shot_band(tmp_path):
+@pytest.mark.parametrize("raw", [True, False])
+def test_streamed_hic_read_gives_the_one_shot_band(tmp_path, raw):
     """normalize.read_hic_stream_to_device (slabs copied to the device while later blocks inflate; what `-f x.hic` uses on a
     GPU) delivers the record set of the one-shot packed read, and band_from_packed builds the identical band from either --
-    with slabs much smaller than the chromosome, so that many are in flight and reused."""
+    with slabs much smaller than the chromosome, so that many are in flight and reused.  raw=True (the default for v7-9): the
+    host only inflates, the rows are decoded, normalised, filtered and scattered by mst_band_scatter_hic_rows; raw=False: the
+    host decodes into packed records."""
     import sys
     import torch
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -841,24 +851,35 @@ def test_streamed_hic_read_gives_the_one_shot_band(tmp_path):
     near = (y - x) <= dpx
     hic = str(tmp_path / "st.hic")
     kr = np.random.default_rng(2).uniform(0.6, 1.7, n + 1)
+    kr[[17, 5100]] = np.nan
     write_hic(hic, [("All", 1), ("chrB", n * res)], {1: {res: (x[near], y[near], np.round(v[near]) + 1.0)}}, {("KR", 1, res): kr},
               version=8, block_bin_count=128, float_counts=False)
     dev = torch.device("cuda", 0)
     with HicFile(hic) as h:
         one = read_intra_packed(h, "chrB", res, "KR", dpx, 0)
-        st = read_hic_stream_to_device(h, "chrB", res, "KR", dpx, 0, dev, threads=4, slab_records=20000, n_slabs=6)
-    assert st.count == len(one) > 100000 and st.n == one.n and len(st.device_parts) > 8
+        st = read_hic_stream_to_device(h, "chrB", res, "KR", dpx, 0, dev, threads=4, slab_records=20000, n_slabs=6, raw=raw,
+                                       keep_raw=True)
+    assert st.count == len(one) > 100000 and st.n == one.n
+    assert len(st.raw_parts if raw else st.device_parts) > 8 and (st.device_band is not None) == raw
     sx, sy, sv = st.coo()
     ox, oy, ov = one.coo()
     so, oo = np.lexsort((sy, sx)), np.lexsort((oy, ox))
     assert np.array_equal(sx[so], ox[oo]) and np.array_equal(sy[so], oy[oo]) and np.array_equal(sv[so], ov[oo])
-    assert torch.equal(band_from_packed(st, dpx, dev), band_from_packed(one, dpx, dev))
-    assert torch.equal(band_from_packed(st, dpx, dev, check=True), band_from_packed(one, dpx, dev))     # read-back check passes
+    want = band_from_packed(one, dpx, dev)
+    assert torch.equal(band_from_packed(st, dpx, dev), want) and want.shape[1] == one.n
+    assert torch.equal(band_from_packed(st, dpx, dev, check=True), want)     # read-back check passes
     # slabs much smaller than a block: a slab is handed over when it is full, in the middle of a block if need be -- same band
     with HicFile(hic) as h:
-        tiny = read_hic_stream_to_device(h, "chrB", res, "KR", dpx, 0, dev, threads=3, slab_records=4096, n_slabs=7)
-    assert tiny.count == len(one) and len(tiny.device_parts) >= len(one) // 4096
-    assert torch.equal(band_from_packed(tiny, dpx, dev), band_from_packed(one, dpx, dev))
+        tiny = read_hic_stream_to_device(h, "chrB", res, "KR", dpx, 0, dev, threads=3, slab_records=4096, n_slabs=7, raw=raw,
+                                         keep_raw=True)
+        # ... and a caller's chromosome size that cuts the last bins off (straw's window end, mustache.py:320-333)
+        cut = read_hic_stream_to_device(h, "chrB", res, "KR", dpx, (n - 40) * res, dev, threads=3, slab_records=4096, raw=raw)
+        cut_one = read_intra_packed(h, "chrB", res, "KR", dpx, (n - 40) * res)
+    assert tiny.count == len(one) and len(tiny.raw_parts if raw else tiny.device_parts) >= len(one) // 4096 // (2 if raw else 1)
+    assert torch.equal(band_from_packed(tiny, dpx, dev), want)
+    assert cut.count == len(cut_one) < len(one) and cut.n == cut_one.n <= n - 40
+    assert torch.equal(band_from_packed(cut, dpx, dev), band_from_packed(cut_one, dpx, dev))
+    assert torch.equal(band_from_packed(cut, dpx, dev, check=True), band_from_packed(cut_one, dpx, dev))   # not kept: re-read + check
 
 
 def test_graph_replay_gives_identical_records():

@@ -35,10 +35,10 @@ def test_io_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(ROOT, "mustache_amd", "libmustache_io.so"))
     header = open(os.path.join(ROOT, "include", "mustache_io.h")).read()
     names = set(re.findall(r"\b(mst_(?:io|hic|text)_\w+)\s*\(", header))
-    assert len(names) == 23
+    assert len(names) == 28
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.mst_io_abi_version() == 2
+    assert lib.mst_io_abi_version() == 3
 
 
 @pytest.mark.parametrize("version,float_counts,dense,short_coords,bbc", [
@@ -366,3 +366,59 @@ def test_streamed_read_equals_packed_read(tmp_path, version, float_counts, dense
     want = "%d %d %d %r" % (len(whole), int(whole.x.astype(np.int64).sum()), int(whole.dist.astype(np.int64).sum()),
                             float(whole.v.astype(np.float64).sum()))
     assert r.stdout.strip() == want
+
+
+@pytest.mark.parametrize("version,float_counts,dense,short_coords,n_parts", [
+    (8, True, False, True, 1), (8, False, False, True, 2), (9, True, False, False, 3), (8, True, True, True, 1),
+    (9, False, False, True, 1), (8, False, True, True, 2), (9, False, True, False, 1)])
+def test_raw_streamed_rows_decode_to_the_packed_read(tmp_path, version, float_counts, dense, short_coords, n_parts):
+    """mst_hic_rawstream_*: the host only inflates and copies each row's record bytes + a 16-byte directory entry; the rows,
+    decoded by the NumPy restatement of the device kernel (tests/hic_rows_numpy.py: columns, counts, the division by the norm
+    vector, every filter), are exactly the records of the host decoder's packed read -- row-list and dense blocks, short and long
+    coordinates, short and float counts, slabs larger than a block and slabs of a few rows, several parts."""
+    from hic_rows_numpy import decode_slab
+    from mustache_amd.hicfile import HicFile, HicRawStream, read_intra_packed
+    n, res, dpx = 2500, 5000, 260
+    x, y, c = _contacts(n, 320, 50000, 11 * version + n_parts, integer=not float_counts)
+    norm = np.random.default_rng(5).uniform(0.5, 2.0, n + 1)
+    norm[[9, 300]] = np.nan
+    p = str(tmp_path / "s.hic")
+    write_hic(p, [("All", 7500), ("chr1", n * res)], {1: {res: (x, y, c)}}, {("KR", 1, res): norm}, version=version,
+              block_bin_count=64, float_counts=float_counts, dense_blocks=dense, short_coords=short_coords)
+    size_bp = (n - 3) * res
+    with HicFile(p) as h:
+        whole = read_intra_packed(h, "chr1", res, "KR", dpx, size_bp)
+        key_w = whole.x.astype(np.int64) * (1 << 20) + whole.dist
+        order_w = np.argsort(key_w)
+        for slab_bytes, n_slabs in ((1 << 16, 5), (4096, 9)):
+            mem = np.zeros(n_slabs * slab_bytes + 16, np.uint8)
+            base0 = (-mem.ctypes.data) % 16                        # 16-byte aligned slab memory
+            got, blocks, rows_seen = [], 0, 0
+            for part in range(n_parts):
+                st = HicRawStream(h, "chr1", res, "KR", dpx, mem.ctypes.data + base0, n_slabs, slab_bytes, threads=3,
+                                  part=(part, n_parts))
+                nv, length = st.info()
+                assert length == n * res and len(nv) == n + 1
+                assert np.array_equal(nv, norm.astype(np.float32).astype(np.float64) if version > 8 else norm, equal_nan=True)
+                while True:
+                    r = st.next(50)
+                    if r is None:
+                        continue
+                    if r is False:
+                        break
+                    slab, nbytes, rows = r
+                    assert rows > 0 and nbytes + 16 * rows <= slab_bytes and nbytes % 2 == 0
+                    base = base0 + slab * slab_bytes
+                    got.append(decode_slab(mem[base:base + nbytes].copy(), mem[base + slab_bytes - 16 * rows:base + slab_bytes].copy(),
+                                           nv, dpx, -(-size_bp // res)))
+                    rows_seen += rows
+                    st.release(slab)
+                st.close()
+                blocks += st.blocks_mine
+                assert st.blocks_total == whole.blocks_total
+            assert st.rows_total > 0 and blocks == whole.blocks_total
+            gx, gy, gv = (np.concatenate([g[i] for g in got]) for i in range(3))
+            k = gx * (1 << 20) + (gy - gx)
+            o = np.argsort(k)
+            assert len(k) == len(key_w) > 10000 and np.array_equal(k[o], key_w[order_w]) and np.array_equal(gv[o], whole.v[order_w])
+            assert int(gy.max()) + 1 == whole.n

@@ -43,6 +43,33 @@ def _native(path, chrom, res, norm, max_dist):
     return sorted(zip(x.tolist(), y.tolist(), v.astype(np.float32)))
 
 
+def _native_raw(path, chrom, res, norm, max_dist, slab_bytes=4096, n_slabs=4):
+    """the same records through the RAW stream (mst_hic_rawstream_*: the host only inflates and copies the rows) decoded by
+    the NumPy restatement of the device kernel (tests/hic_rows_numpy.py) -- versions 7-9"""
+    from hic_rows_numpy import decode_slab
+    from mustache_amd.hicfile import HicFile, HicRawStream
+    mem = np.zeros(n_slabs * slab_bytes + 16, np.uint8)
+    base0 = (-mem.ctypes.data) % 16
+    out = []
+    with HicFile(path) as h:
+        st = HicRawStream(h, chrom, res, norm, max_dist, mem.ctypes.data + base0, n_slabs, slab_bytes, threads=2)
+        nv, _ = st.info()
+        while True:
+            r = st.next(50)
+            if r is None:
+                continue
+            if r is False:
+                break
+            slab, nbytes, rows = r
+            base = base0 + slab * slab_bytes
+            x, y, v = decode_slab(mem[base:base + nbytes].copy(), mem[base + slab_bytes - 16 * rows:base + slab_bytes].copy(), nv,
+                                  max_dist)
+            out += list(zip(x.tolist(), y.tolist(), v))
+            st.release(slab)
+        st.close()
+    return sorted(out)
+
+
 def _same(a, b):
     assert len(a) == len(b), (len(a), len(b))
     for (ax, ay, av), (bx, by, bv) in zip(a, b):
@@ -71,6 +98,7 @@ def test_everything_the_writer_emits_decodes_identically_in_both_readers(tmp_pat
     assert py.version == version and [nm for nm, _ in py.chromosomes] == ["All", "chr1", "chrX"] and py.resolutions == [res]
     for norm_name, max_dist in (("NONE", -1), ("KR", -1), ("KR", 120), ("VC", 40)):
         _same(_filtered(py.records("chr1", res, norm_name), max_dist), _native(p, "chr1", res, norm_name, max_dist))
+        _same(_native_raw(p, "chr1", res, norm_name, max_dist), _native(p, "chr1", res, norm_name, max_dist))
     assert len(_native(p, "chr1", res, "KR", -1)) > 5000
 
 
@@ -197,6 +225,12 @@ def test_hand_assembled_corner_cases_decode_identically_in_both_readers(tmp_path
     # these hand-numbered blocks do not sit where their numbers say -- block selection is covered by the writer test above)
     for norm_name in ("NONE", "KR"):
         _same(_filtered(py.records("c", res, norm_name), -1), _native(p, "c", res, norm_name, -1))
+        if version >= 7:          # ... and through the raw rows (every corner case above reaches the device decoder's restatement)
+            _same(_native_raw(p, "c", res, norm_name, -1), _native(p, "c", res, norm_name, -1))
+    if version == 6:              # plain records have no rows: the raw stream refuses them, the caller uses the host decoder
+        from mustache_amd.hicfile import HicError
+        with pytest.raises(HicError, match="plain records"):
+            _native_raw(p, "c", res, "NONE", -1)
     assert len(_native(p, "c", res, "NONE", -1)) >= (3 if version == 6 else 18)
     # the packed form agrees with the classic one on the same file
     from mustache_amd.hicfile import HicFile, read_intra_packed

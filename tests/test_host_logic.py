@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.exported_symbols())
-    assert lib.mst_abi_version() == _lib.MST_ABI_VERSION == 2
+    assert lib.mst_abi_version() == _lib.MST_ABI_VERSION == 3
 
 
 def test_level_table_matches_oracle():

@@ -151,3 +151,45 @@ def test_all_gather_packed_three_ranks_uint16_and_int32():
             assert [p[3] for p in parts] == [1000, 0, 2477]
             for (px, pd, pv, cnt), (ox, od, ov) in zip(parts, own):
                 assert np.array_equal(px, ox) and np.array_equal(pd, od) and np.array_equal(pv, ov)
+
+
+def _raw_worker(rank, ws, port, q):
+    import torch
+    import torch.distributed as dist
+    from mustache_amd.sharding import all_gather_raw
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    rng = np.random.default_rng(300 + rank)
+    parts = []
+    for k in range([3, 0, 2][rank]):                 # slabs per rank: unequal, one rank without any
+        rows = int(rng.integers(1, 40))
+        nbytes = 2 * int(rng.integers(1, 3000))      # even, not a multiple of 16 in general
+        parts.append((torch.from_numpy(rng.integers(0, 256, nbytes).astype(np.uint8)),
+                      torch.from_numpy(rng.integers(0, 256, 16 * rows).astype(np.uint8)), rows))
+    me, got = all_gather_raw(parts, torch.device("cpu"))
+    q.put((rank, me, [[(p.numpy().copy(), d.numpy().copy(), r) for p, d, r in lst] for lst in got]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_raw_three_ranks():
+    """sharding.all_gather_raw (the exchange of the raw `.hic` slabs, N > 1 ranks on one chromosome): every rank receives every
+    rank's slabs byte for byte -- payloads of odd sizes, directories, row counts; a rank without slabs takes part."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_raw_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(3)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    own = [r[2][r[0]] for r in res]
+    assert [len(o) for o in own] == [3, 0, 2]
+    for rank, me, got in res:
+        assert me == rank and [len(g) for g in got] == [3, 0, 2]
+        for r in range(3):
+            for (gp, gd, gr), (op, od, orr) in zip(got[r], own[r]):
+                assert gr == orr and np.array_equal(gp, op) and np.array_equal(gd, od)

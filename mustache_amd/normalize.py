@@ -237,8 +237,13 @@ def _read_hic_raw_to_band(hic, chrom, res, norm, dpx, chrom_size_bp, device, par
     pc = PackedContacts(None, None, None, ymax1, res, part=part[0], n_parts=part[1], blocks_total=st.blocks_total,
                         blocks_mine=st.blocks_mine, count=kept)
     pc.device_band, pc.band_stats, pc.raw_parts, pc.raw_ctx = band, stats, parts if keep else None, ctx
-    pc.raw_ctx["reread"] = lambda: read_hic_stream_to_device(hic, chrom, res, norm, dpx, chrom_size_bp, device, part=(0, 1),
-                                                             threads=threads, slab_records=slab_records, raw=False)
+
+    def reread():             # the whole chromosome through the host decoder, from a handle of its own (the caller's may be closed)
+        from .hicfile import HicFile
+        with HicFile(hic.path) as h2:
+            return read_hic_stream_to_device(h2, chrom, res, norm, dpx, chrom_size_bp, device, part=(0, 1), threads=threads,
+                                             slab_records=slab_records, raw=False)
+    pc.raw_ctx["reread"] = reread
     pc.read_s = time.time() - t0
     return pc
 

@@ -1337,7 +1337,15 @@ struct mst_hic_rawstream {
             pay = 0;
             rows = 0;
         }
-        // one row: `count` records of `rec` bytes at p (columns + counts, or counts alone for a dense grid's row)
+        // directory entry of a row whose records already lie in this slab at byte `off`
+        void list_row(int64_t off, int64_t count, int64_t y, int32_t x_off, uint32_t flags) {
+            if (y < INT32_MIN || y > INT32_MAX) throw FormatError{"bin index does not fit 32 bits"};
+            if (count >= ((int64_t)1 << 28)) throw FormatError{"a row holds more records than a slab"};
+            mst_hic_row e{(uint32_t)off, (int32_t)y, x_off, (uint32_t)count | flags};
+            memcpy(m + s->slab_bytes - 16 * ((int64_t)rows + 1), &e, 16);
+            ++rows;
+        }
+        // one row: `count` records of `rec` bytes at p (columns + counts, or counts alone for a dense grid's row), copied in
         void put_row(const uint8_t *p, int64_t count, int64_t rec, int64_t y, int32_t x_off, uint32_t flags) {
             if (count <= 0) return;
             if (y < INT32_MIN || y > INT32_MAX) throw FormatError{"bin index does not fit 32 bits"};
@@ -1355,8 +1363,9 @@ struct mst_hic_rawstream {
         }
     };
 
-    // header + rows of one inflated block (the walk of decode_records, without touching a record)
-    void put_block(Worker &w, const uint8_t *data, size_t n) {
+    // header + rows of one inflated block (the walk of decode_records, without touching a record): row(p, count, rec, y, x_off, flags)
+    template <class Row>
+    void walk_block(const uint8_t *data, size_t n, Row row) {
         Cursor c(data, n);
         if (c.get<int32_t>() < 0) throw FormatError{"negative record count in a block"};
         const int32_t x_off = c.get<int32_t>();
@@ -1378,7 +1387,7 @@ struct mst_hic_rawstream {
                 if (cols < 0) cols = 0;                           // the decoder's loop runs zero times as well
                 const uint8_t *p = c.p;
                 c.skip((uint64_t)cols * (uint64_t)rec);
-                w.put_row(p, cols, rec, (int64_t)y_off + y, x_off, fc | (short_x ? 0u : MST_HIC_ROW_INT_COLUMNS));
+                if (cols > 0) row(p, (int64_t)cols, rec, (int64_t)y_off + y, x_off, fc | (short_x ? 0u : MST_HIC_ROW_INT_COLUMNS));
             }
         } else if (type == 2) {
             const int32_t n_pts = c.get<int32_t>();
@@ -1389,16 +1398,63 @@ struct mst_hic_rawstream {
                 const int64_t cnt = n_pts - i < wd ? n_pts - i : wd;
                 const uint8_t *p = c.p;
                 c.skip((uint64_t)cnt * (uint64_t)rec);
-                w.put_row(p, cnt, rec, (int64_t)y_off + i / wd, x_off, fc | MST_HIC_ROW_DENSE);
+                row(p, cnt, rec, (int64_t)y_off + i / wd, x_off, fc | MST_HIC_ROW_DENSE);
             }
         } else {
             throw FormatError{"unknown block type"};
         }
     }
 
+    // One block.  The usual case: the zlib stream is inflated STRAIGHT INTO the worker's slab (no staging buffer, no copy) when
+    // the room left is at least `ratio` times the compressed size -- the largest expansion this worker has seen so far, with a
+    // margin -- and its rows are then listed where they lie (the block's 14-18 header bytes and 4-8 bytes per row travel along
+    // unused).  A block that does not fit what is left opens the next slab; one that does not fit an empty slab goes through the
+    // staging buffer and is cut at row boundaries.
+    void one_block(Worker &w, const BlockRef *b, std::vector<uint8_t> &buf, std::vector<uint8_t> &pad, double &ratio) {
+        const uint8_t *comp = h->map + b->pos;
+        const size_t comp_size = (size_t)b->size, past = h->size - (size_t)b->pos - comp_size;
+        if (!use_zlib() && past >= mst_inflate::kSlack) {
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                if (w.cur < 0) w.next_slab();
+                const int64_t at = (w.pay + 15) / 16 * 16;
+                // the directory grows down from the slab's end: room for this block's rows is kept free (checked after the walk)
+                const int64_t room = slab_bytes - at - 16 * ((int64_t)w.rows + 1) - (int64_t)mst_inflate::kSlack;
+                if (room >= (int64_t)((double)comp_size * ratio) + 64) {
+                    size_t n_out = 0;
+                    const int rc = mst_inflate::inflate_zlib(comp, comp_size, w.m + at, (size_t)room, &n_out);
+                    if (rc == mst_inflate::kOk) {
+                        const double seen = (double)n_out / (double)(comp_size ? comp_size : 1) * 1.05;
+                        if (seen > ratio) ratio = seen;
+                        int64_t nrows = 0;
+                        walk_block(w.m + at, n_out, [&](const uint8_t *, int64_t, int64_t, int64_t, int32_t, uint32_t) { ++nrows; });
+                        if (at + (int64_t)n_out + 16 * ((int64_t)w.rows + nrows) <= slab_bytes) {
+                            walk_block(w.m + at, n_out, [&](const uint8_t *p, int64_t count, int64_t, int64_t y, int32_t x_off, uint32_t flags) {
+                                w.list_row((int64_t)(p - w.m), count, y, x_off, flags);
+                            });
+                            w.pay = at + (int64_t)n_out;
+                            w.pay += w.pay & 1;
+                            return;
+                        }
+                    } else if (rc != mst_inflate::kOutputFull) {
+                        throw FormatError{"zlib inflate failed"};
+                    } else if (ratio < 64.0) {
+                        ratio *= 2.0;                           // the estimate was too small: remember, and take a fresh slab
+                    }
+                }
+                if (w.rows == 0 && w.pay == 0) break;           // does not fit an EMPTY slab: staged below
+                w.next_slab();
+            }
+        }
+        const size_t n_out = inflate_block(comp, comp_size, past, buf, pad);
+        walk_block(buf.data(), n_out, [&](const uint8_t *p, int64_t count, int64_t rec, int64_t y, int32_t x_off, uint32_t flags) {
+            w.put_row(p, count, rec, y, x_off, flags);
+        });
+    }
+
     void work() {
         std::vector<uint8_t> buf, pad;
         Worker w{this};
+        double ratio = 2.0;
         try {
             for (;;) {
                 const size_t i = next.fetch_add(1);
@@ -1407,10 +1463,7 @@ struct mst_hic_rawstream {
                     std::lock_guard<std::mutex> lk(mu);
                     if (failed || cancelled) break;
                 }
-                const BlockRef *b = todo[i];
-                const size_t n_out = inflate_block(h->map + b->pos, (size_t)b->size, h->size - (size_t)b->pos - (size_t)b->size,
-                                                   buf, pad);
-                put_block(w, buf.data(), n_out);
+                one_block(w, todo[i], buf, pad, ratio);
             }
             w.publish();
         } catch (const Cancelled &) {

@@ -186,9 +186,16 @@ diag_stats_kernel(const double *__restrict__ band, int64_t n, double *__restrict
 // head (<= 15 samples) + whole aligned blocks + tail (<= 15 samples): ~150 additions instead of W = 2000, in an order
 // that depends only on the window's absolute position (deterministic, independent of how the diagonal is segmented),
 // and with the rounding behaviour of a two-level (blocked) summation.
+// Two instantiations: <16, true> (windows up to ~8400 bins: samples AND their squares staged, 16-sample blocks -- the form every
+// result so far was produced with) and <64, false> (windows up to 16384 bins, i.e. resolutions down to ~125 bp: samples only --
+// the square is formed where it is summed, the same product -- and 64-sample blocks, so that 1024 + 16384 samples and their
+// block sums fit the 160 KB of LDS).  Both stay far below 128 VGPRs: no scratch (the walking kernel's <1024, 16> form, which
+// served these windows until round 4, spilled 488 registers).
 constexpr int kSeg = 1024;
 constexpr int kBlk = 16;
+constexpr int kBlkWide = 64;
 
+template <int BLK, bool STAGE_SQ>
 __global__ void __launch_bounds__(kThreads)
 normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ band_out, int64_t n, int W,
                        const double *__restrict__ diag_stats) {
@@ -198,16 +205,17 @@ normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ 
     const int64_t seg0 = (int64_t)blockIdx.x * kSeg;
     if (seg0 >= L) return;
     const int left = W / 2;                 // np.convolve(..., 'same'): window = [i - W/2, i - W/2 + W - 1]
-    // tile element t <-> absolute position base + t; base is rounded DOWN to a multiple of kBlk so LDS blocks are the
+    // tile element t <-> absolute position base + t; base is rounded DOWN to a multiple of BLK so LDS blocks are the
     // absolute aligned blocks
     const int64_t first = seg0 - left;
-    const int64_t base = (first >= 0 ? first : first - (kBlk - 1)) / kBlk * kBlk;      // floor to multiple of kBlk
+    const int64_t base = (first >= 0 ? first : first - (BLK - 1)) / BLK * BLK;      // floor to multiple of BLK
     const int tile = (int)(seg0 + kSeg - 1 - left + W - base) + 1;                     // covers the last window's end
-    const int nblk = (tile + kBlk - 1) / kBlk;
-    double *val = lds, *sq = val + nblk * kBlk, *b1 = sq + nblk * kBlk, *b2 = b1 + nblk;
+    const int nblk = (tile + BLK - 1) / BLK;
+    double *val = lds, *sqa = val + nblk * BLK, *b1 = sqa + (STAGE_SQ ? nblk * BLK : 0), *b2 = b1 + nblk;
     int *bc = reinterpret_cast<int *>(b2 + nblk);
+    auto sq = [&](int t) { return STAGE_SQ ? sqa[t] : val[t] * val[t]; };       // vals ** 2  (:649)
     const double *row = band_in + (int64_t)d * n;
-    for (int t = threadIdx.x; t < nblk * kBlk; t += kThreads) {
+    for (int t = threadIdx.x; t < nblk * BLK; t += kThreads) {
         const int64_t i = base + t;
         double v = 0.0;
         if (i >= 0 && i < L) {
@@ -215,18 +223,18 @@ normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ 
             if (r != 0.0) v = r + 0.001;    // vals[x] = v + 0.001   (:635)
         }
         val[t] = v;
-        sq[t] = v * v;                      // vals ** 2             (:649)
+        if (STAGE_SQ) sqa[t] = v * v;
     }
     __syncthreads();
     for (int q = threadIdx.x; q < nblk; q += kThreads) {
         double s1 = 0.0, s2 = 0.0;
         int c = 0;
 #pragma unroll
-        for (int u = 0; u < kBlk; ++u) {
-            const double a = val[q * kBlk + u];
+        for (int u = 0; u < BLK; ++u) {
+            const double a = val[q * BLK + u];
             c += (a != 0.0) ? 1 : 0;
             s1 = s1 + a;
-            s2 = s2 + sq[q * kBlk + u];
+            s2 = s2 + sq(q * BLK + u);
         }
         b1[q] = s1;
         b2[q] = s2;
@@ -244,8 +252,8 @@ normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ 
         double z = 0.0;
         if (x != 0.0) {
             const int tb = ta + W;                       // exclusive end
-            const int A = (ta + kBlk - 1) / kBlk * kBlk; // first aligned block start >= ta
-            const int B = tb / kBlk * kBlk;              // last aligned block end <= tb
+            const int A = (ta + BLK - 1) / BLK * BLK; // first aligned block start >= ta
+            const int B = tb / BLK * BLK;              // last aligned block end <= tb
             double s1 = 0.0, s2 = 0.0;
             int c = 0;
             if (A <= B) {
@@ -254,11 +262,11 @@ normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ 
                     const double a = val[t];
                     c += (a != 0.0) ? 1 : 0;
                     h1 = h1 + a;
-                    h2 = h2 + sq[t];
+                    h2 = h2 + sq(t);
                 }
                 s1 = h1;
                 s2 = h2;
-                for (int q = A / kBlk; q < B / kBlk; ++q) {   // whole aligned blocks
+                for (int q = A / BLK; q < B / BLK; ++q) {   // whole aligned blocks
                     c += bc[q];
                     s1 = s1 + b1[q];
                     s2 = s2 + b2[q];
@@ -268,7 +276,7 @@ normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ 
                     const double a = val[t];
                     c += (a != 0.0) ? 1 : 0;
                     t1 = t1 + a;
-                    t2 = t2 + sq[t];
+                    t2 = t2 + sq(t);
                 }
                 s1 = s1 + t1;
                 s2 = s2 + t2;
@@ -277,7 +285,7 @@ normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ 
                     const double a = val[t];
                     c += (a != 0.0) ? 1 : 0;
                     s1 = s1 + a;
-                    s2 = s2 + sq[t];
+                    s2 = s2 + sq(t);
                 }
             }
             const double cnt = (double)c;
@@ -915,13 +923,9 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
     const int nd = dpx + 2;
     diag_stats_kernel<<<nd, kThreads, 0, s>>>(band_in, n, diag_stats);
     MST_LAUNCH_CHECK();
-    // walking kernel: windows up to 4096 bins at full speed; windows beyond what the blocked-sum kernel's LDS holds (~8400) run
-    // through the <1024, 16> instantiation (128-VGPR cap: it spills, it is slow, it is correct) so that resolutions down to
-    // ~125 bp work at all, as they do in the reference
-    const size_t blocked_nblk = (size_t)(kSeg + (window > 0 ? window : 0) + 2 * kBlk + kBlk - 1) / kBlk;
-    const size_t blocked_lds = sizeof(double) * (2 * blocked_nblk * kBlk + 2 * blocked_nblk) + sizeof(int) * blocked_nblk + 16;
-    const bool huge = local == 1 && blocked_lds > 160 * 1024 && window <= 1024 * 16;
-    if (local == 1 && window >= 2 && (window <= 512 * 8 || huge)) {
+    // walking kernel: windows up to 4096 bins at full speed; wider ones (resolutions below ~490 bp) go through the blocked-sum
+    // kernel further down
+    if (local == 1 && window >= 2 && window <= 512 * 8) {
         // default: the walking kernel -- one scan per sample, blocks of `window` samples along each diagonal
         const int nb = (int)((n + window - 1) / window);                  // output blocks per diagonal (covers [0, n))
         int run = (int)(((int64_t)nb * nd + 8191) / 8192);                // >= ~8 k workgroups when the band is large enough
@@ -938,8 +942,7 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
         else if (window <= 256 * 4) MST_WALK_CASE(256, 4)
         // (measured at W = 2000: <512, 4> 3.4 ms, <256, 8> 4.0 ms, <1024, 2> 5.8 ms)
         else if (window <= 512 * 4) MST_WALK_CASE(512, 4)
-        else if (window <= 512 * 8) MST_WALK_CASE(512, 8)
-        else MST_WALK_CASE(1024, 16)
+        else MST_WALK_CASE(512, 8)
 #undef MST_WALK_CASE
         MST_LAUNCH_CHECK();
         return MST_OK;
@@ -975,22 +978,33 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
     }
 #endif
     if (local) {
-        // wide windows: blocked-sum kernel.  LDS: 2 doubles per staged sample + 2 doubles and an int per 16-sample block,
-        // for up to SEG + W + 2*16 samples
-        const size_t nblk = (size_t)(kSeg + window + 2 * kBlk + kBlk - 1) / kBlk;
-        const size_t lds = sizeof(double) * (2 * nblk * kBlk + 2 * nblk) + sizeof(int) * nblk + 16;
-        if (window < 2 || lds > 160 * 1024)
+        // wide windows: blocked-sum kernel.  LDS: 2 doubles per staged sample + 2 doubles and an int per 16-sample block, for up to
+        // SEG + W + 2 * 16 samples; beyond ~8400 bins: 1 double per sample and 64-sample blocks (see the kernel)
+        auto lds_need = [&](size_t blk, size_t arrays) {
+            const size_t nblk = (size_t)(kSeg + window + 2 * blk + blk - 1) / blk;
+            return sizeof(double) * (arrays * nblk * blk + 2 * nblk) + sizeof(int) * nblk + 16;
+        };
+        const size_t lds = window < 2 ? 0 : lds_need(kBlk, 2), lds_wide = window < 2 ? 0 : lds_need(kBlkWide, 1);
+        const bool wide = lds > 160 * 1024;
+        if (window < 2 || (wide && lds_wide > 160 * 1024))
             return mst::fail(MST_E_ARG,
                              "mst_normalize_band: window of %d bins (= 2 Mb / resolution) is outside [2, 16384]: the sliding-window "
                              "normalisation supports resolutions down to ~125 bp",
                              window);
-        static unsigned long long lds_allowed = 0;      // per device (mst_common.h)
-        MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&normalize_local_kernel), 160 * 1024,
-                                       &lds_allowed));
         // rows are written for i < n - d only; clear the tails so the output band is fully defined
         MST_HIP(hipMemsetAsync(band_out, 0, sizeof(double) * (size_t)nd * n, s));
         dim3 grid((unsigned)((n + kSeg - 1) / kSeg), nd);
-        normalize_local_kernel<<<grid, kThreads, lds, s>>>(band_in, band_out, n, window, diag_stats);
+        if (wide) {
+            static unsigned long long lds_allowed_wide = 0;      // per device (mst_common.h)
+            MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&normalize_local_kernel<kBlkWide, false>), 160 * 1024,
+                                           &lds_allowed_wide));
+            normalize_local_kernel<kBlkWide, false><<<grid, kThreads, lds_wide, s>>>(band_in, band_out, n, window, diag_stats);
+        } else {
+            static unsigned long long lds_allowed = 0;
+            MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&normalize_local_kernel<kBlk, true>), 160 * 1024,
+                                           &lds_allowed));
+            normalize_local_kernel<kBlk, true><<<grid, kThreads, lds, s>>>(band_in, band_out, n, window, diag_stats);
+        }
     } else {
         const int dlimit = (int64_t)dpx < n ? dpx : (int)n;     // range(min(distance_in_px, n))   (:674-675)
         int64_t want = (n + kThreads - 1) / kThreads;

@@ -291,10 +291,15 @@ diff_dog_kernel(const double *__restrict__ band1, const double *__restrict__ ban
             diff_blur_dispatch<T>(lv->radius[o][0], ct, vb, taps, tid, vsrc, vdst, hsrc, g2);
         }
         {
+            // the pointer is laundered so that this blur's taps (up to 29 doubles = 58 scalar registers) are fetched AFTER the
+            // first blur has let go of its own -- hoisted above it, the two sets together spilled 64 scalar registers
+            // (the default tile, radii <= 8, has registers to spare and is left as it was)
+            const DiffLevels *lv3 = lv;
+            if constexpr (RMAX > 8) asm volatile("" : "+s"(lv3));
             double taps[RMAX + 1];
 #pragma unroll
-            for (int j = 0; j <= RMAX; ++j) taps[j] = lv->taps[o][1][j];
-            diff_blur_dispatch<T>(lv->radius[o][1], ct, vb, taps, tid, vsrc, vdst, hsrc, g3);
+            for (int j = 0; j <= RMAX; ++j) taps[j] = lv3->taps[o][1][j];
+            diff_blur_dispatch<T>(lv3->radius[o][1], ct, vb, taps, tid, vsrc, vdst, hsrc, g3);
         }
         double s1 = 0.0, s2 = 0.0;
         double *out = dog + (((size_t)o * B + b) * CH + gy) * CH + x0 + cg * K;
@@ -383,7 +388,7 @@ pair_pvalue_dog_kernel(const mst_found *__restrict__ found, uint32_t found_cap, 
 
 using DiffTile8 = Tile<32, 64, 8>;        // the reference's default octaves: G_2 / G_3 radii 4, 4 and 7, 8
 using DiffTile14 = Tile<32, 64, 14>;
-using DiffTile28 = Tile<32, 32, 28, 4, 1>;   // 256 threads x 4 pixels, like the sigma loop's wide tile
+using DiffTile28 = Tile<32, 64, 28, 4, 1, false, true>;   // 512 threads x 4 pixels, tight pitches: the sigma loop's wide tile
 
 template <class T>
 size_t diff_lds_bytes() { return sizeof(double) * (size_t)(T::CT_ELEMS + T::VB_ELEMS + 2 * T::NT); }

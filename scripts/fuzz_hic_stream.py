@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised check of the streamed `.hic` read (mst_hic_stream_*; CPU only): random files (versions 8-9, row-list / dense
+"""Randomised check of the streamed `.hic` reads (mst_hic_stream_* and, since round 5, the RAW form mst_hic_rawstream_* whose
+rows are decoded here by the NumPy restatement of the device kernel, tests/hic_rows_numpy.py; CPU only): random files (versions 8-9, row-list / dense
 blocks, short / long coordinates, integer / float counts, block sizes), random slab sizes from 2 records to larger than any
 block, random slab and thread counts, random part splits, a consumer that releases slabs late and out of order -- the records
 delivered must be exactly those of the one-shot packed read.  argv: cases [seed]"""
@@ -12,7 +13,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np                                                     # noqa: E402
 from hic_writer import write_hic                                       # noqa: E402
-from mustache_amd.hicfile import HicFile, HicStream, read_intra_packed  # noqa: E402
+from hic_rows_numpy import decode_slab                                 # noqa: E402
+from mustache_amd.hicfile import HicFile, HicRawStream, HicStream, read_intra_packed  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -80,8 +82,43 @@ for case in range(cases):
         o, ow = np.argsort(k, kind="stable"), np.argsort(key_w, kind="stable")
         ok = blocks == whole.blocks_total and len(k) == len(key_w) and np.array_equal(k[o], key_w[ow]) and \
             np.array_equal(v[o], whole.v[ow])
+        # the raw form: slabs of row payloads + directories (from 4 KB, i.e. blocks staged and cut at rows, to slabs that take
+        # whole blocks inflated in place), the same late / out-of-order releases
+        slab_bytes = 16 * int(rng.choice([256, 300, 1024, 4096, 65536]))
+        rmem = np.zeros(n_slabs * slab_bytes + 16, np.uint8)
+        base0 = (-rmem.ctypes.data) % 16
+        rk, rv, rblocks = [], [], 0
+        for part in range(n_parts):
+            st = HicRawStream(h, "chr1", res, "KR", dpx, rmem.ctypes.data + base0, n_slabs, slab_bytes, threads=threads,
+                              part=(part, n_parts))
+            nv, _ = st.info()
+            held = []
+            while True:
+                r = st.next(20)
+                if r is None:
+                    if held:
+                        st.release(held.pop(int(rng.integers(len(held)))))
+                    continue
+                if r is False:
+                    break
+                slab, nbytes, rows = r
+                base = base0 + slab * slab_bytes
+                gx, gy, gv = decode_slab(rmem[base:base + nbytes].copy(), rmem[base + slab_bytes - 16 * rows:base + slab_bytes].copy(),
+                                         nv, dpx)
+                rk.append(gx * (1 << 20) + (gy - gx))
+                rv.append(gv)
+                held.append(slab)
+                while len(held) > hold:
+                    st.release(held.pop(int(rng.integers(len(held)))))
+            st.close()
+            rblocks += st.blocks_mine
+        k = np.concatenate(rk) if rk else np.zeros(0, np.int64)
+        v = np.concatenate(rv) if rv else np.zeros(0, np.float32)
+        o = np.argsort(k, kind="stable")
+        ok = ok and rblocks == whole.blocks_total and len(k) == len(key_w) and np.array_equal(k[o], key_w[ow]) and \
+            np.array_equal(v[o], whole.v[ow])
     desc = dict(n=n, res=res, dpx=dpx, records=len(key_w), version=version, dense=dense, short=short_coords, floats=float_counts,
-                bbc=bbc, dist_bytes=dist_bytes, parts=n_parts, cap=cap, slabs=n_slabs, threads=threads, hold=hold)
+                bbc=bbc, dist_bytes=dist_bytes, parts=n_parts, cap=cap, slabs=n_slabs, threads=threads, hold=hold, raw_slab=slab_bytes)
     print("case %3d %s %s" % (case, "ok " if ok else "MISMATCH", desc), flush=True)
     bad += not ok
 print("done: %d cases, %d mismatches" % (cases, bad))

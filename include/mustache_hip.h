@@ -46,6 +46,9 @@ extern "C" {
                                * time and replayed afterwards -- one graph launch instead of ~16 runtime calls in front of the
                                * fused kernel (small launches are latency-bound).  Identical results; ignored on the legacy
                                * default stream (it cannot be captured) and by PROFILE builds. */
+#define MST_FLAG_NO_WAIT 16   /* mst_found_finish only: enqueue and return -- the caller queues more work behind it (the two-sample
+                               * path: pair p-values, BH, gathers), synchronises ONCE and then asks mst_found_summary_status */
+#define MST_BH_RETRY 0xFFFFFFFFu /* mst_bh_select_nowait: out_count of a block whose candidate subset exceeds 4096 records */
 #define MST_FLAG_FMA 2        /* OPT-IN relaxed arithmetic: fuse the multiply-add of each tap pair.  DoG values then differ
                                  from the reference's by ~1e-16 relative (instead of being bit-identical); default off */
 
@@ -136,8 +139,11 @@ int mst_found_pvalues(const mst_found *found, uint32_t found_cap, const uint32_t
  * lvl_host / pv_host (page-locked, same shapes; all three or none) they are copied to the host before the synchronisation, so a
  * caller whose pack_pitch (its guess of the largest count) is confirmed by the summary needs no second round trip.
  * flags: 0, or MST_FLAG_GRAPH (a call that repeats with every argument unchanged is replayed as one hipGraph: for small,
- * latency-bound launches; it slows large pipelined ones).  Same error returns as mst_found_pvalues. */
+ * latency-bound launches; it slows large pipelined ones), and / or MST_FLAG_NO_WAIT (no synchronisation, no status: the call
+ * returns once everything is queued; after the caller's own synchronisation of `stream`, mst_found_summary_status(summary_host,
+ * found_cap) gives the status this call would have returned).  Same error returns as mst_found_pvalues. */
 uint64_t mst_found_summary_bytes(int32_t B);
+int mst_found_summary_status(const void *summary_host, uint32_t found_cap);
 int mst_found_finish(const mst_found *found, uint32_t found_cap, const uint32_t *found_count, const uint32_t *nz_count,
                      const double *level_stats, int32_t B, int32_t n_tested, double *pval, double *fit, uint32_t pack_pitch,
                      int32_t *pix_out, uint8_t *lvl_out, double *pv_out, void *scratch_dev, void *summary_host,
@@ -167,6 +173,16 @@ int mst_bh_select_records(const mst_found *found, const double *pval, const uint
                           uint32_t found_cap, double threshold, uint32_t out_cap, uint32_t *out_pixel, uint32_t *out_level,
                           double *out_q, uint32_t *out_index, uint32_t *out_count, void *workspace,
                           uint64_t workspace_bytes, void *stream);
+
+/* mst_bh_select_records (out_index may be NULL) WITHOUT the host synchronisation: the in-LDS sort is launched for every block,
+ * and a block whose candidate subset exceeds 4096 records (threshold near 1) gets out_count[b] = MST_BH_RETRY instead of a
+ * count -- the caller, once it has synchronised for out_count anyway, then runs mst_bh_select / mst_bh_fdr + mst_select_below
+ * for the launch.  Lets a latency-bound caller (the two-sample path on a few blocks) queue everything behind the fused
+ * kernels and wait once. */
+int mst_bh_select_nowait(const mst_found *found, const double *pval, const uint32_t *found_count, int32_t B,
+                         uint32_t found_cap, double threshold, uint32_t out_cap, uint32_t *out_pixel, uint32_t *out_level,
+                         double *out_q, uint32_t *out_index, uint32_t *out_count, void *workspace,
+                         uint64_t workspace_bytes, void *stream);
 
 /* mustache.py:789-797 (selection of the pixels with o < pt) on the device: the found records of each block whose q-value
  * is below `threshold`, compacted into out_pixel / out_level / out_q [B][out_cap] (order within a block unspecified).
@@ -248,8 +264,8 @@ int mst_band_to_coo(const double *band, const int64_t *x, const int64_t *y, int6
 /* normalize_sparse (mustache.py:622-686) on the band, out of place (band_in != band_out).
  *   local != 0 : branch A (:628-669), taken by the caller when (n - dpx) * res > 2e6; `window` = int(2e6 / res).
  *                (local == 1: the library picks the kernel -- the walking kernel (blocks of `window` samples along each
- *                diagonal, one scan per sample) for windows up to 4096, blocked sums up to ~8400, a slow spilling form
- *                of the walking kernel up to 16384, an error beyond.  PROFILE builds of the library additionally accept
+ *                diagonal, one scan per sample) for windows up to 4096, blocked sums (16-sample blocks) up to ~8400 and
+ *                (64-sample blocks, samples only in LDS) up to 16384, an error beyond.  PROFILE builds additionally accept
  *                local == 2 (blocked sums whatever the window) and local == 3 (round 1's segment kernel) as cross-checks;
  *                the product library refuses them.)
  *                Per diagonal d <= dpx+1: vals = v + 0.001; counts / sum / sum of squares over the zero-padded

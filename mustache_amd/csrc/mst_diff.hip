@@ -519,7 +519,8 @@ pair_gather_kernel(const mst_found *__restrict__ found, uint32_t found_cap, cons
                    double *__restrict__ out_pair, double *__restrict__ out_value, double *__restrict__ out_other) {
     __shared__ double hit;
     const int fb = blockIdx.y, slot = blockIdx.x;
-    const uint32_t nsel = sel_count[fb] < out_cap ? sel_count[fb] : out_cap;
+    const uint32_t sc = sel_count[fb];                  // MST_BH_RETRY: the selection of this block has not happened yet
+    const uint32_t nsel = sc == MST_BH_RETRY ? 0u : (sc < out_cap ? sc : out_cap);
     if ((uint32_t)slot >= nsel) return;
     const size_t o = (size_t)fb * out_cap + slot;
     const uint32_t idx = sel_index[o], pixel = sel_pixel[o];

@@ -289,6 +289,10 @@ bh_select_lds_kernel(const double *__restrict__ keys, const uint32_t *__restrict
         if (t == 0) out_count[b] = 0;
         return;
     }
+    if (k > p_max) {                                     // only the no-wait form launches without knowing the subset sizes
+        if (t == 0) out_count[b] = MST_BH_RETRY;
+        return;
+    }
     uint32_t P = 2;
     while (P < k) P <<= 1;
     for (uint32_t i = t; i < P; i += kBH) {
@@ -358,7 +362,8 @@ constexpr size_t sort_lds_bytes(uint32_t p_max) {
 namespace {
 int bh_select_impl(const mst_found *found, const double *pval, const uint32_t *count, int32_t B, uint32_t cap,
                    double threshold, uint32_t out_cap, uint32_t *out_pixel, uint32_t *out_level, double *out_q,
-                   uint32_t *out_count, uint32_t *out_index, void *workspace, uint64_t workspace_bytes, void *stream) {
+                   uint32_t *out_count, uint32_t *out_index, void *workspace, uint64_t workspace_bytes, void *stream,
+                   bool nowait = false) {
     if (!found || !pval || !count || !out_pixel || !out_level || !out_q || !out_count || !workspace || B <= 0 ||
         B > 65535 || cap == 0 || out_cap == 0 || (size_t)B * cap > 0x7FFFFFFFull)
         return mst::fail(MST_E_ARG, "mst_bh_select: bad argument (B * cap must fit in int32)");
@@ -397,6 +402,15 @@ int bh_select_impl(const mst_found *found, const double *pval, const uint32_t *c
     compact_below_kernel<<<dim3(gx, B), 256, 0, s>>>(pval, count, cap, thr, keys_in, idx_in, k_sub);
     MST_LAUNCH_CHECK();
     // 3. sort + BH + selection: in LDS when every block's subset fits (the normal case), else the segmented radix sort
+    if (nowait) {
+        // no look at the subset sizes: the in-LDS sort sized for the largest subset it takes; a block with a larger one
+        // reports MST_BH_RETRY instead of a count
+        bh_select_lds_kernel<<<B, kBH, sort_lds_bytes(kSortMax), s>>>(keys_in, idx_in, k_sub, count, cap, found, threshold,
+                                                                     out_cap, out_pixel, out_level, out_q, out_count, out_index,
+                                                                     (uint32_t)kSortMax);
+        MST_LAUNCH_CHECK();
+        return MST_OK;
+    }
     std::vector<uint32_t> k_host((size_t)B);
     MST_HIP(hipMemcpyAsync(k_host.data(), k_sub, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
     MST_HIP(hipStreamSynchronize(s));
@@ -437,6 +451,14 @@ extern "C" int mst_bh_select_records(const mst_found *found, const double *pval,
     if (!out_index) return mst::fail(MST_E_ARG, "mst_bh_select_records: bad argument");
     return bh_select_impl(found, pval, count, B, cap, threshold, out_cap, out_pixel, out_level, out_q, out_count, out_index,
                           workspace, workspace_bytes, stream);
+}
+
+extern "C" int mst_bh_select_nowait(const mst_found *found, const double *pval, const uint32_t *count, int32_t B,
+                                    uint32_t cap, double threshold, uint32_t out_cap, uint32_t *out_pixel,
+                                    uint32_t *out_level, double *out_q, uint32_t *out_index, uint32_t *out_count,
+                                    void *workspace, uint64_t workspace_bytes, void *stream) {
+    return bh_select_impl(found, pval, count, B, cap, threshold, out_cap, out_pixel, out_level, out_q, out_count, out_index,
+                          workspace, workspace_bytes, stream, true);
 }
 
 extern "C" int mst_select_below(const mst_found *found, const double *q, const uint32_t *found_count, int32_t B,

@@ -403,6 +403,15 @@ extern "C" int mst_found_pvalues(const mst_found *found, uint32_t found_cap, con
     return MST_OK;
 }
 
+extern "C" int mst_found_summary_status(const void *summary_host, uint32_t found_cap) {
+    if (!summary_host) return mst::fail(MST_E_ARG, "mst_found_summary_status: bad argument");
+    int dflags = 0;
+    memcpy(&dflags, summary_host, sizeof(int));
+    if (dflags & 1) return mst::fail(MST_E_OVERFLOW, "found-pixel capacity %u exceeded in at least one block", found_cap);
+    if (dflags & 2) return mst::fail(MST_E_NONFINITE, "non-finite DoG statistics (input block holds NaN/inf)");
+    return MST_OK;
+}
+
 extern "C" uint64_t mst_found_summary_bytes(int32_t B) {
     if (B <= 0) return 0;
     return 16 + 8 * (uint64_t)((B + 1) / 2) * 2 + sizeof(double) * 2 * MST_MAX_TESTED * (uint64_t)B;
@@ -542,6 +551,7 @@ extern "C" int mst_found_finish(const mst_found *found, uint32_t found_cap, cons
         const int erc = enqueue();
         if (erc != MST_OK) return erc;
     }
+    if (flags & MST_FLAG_NO_WAIT) return MST_OK;             // the caller synchronises and asks mst_found_summary_status
     MST_HIP(hipStreamSynchronize(s));
     int dflags = 0;
     memcpy(&dflags, summary_host, sizeof(int));

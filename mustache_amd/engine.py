@@ -487,6 +487,14 @@ class ScaleSpaceEngine:
             buf = self._pin[("summary", B)] = torch.empty(need, dtype=torch.uint8, pin_memory=True)
         return buf
 
+    @staticmethod
+    def _parse_summary(summ, B):
+        """mst_found_finish's summary block (include/mustache_hip.h) -> (found counts, tested-pixel counts, fits) host arrays"""
+        h = summ.numpy()
+        cw = 8 * ((B + 1) // 2)
+        return (h[16:16 + 4 * B].view(np.uint32).astype(np.int64), h[16 + cw:16 + cw + 4 * B].view(np.uint32).astype(np.int64),
+                h[16 + 2 * cw:16 + 2 * cw + 16 * _lib.MST_MAX_TESTED * B].view(np.float64).reshape(B, _lib.MST_MAX_TESTED, 2).copy())
+
     def _ss_finish(self, st, packed=False, relaunch=True):
         """p-values of the found pixels (ONE synchronisation of the launch stream: mst_found_finish brings the overflow flag, the
         record counts, the tested-pixel counts and the fits back in the same round trip); a record-capacity overflow re-runs the
@@ -531,12 +539,7 @@ class ScaleSpaceEngine:
                     st = self._ss_launch(c, nz, nz_count, skip_empty, cap, timing, fma, band_src, reuse=st.get("reuse"))
         if st["ev"] is not None:
             st["args"][4].append(st["ev"])      # mst_found_finish synchronised the stream: the events are complete
-        h = summ.numpy()
-        cw = 8 * ((B + 1) // 2)
-        st["count_h"] = h[16:16 + 4 * B].view(np.uint32).astype(np.int64)
-        st["nz_h"] = h[16 + cw:16 + cw + 4 * B].view(np.uint32).astype(np.int64)
-        st["fit_h"] = h[16 + 2 * cw:16 + 2 * cw + 16 * _lib.MST_MAX_TESTED * B].view(np.float64).reshape(
-            B, _lib.MST_MAX_TESTED, 2).copy()
+        st["count_h"], st["nz_h"], st["fit_h"] = self._parse_summary(summ, B)
         st["prefetched"] = None
         if packed:
             mx = int(st["count_h"].max(initial=0))
@@ -872,7 +875,17 @@ class ScaleSpaceEngine:
         ws_bytes = self._ws_bytes.get((P, CH))
         if ws_bytes is None:
             ws_bytes = self._ws_bytes[(P, CH)] = int(self.lib.mst_scale_space_workspace_bytes(P, CH, lv))
-        with torch.cuda.device(self.device):
+        # A SMALL call (its buffers are kept between calls, _carve) repeats with identical arguments when the caller repeats it: the
+        # two fused launches are then replayed as hipGraphs (MST_FLAG_GRAPH: uploads, counter zeroing, kernel, reduction in one
+        # launch each, no dispatch gaps -- ~40 us of idle device before each kernel otherwise).  A graph cannot be captured on the
+        # legacy default stream: such a call runs on the first side stream.
+        small = 2 * P * cap * 24 + 2 * ws_bytes < (200 << 20)
+        cur = torch.cuda.current_stream(self.device)
+        side = None
+        if small and cur.cuda_stream == 0:
+            side = device_streams(self.device)[0]
+            side.wait_stream(cur)                           # the bands were produced on the caller's stream
+        with torch.cuda.device(self.device), torch.cuda.stream(side if side is not None else cur):
             dog = None
             while True:
                 # ONE set of record buffers for both samples (sample 1 in rows [0, P), sample 2 in [P, 2P)): the two fused
@@ -886,7 +899,8 @@ class ScaleSpaceEngine:
                 for k, (bd, ws) in enumerate(zip(bands, (ws1, ws2))):
                     sl = slice(k * P, (k + 1) * P)
                     self._ss_launch(None, None, nzc[sl], skip_empty, cap, None, False, (bd, int(n), int(dpx), starts_i, int(CH)),
-                                    out=dict(ws=ws, stats=stats[sl], fit=fit[sl], count=count[sl], found=found[sl], pval=pval[sl]))
+                                    out=dict(ws=ws, stats=stats[sl], fit=fit[sl], count=count[sl], found=found[sl], pval=pval[sl]),
+                                    graph=small)
                 if dog is None:
                     # the difference kernel needs the bands only: queued behind the sigma loops, before anything is waited for
                     dog = torch.empty((n_oct, P, CH, CH), dtype=torch.float64, device=self.device)
@@ -899,6 +913,14 @@ class ScaleSpaceEngine:
                 st = dict(args=(None, None, nzc, skip_empty, None, False, None), B=2 * P, CH=CH, found_cap=cap, stats=stats,
                           fit=fit, count=count, found=found, pval=pval, ev=None, reuse=None, graph=False)
                 try:
+                    if select_below is not None:
+                        # the per-chromosome driver's form: everything behind the kernels is queued at once and waited for ONCE
+                        done = self._pairs_one_wait(st, P, dog, nfit, n_oct, tpo, float(select_below))
+                        if done is not None:
+                            recs, fits, nz_h, norm_fit = done
+                            batch = PairBandBatch(self, bands, n, dpx, starts, CH, nz_h, recs, fits)
+                            batch.norm_fit = norm_fit
+                            return batch
                     st = self._ss_finish(st, relaunch=False)
                     break
                 except _lib.MstOverflow:        # rare: a block with an unusually dense set of local maxima -- both samples again
@@ -922,6 +944,64 @@ class ScaleSpaceEngine:
         batch = PairBandBatch(self, bands, n, dpx, starts, CH, st["nz_h"], recs, fits)
         batch.norm_fit = norm_fit
         return batch
+
+    def _pairs_one_wait(self, st, P, dog, nfit, n_oct, tpo, pt):
+        """Behind the two sigma loops and the difference kernel of a two-sample launch: p-values (mst_found_finish, no wait), pair
+        p-values, BH + selection q < pt (mst_bh_select_nowait), the differential test's look-ups for the selected records
+        (mst_pair_gather) and the downloads -- all queued back to back, ONE synchronisation, then the checks that used to cost a
+        round trip each (record capacity: MstOverflow to the caller; selection capacity / oversized BH subset: None, the caller
+        takes the step-by-step path).  A call on six block pairs of 2000 x 2000 is 1.4 ms of kernels: three more waits of
+        ~45 us each were 10 % of it.  Returns (records, fits, tested-pixel counts, norm.fit) or None."""
+        B, cap, CH = st["B"], st["found_cap"], st["CH"]
+        found, pval, count, fit, stats, nzc = st["found"], st["pval"], st["count"], st["fit"], st["stats"], st["args"][2]
+        nt = self.levels.n_tested
+        sel = self._pair_sel_cap = getattr(self, "_pair_sel_cap", 256)
+        ws_bytes = int(self.lib.mst_bh_workspace_bytes(B, cap))
+        if ws_bytes == 0:
+            return None
+        summ = self._summary_pin(B)
+        scratch, ppair, pix, lvl, idx, qs, n_sel, g, ws = self._carve(
+            (summ.numel(), torch.uint8, (summ.numel(),)), (B * cap * 8, torch.float64, (B, cap)), (B * sel * 4, torch.int32, (B, sel)),
+            (B * sel * 4, torch.int32, (B, sel)), (B * sel * 4, torch.int32, (B, sel)), (B * sel * 8, torch.float64, (B, sel)),
+            (B * 4, torch.int32, (B,)), (3 * B * sel * 8, torch.float64, (3, B, sel)), (ws_bytes, torch.uint8, (ws_bytes,)),
+            reuse=("pairs-tail", 0))
+        none3 = (None, None, None)
+        _lib.check(self.lib.mst_found_finish(_ptr(found), cap, _ptr(count), _ptr(nzc), _ptr(stats), B, nt, _ptr(pval), _ptr(fit), 0,
+                                             *none3, _ptr(scratch), ctypes.c_void_p(summ.data_ptr()), *none3, 16, _stream()))
+        for off in (0, P):
+            _lib.check(self.lib.mst_pair_pvalues_dog(_ptr(found), cap, _ptr(count), _ptr(dog), _ptr(nfit), P, CH, n_oct, tpo, off,
+                                                     _ptr(ppair), _stream()))
+        _lib.check(self.lib.mst_bh_select_nowait(_ptr(found), _ptr(pval), _ptr(count), B, cap, pt, sel, _ptr(pix), _ptr(lvl), _ptr(qs),
+                                                 _ptr(idx), _ptr(n_sel), _ptr(ws), ws_bytes, _stream()))
+        _lib.check(self.lib.mst_pair_gather(_ptr(found), cap, _ptr(count), _ptr(ppair), int(P), _ptr(idx), _ptr(pix), _ptr(n_sel), sel,
+                                            sel, _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _stream()))
+        self._pin_flip ^= 1
+        host = [self._pinned(k, tuple(t.shape), t.dtype) for k, t in (("pw_n", n_sel), ("pw_pix", pix), ("pw_lvl", lvl), ("pw_q", qs),
+                                                                      ("pw_g", g), ("pw_nfit", nfit))]
+        for hbuf, t in zip(host, (n_sel, pix, lvl, qs, g, nfit)):
+            hbuf.copy_(t, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        _lib.check(self.lib.mst_found_summary_status(ctypes.c_void_p(summ.data_ptr()), cap))       # MstOverflow: relaunch, larger lists
+        n_h = host[0].numpy().view(np.uint32).astype(np.int64)
+        if (n_h == 0xFFFFFFFF).any() or n_h.max(initial=0) > sel:
+            if not (n_h == 0xFFFFFFFF).any():
+                self._pair_sel_cap = int(n_h.max()) * 2          # room for every selected record from the next call on
+            return None
+        _, nz_h, fit_h = self._parse_summary(summ, B)
+        pix_h, lvl_h, q_h, g_h = host[1].numpy().view(np.uint32), host[2].numpy().view(np.uint32), host[3].numpy(), host[4].numpy()
+        # the kernel appends in arbitrary order: ONE sort by (block, pixel) over all selected records (pixels are unique inside a
+        # block), then every block's arrays are slices of the sorted ones
+        live = np.arange(sel)[None, :] < n_h[:, None]
+        bb, ss = np.nonzero(live)
+        order = np.argsort((bb.astype(np.int64) << 32) | pix_h[bb, ss], kind="stable")
+        bb, ss = bb[order], ss[order]
+        cols = {"pixel": pix_h[bb, ss], "level": lvl_h[bb, ss], "q": q_h[bb, ss], "pair": g_h[0][bb, ss], "value": g_h[1][bb, ss],
+                "v_other": g_h[2][bb, ss]}
+        ends = np.cumsum(n_h)
+        fit_c = fit_h[:, :nt, :].copy()
+        recs = [{k: v[e - m:e] for k, v in cols.items()} for e, m in zip(ends.tolist(), n_h.tolist())]
+        fits = [(fit_c[b, :, 0], fit_c[b, :, 1]) for b in range(B)]
+        return recs, fits, nz_h, host[5].numpy().copy()
 
     def run_band_pairs_overlapped(self, bands, n, dpx, groups, CH, skip_empty=True, select_below=None):
         """run_band_pairs over several groups of block pairs with the device work of group i + 1 queued BEFORE the results of

@@ -516,6 +516,7 @@ def main():
                 "band_skip": {"value": round(w.total_mpix / (dt_ns / hs), 1), "unit": "Mpix/s", "kernel_ms_per_step": round(kns, 3),
                               "roofline": {"bound": "fp64_valu", "achieved": round(tf_ns, 3), "peak": PEAK_TF, "unit": "TFLOP/s",
                                            "frac": round(tf_ns / PEAK_TF, 4)}},
+                "work_items_per_launch": {"dense": work_items(w, False, share=False)[3], "band_skip": work_items(w, True, share=False)[3]},
                 "note": "MST_FLAG_NO_SHARE: every workgroup's flops are algorithmic flops of one block -- the kernel's own efficiency"}
     tile_sharing = {"speedup": round(value / no_share["value"], 4), "kernel_speedup": round(kn / (k_ms * launches_per_step), 4),
                     "band_skip_speedup": round(band_skip["value"] / no_share["band_skip"]["value"], 4),

@@ -417,16 +417,12 @@ int diff_levels(const mst_levels *lv, DiffLevels *out, int *max_radius) {
     return MST_OK;
 }
 
+// tiles (no ring here: a tile owns all its RGR x RGC pixels) that can reach the band, row-major, and the inverse map:
+// list[0 .. m) = tile numbers, list[nt + t] = slot of tile t or -1.  Returns m.
 template <class T>
-int diff_dog_launch(const double *band1, const double *band2, int64_t n, int dpx, const int64_t *d_starts, int CH, int B,
-                    const DiffLevels *d_lv, int n_oct, double *dog, double *partial, int32_t *d_tiles, uint32_t *mask_count,
-                    double *fit, hipStream_t s) {
-    static unsigned long long lds_allowed = 0;
-    MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&diff_dog_kernel<T>), (int)diff_lds_bytes<T>(),
-                                   &lds_allowed));
+int diff_tile_list(int CH, int dpx, int32_t *list) {
     const int tx = (CH + T::RGC - 1) / T::RGC, nt = diff_tiles<T>(CH);
-    // tiles (no ring here: a tile owns all its RGR x RGC pixels) that can reach the band, row-major; and the inverse map
-    std::vector<int32_t> list(2 * (size_t)nt, -1);
+    for (int i = 0; i < 2 * nt; ++i) list[i] = -1;
     int m = 0;
     for (int t = 0; t < nt; ++t) {
         const int y0 = (t / tx) * T::RGR, x0 = (t % tx) * T::RGC;
@@ -437,7 +433,17 @@ int diff_dog_launch(const double *band1, const double *band2, int64_t n, int dpx
             list[(size_t)m++] = t;
         }
     }
-    MST_HIP(mst::upload_small(d_tiles, list.data(), sizeof(int32_t) * 2 * (size_t)nt, s));
+    return m;
+}
+
+template <class T>
+int diff_dog_launch(const double *band1, const double *band2, int64_t n, int dpx, const int64_t *d_starts, int CH, int B,
+                    const DiffLevels *d_lv, int n_oct, double *dog, double *partial, int32_t *d_tiles, int m,
+                    uint32_t *mask_count, double *fit, hipStream_t s) {
+    static unsigned long long lds_allowed = 0;
+    MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&diff_dog_kernel<T>), (int)diff_lds_bytes<T>(),
+                                   &lds_allowed));
+    const int tx = (CH + T::RGC - 1) / T::RGC, nt = diff_tiles<T>(CH);
     if (m > 0) {
         diff_dog_kernel<T><<<dim3((m + 7) / 8 * 8, B), T::NT, diff_lds_bytes<T>(), s>>>(band1, band2, n, dpx, d_starts, CH, B,
                                                                                       d_lv, dog, partial, mask_count, tx, m,
@@ -479,16 +485,26 @@ extern "C" int mst_diff_dog_band(const double *band1, const double *band2, int64
     int32_t *d_tiles = reinterpret_cast<int32_t *>(w);
     w += diff_align(sizeof(int32_t) * 2 * (size_t)diff_tiles<DiffTile28>(CH));
     double *partial = reinterpret_cast<double *>(w);
-    MST_HIP(mst::upload_small(d_lv, &h, sizeof(h), s));
-    MST_HIP(mst::upload_small(d_starts, starts, sizeof(int64_t) * B, s));
+    // the three tables the kernel reads -- levels, block origins, tile list -- lie side by side in the workspace: ONE upload
+    // (three staged copies, each with its dispatch gap, were 30 us in front of a 150 us kernel)
+    static thread_local std::vector<char> tab;
+    const size_t tab_bytes = (size_t)(reinterpret_cast<char *>(partial) - reinterpret_cast<char *>(d_lv));
+    tab.assign(tab_bytes, 0);
+    memcpy(tab.data(), &h, sizeof(h));
+    memcpy(tab.data() + (reinterpret_cast<char *>(d_starts) - reinterpret_cast<char *>(d_lv)), starts, sizeof(int64_t) * (size_t)B);
+    int32_t *h_tiles = reinterpret_cast<int32_t *>(tab.data() + (reinterpret_cast<char *>(d_tiles) - reinterpret_cast<char *>(d_lv)));
+    const int which = mr <= DiffTile8::RMAX ? 0 : (mr <= DiffTile14::RMAX ? 1 : 2);
+    const int m = which == 0 ? diff_tile_list<DiffTile8>(CH, dpx, h_tiles)
+                             : (which == 1 ? diff_tile_list<DiffTile14>(CH, dpx, h_tiles) : diff_tile_list<DiffTile28>(CH, dpx, h_tiles));
+    MST_HIP(mst::upload_small(d_lv, tab.data(), tab_bytes, s));
     MST_HIP(hipMemsetAsync(mask_count, 0, sizeof(uint32_t) * B, s));
-    if (mr <= DiffTile8::RMAX)
-        return diff_dog_launch<DiffTile8>(band1, band2, n, dpx, d_starts, CH, B, d_lv, h.n_octaves, dog, partial, d_tiles,
+    if (which == 0)
+        return diff_dog_launch<DiffTile8>(band1, band2, n, dpx, d_starts, CH, B, d_lv, h.n_octaves, dog, partial, d_tiles, m,
                                           mask_count, fit, s);
-    if (mr <= DiffTile14::RMAX)
-        return diff_dog_launch<DiffTile14>(band1, band2, n, dpx, d_starts, CH, B, d_lv, h.n_octaves, dog, partial, d_tiles,
+    if (which == 1)
+        return diff_dog_launch<DiffTile14>(band1, band2, n, dpx, d_starts, CH, B, d_lv, h.n_octaves, dog, partial, d_tiles, m,
                                            mask_count, fit, s);
-    return diff_dog_launch<DiffTile28>(band1, band2, n, dpx, d_starts, CH, B, d_lv, h.n_octaves, dog, partial, d_tiles,
+    return diff_dog_launch<DiffTile28>(band1, band2, n, dpx, d_starts, CH, B, d_lv, h.n_octaves, dog, partial, d_tiles, m,
                                        mask_count, fit, s);
 }
 
@@ -539,6 +555,50 @@ pair_gather_kernel(const mst_found *__restrict__ found, uint32_t found_cap, cons
     }
 }
 
+// The same gather with ONE workgroup per block: the selected pixels go into a small open-addressing table in LDS (pixel ->
+// slot), then the partner block's found list is walked once and every record looks its pixel up -- 12 workgroups reading
+// their partner's list once instead of one workgroup per selected record reading it all (3 072 workgroups, 37 us on six block
+// pairs: a third of what the whole tail of a two-sample call costs).  H = table size (a power of two >= 2 * out_cap).
+constexpr int kGatherThreads = 1024;
+__global__ void __launch_bounds__(kGatherThreads)
+pair_gather_block_kernel(const mst_found *__restrict__ found, uint32_t found_cap, const uint32_t *__restrict__ found_count,
+                         const double *__restrict__ ppair, int P, const uint32_t *__restrict__ sel_index,
+                         const uint32_t *__restrict__ sel_pixel, const uint32_t *__restrict__ sel_count, uint32_t out_cap,
+                         double *__restrict__ out_pair, double *__restrict__ out_value, double *__restrict__ out_other, uint32_t H) {
+    extern __shared__ uint32_t gather_tab[];
+    uint32_t *keys = gather_tab, *slots = gather_tab + H;
+    constexpr uint32_t kEmpty = 0xFFFFFFFFu;               // no pixel index: CH * CH - 1 < 2^32 - 1
+    const int fb = blockIdx.x, tid = threadIdx.x;
+    const uint32_t sc = sel_count[fb];                     // MST_BH_RETRY: the selection of this block has not happened yet
+    const uint32_t nsel = sc == MST_BH_RETRY ? 0u : (sc < out_cap ? sc : out_cap);
+    if (nsel == 0) return;
+    for (uint32_t i = tid; i < H; i += kGatherThreads) keys[i] = kEmpty;
+    __syncthreads();
+    auto hash = [&](uint32_t px) { return (px * 2654435761u) & (H - 1); };
+    for (uint32_t slot = tid; slot < nsel; slot += kGatherThreads) {
+        const size_t o = (size_t)fb * out_cap + slot;
+        const uint32_t idx = sel_index[o], pixel = sel_pixel[o];
+        out_pair[o] = ppair[(size_t)fb * found_cap + idx];
+        out_value[o] = found[(size_t)fb * found_cap + idx].value;
+        out_other[o] = __longlong_as_double(0x7FF8000000000000ll);       // NaN = the partner did not find this pixel
+        uint32_t h = hash(pixel);
+        while (atomicCAS(&keys[h], kEmpty, pixel) != kEmpty) h = (h + 1) & (H - 1);   // pixels are unique inside a block
+        slots[h] = slot;
+    }
+    __syncthreads();
+    const int pb = fb < P ? fb + P : fb - P;
+    const uint32_t np = found_count[pb] < found_cap ? found_count[pb] : found_cap;
+    const mst_found *pf = found + (size_t)pb * found_cap;
+    for (uint32_t i = tid; i < np; i += kGatherThreads) {
+        const mst_found r = pf[i];
+        for (uint32_t h = hash(r.pixel); keys[h] != kEmpty; h = (h + 1) & (H - 1))
+            if (keys[h] == r.pixel) {
+                out_other[(size_t)fb * out_cap + slots[h]] = r.value;
+                break;
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int mst_pair_gather(const mst_found *found, uint32_t found_cap, const uint32_t *found_count, const double *ppair,
@@ -549,6 +609,14 @@ extern "C" int mst_pair_gather(const mst_found *found, uint32_t found_cap, const
         !out_other || P <= 0 || 2 * P > 65535 || found_cap == 0 || out_cap == 0 || max_selected > out_cap)
         return mst::fail(MST_E_ARG, "mst_pair_gather: bad argument");
     if (max_selected == 0) return MST_OK;
+    if (out_cap <= 4096) {                                  // the table fits the default 64 KB of dynamic LDS
+        uint32_t H = 64;
+        while (H < 2 * out_cap) H <<= 1;
+        pair_gather_block_kernel<<<2 * P, kGatherThreads, sizeof(uint32_t) * 2 * H, mst::as_stream(stream)>>>(
+            found, found_cap, found_count, ppair, P, sel_index, sel_pixel, sel_count, out_cap, out_pair, out_value, out_other, H);
+        MST_LAUNCH_CHECK();
+        return MST_OK;
+    }
     pair_gather_kernel<<<dim3(max_selected, 2 * P), kThreads, 0, mst::as_stream(stream)>>>(
         found, found_cap, found_count, ppair, P, sel_index, sel_pixel, sel_count, out_cap, out_pair, out_value, out_other);
     MST_LAUNCH_CHECK();

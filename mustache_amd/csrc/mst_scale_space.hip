@@ -1085,12 +1085,30 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
         gent->image_used += align_up(bytes, 256);
         return hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, s);
     };
+    // Captured launches (small, latency-bound): the four tables lie side by side in the workspace -- the tile positions packed
+    // right behind the work list instead of at their worst-case offset -- in the order and alignment of the graph entry's
+    // page-locked image, so ONE copy node uploads them all (four nodes of ~5 us each stood in front of a 0.5 ms kernel).
+    if (gent) d_sop = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(d_items) + align_up(items_bytes, 256));
     auto enqueue = [&]() -> int {
-        MST_HIP(up(d_lv, &h, sizeof(h)));
+        if (gent) {
+            char *img = gent->image;
+            const size_t o1 = align_up(sizeof(DevLevels), 256), o2 = o1 + align_up(sizeof(int64_t) * (size_t)B, 256),
+                         o3 = o2 + align_up(items_bytes, 256);
+            memcpy(img, &h, sizeof(h));
+            if (BAND) memcpy(img + o1, starts_host, sizeof(int64_t) * (size_t)B);
+            if (n_items) {
+                memcpy(img + o2, hit->items.data(), items_bytes);
+                memcpy(img + o3, hit->sop.data(), sop_bytes);
+            }
+            gent->image_used = n_items ? o3 + sop_bytes : o2;
+            MST_HIP(hipMemcpyAsync(d_lv, img, gent->image_used, hipMemcpyHostToDevice, s));
+        } else {
+            MST_HIP(up(d_lv, &h, sizeof(h)));
+        }
         zero_counts_kernel<<<(B + 255) / 256, 256, 0, s>>>(found_count, BAND ? src.nz_count : nullptr, B);
         MST_LAUNCH_CHECK();
         if (BAND) {
-            MST_HIP(up(d_starts, starts_host, sizeof(int64_t) * B));
+            if (!gent) MST_HIP(up(d_starts, starts_host, sizeof(int64_t) * B));
             src.starts = d_starts;
         }
         if (n_items == 0) {          // no tile reaches the band: nothing is tested, nothing is found
@@ -1098,10 +1116,7 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
             MST_LAUNCH_CHECK();
             return MST_OK;
         }
-        if (gent) {
-            MST_HIP(up(d_items, hit->items.data(), items_bytes));
-            MST_HIP(up(d_sop, hit->sop.data(), sop_bytes));
-        } else {
+        if (!gent) {
             MST_HIP(hit->pin_items.upload(d_items, s));
             MST_HIP(hit->pin_sop.upload(d_sop, s));
         }

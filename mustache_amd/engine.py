@@ -663,16 +663,20 @@ class ScaleSpaceEngine:
                 if full_sort:
                     _lib.check(self.lib.mst_select_below(_ptr(found), _ptr(q), _ptr(count), B, found_cap, pt, cap,
                                                          _ptr(pix), _ptr(lvl), _ptr(qs), _ptr(n_sel), _stream()))
-                elif pair is not None:
-                    idx = torch.empty((B, cap), dtype=torch.int32, device=self.device)
-                    _lib.check(self.lib.mst_bh_select_records(_ptr(found), _ptr(pval), _ptr(count), B, found_cap, pt, cap,
-                                                              _ptr(pix), _ptr(lvl), _ptr(qs), _ptr(idx), _ptr(n_sel),
-                                                              _ptr(ws), ws_bytes, _stream()))
                 else:
-                    _lib.check(self.lib.mst_bh_select(_ptr(found), _ptr(pval), _ptr(count), B, found_cap, pt, cap,
-                                                      _ptr(pix), _ptr(lvl), _ptr(qs), _ptr(n_sel), _ptr(ws), ws_bytes,
-                                                      _stream()))
+                    # without the library's own look at the subset sizes (mst_bh_select_nowait: the in-LDS sort for every
+                    # block): the counts are read right below anyway, and a block whose subset does not fit it says so there
+                    idx = torch.empty((B, cap), dtype=torch.int32, device=self.device) if pair is not None else None
+                    args = (_ptr(found), _ptr(pval), _ptr(count), B, found_cap, pt, cap, _ptr(pix), _ptr(lvl), _ptr(qs),
+                            None if idx is None else _ptr(idx), _ptr(n_sel), _ptr(ws), ws_bytes, _stream())
+                    _lib.check(self.lib.mst_bh_select_nowait(*args))
                 n_h = n_sel.cpu().numpy().view(np.uint32).astype(np.int64)
+                if not full_sort and (n_h == 0xFFFFFFFF).any():       # MST_BH_RETRY: the segmented radix sort takes the launch
+                    if idx is not None:
+                        _lib.check(self.lib.mst_bh_select_records(*args))
+                    else:
+                        _lib.check(self.lib.mst_bh_select(*(args[:10] + args[11:])))
+                    n_h = n_sel.cpu().numpy().view(np.uint32).astype(np.int64)
                 if n_h.max(initial=0) <= cap:
                     break
                 cap = self._select_cap = int(n_h.max()) * 2         # rare: re-run with room for every selected record
@@ -960,11 +964,16 @@ class ScaleSpaceEngine:
         if ws_bytes == 0:
             return None
         summ = self._summary_pin(B)
-        scratch, ppair, pix, lvl, idx, qs, n_sel, g, ws = self._carve(
+        # everything that goes back to the host lies in ONE device buffer {q, pair / value / other, norm.fit | pixel, level, count}
+        # and comes back in ONE copy (six small copies were 45 us of device time and 0.4 ms of host time)
+        nf = int(nfit.numel())
+        n8, n4 = B * sel + 3 * B * sel + nf, 2 * B * sel + B
+        scratch, ppair, idx, ws, blob = self._carve(
             (summ.numel(), torch.uint8, (summ.numel(),)), (B * cap * 8, torch.float64, (B, cap)), (B * sel * 4, torch.int32, (B, sel)),
-            (B * sel * 4, torch.int32, (B, sel)), (B * sel * 4, torch.int32, (B, sel)), (B * sel * 8, torch.float64, (B, sel)),
-            (B * 4, torch.int32, (B,)), (3 * B * sel * 8, torch.float64, (3, B, sel)), (ws_bytes, torch.uint8, (ws_bytes,)),
-            reuse=("pairs-tail", 0))
+            (ws_bytes, torch.uint8, (ws_bytes,)), (8 * n8 + 4 * n4, torch.uint8, (8 * n8 + 4 * n4,)), reuse=("pairs-tail", 0))
+        f8, i4 = blob[:8 * n8].view(torch.float64), blob[8 * n8:].view(torch.int32)
+        qs, g, nfit_d = f8[:B * sel].view(B, sel), f8[B * sel:4 * B * sel].view(3, B, sel), f8[4 * B * sel:].view(nfit.shape)
+        pix, lvl, n_sel = i4[:B * sel].view(B, sel), i4[B * sel:2 * B * sel].view(B, sel), i4[2 * B * sel:]
         none3 = (None, None, None)
         _lib.check(self.lib.mst_found_finish(_ptr(found), cap, _ptr(count), _ptr(nzc), _ptr(stats), B, nt, _ptr(pval), _ptr(fit), 0,
                                              *none3, _ptr(scratch), ctypes.c_void_p(summ.data_ptr()), *none3, 16, _stream()))
@@ -975,33 +984,42 @@ class ScaleSpaceEngine:
                                                  _ptr(idx), _ptr(n_sel), _ptr(ws), ws_bytes, _stream()))
         _lib.check(self.lib.mst_pair_gather(_ptr(found), cap, _ptr(count), _ptr(ppair), int(P), _ptr(idx), _ptr(pix), _ptr(n_sel), sel,
                                             sel, _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _stream()))
+        nfit_d.copy_(nfit)
         self._pin_flip ^= 1
-        host = [self._pinned(k, tuple(t.shape), t.dtype) for k, t in (("pw_n", n_sel), ("pw_pix", pix), ("pw_lvl", lvl), ("pw_q", qs),
-                                                                      ("pw_g", g), ("pw_nfit", nfit))]
-        for hbuf, t in zip(host, (n_sel, pix, lvl, qs, g, nfit)):
-            hbuf.copy_(t, non_blocking=True)
+        hblob = self._pinned("pw_blob", (int(blob.numel()),), torch.uint8)
+        hblob.copy_(blob, non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        _lib.check(self.lib.mst_found_summary_status(ctypes.c_void_p(summ.data_ptr()), cap))       # MstOverflow: relaunch, larger lists
-        n_h = host[0].numpy().view(np.uint32).astype(np.int64)
-        if (n_h == 0xFFFFFFFF).any() or n_h.max(initial=0) > sel:
-            if not (n_h == 0xFFFFFFFF).any():
-                self._pair_sel_cap = int(n_h.max()) * 2          # room for every selected record from the next call on
+        h8, h4 = hblob[:8 * n8].view(torch.float64).numpy(), hblob[8 * n8:].view(torch.int32).numpy()
+        host = [h4[2 * B * sel:], h4[:B * sel].reshape(B, sel), h4[B * sel:2 * B * sel].reshape(B, sel), h8[:B * sel].reshape(B, sel),
+                h8[B * sel:4 * B * sel].reshape(3, B, sel), h8[4 * B * sel:].reshape(tuple(nfit.shape))]
+        if int(summ.numpy()[:4].view(np.int32)[0]):       # overflow / non-finite flags: the library words the error
+            _lib.check(self.lib.mst_found_summary_status(ctypes.c_void_p(summ.data_ptr()), cap))   # MstOverflow: relaunch, larger lists
+        n_h = host[0].view(np.uint32).astype(np.int64)
+        mx = int(n_h.max(initial=0))
+        if mx > sel:                                     # (MST_BH_RETRY = 0xFFFFFFFF included)
+            if mx != 0xFFFFFFFF:
+                self._pair_sel_cap = mx * 2              # room for every selected record from the next call on
             return None
         _, nz_h, fit_h = self._parse_summary(summ, B)
-        pix_h, lvl_h, q_h, g_h = host[1].numpy().view(np.uint32), host[2].numpy().view(np.uint32), host[3].numpy(), host[4].numpy()
-        # the kernel appends in arbitrary order: ONE sort by (block, pixel) over all selected records (pixels are unique inside a
-        # block), then every block's arrays are slices of the sorted ones
-        live = np.arange(sel)[None, :] < n_h[:, None]
-        bb, ss = np.nonzero(live)
-        order = np.argsort((bb.astype(np.int64) << 32) | pix_h[bb, ss], kind="stable")
-        bb, ss = bb[order], ss[order]
-        cols = {"pixel": pix_h[bb, ss], "level": lvl_h[bb, ss], "q": q_h[bb, ss], "pair": g_h[0][bb, ss], "value": g_h[1][bb, ss],
-                "v_other": g_h[2][bb, ss]}
-        ends = np.cumsum(n_h)
-        fit_c = fit_h[:, :nt, :].copy()
-        recs = [{k: v[e - m:e] for k, v in cols.items()} for e, m in zip(ends.tolist(), n_h.tolist())]
-        fits = [(fit_c[b, :, 0], fit_c[b, :, 1]) for b in range(B)]
-        return recs, fits, nz_h, host[5].numpy().copy()
+        # the kernel appends in arbitrary order: ONE sort by (block, pixel) over the live slots (pixels are unique inside a block),
+        # then every block's arrays are slices of the sorted ones
+        grid = self._slot_grid.get((B, sel)) if hasattr(self, "_slot_grid") else None
+        if grid is None:
+            self._slot_grid = {(B, sel): (np.arange(sel, dtype=np.int64)[None, :], np.arange(B, dtype=np.int64)[:, None] << 32)}
+            grid = self._slot_grid[(B, sel)]
+        live = np.flatnonzero(grid[0] < n_h[:, None])                      # ascending: by block, then slot
+        pixf = host[1].view(np.uint32).reshape(-1)
+        flat = live[np.argsort(((live // sel) << 32) | pixf[live], kind="stable")]
+        g_h = host[4].reshape(3, -1)
+        cols = (("pixel", pixf[flat]), ("level", host[2].view(np.uint32).reshape(-1)[flat]),
+                ("q", host[3].reshape(-1)[flat]), ("pair", g_h[0][flat]), ("value", g_h[1][flat]), ("v_other", g_h[2][flat]))
+        fit_c = fit_h[:, :nt, :]
+        recs, fits, e = [], [], 0
+        for b, m in enumerate(n_h.tolist()):
+            recs.append({k: v[e:e + m] for k, v in cols})
+            fits.append((fit_c[b, :, 0], fit_c[b, :, 1]))
+            e += m
+        return recs, fits, nz_h, host[5].copy()
 
     def run_band_pairs_overlapped(self, bands, n, dpx, groups, CH, skip_empty=True, select_below=None):
         """run_band_pairs over several groups of block pairs with the device work of group i + 1 queued BEFORE the results of

@@ -194,6 +194,37 @@ if "SQ_WAVE_CYCLES" in allc:
 if "SQ_LDS_BANK_CONFLICT" in allc and allc.get("SQ_LDS_IDX_ACTIVE"):
     lines += ["LDS: bank-conflict cycles / LDS active cycles = %.1f %%."
               % (100 * allc["SQ_LDS_BANK_CONFLICT"] / allc["SQ_LDS_IDX_ACTIVE"])]
+# ---- the same counters for each launch form of the PMC runs' 12-block workload (the forms differ in their workgroup counts)
+try:
+    forms = [("dense, tiles shared (the launch `value` times)", shared_items),
+             ("tile list, tiles shared (product mode)", (pmc_line.get("band_skip", {}).get("roofline", {}).get("work_items_per_launch") or [None])[0]),
+             ("dense, every tile once per block (`no_share`)", (pmc_line.get("no_share", {}).get("work_items_per_launch", {}).get("dense") or [None])[0]),
+             ("tile list, every tile once per block", (pmc_line.get("no_share", {}).get("work_items_per_launch", {}).get("band_skip") or [None])[0])]
+    lines += ["", "## The counters by launch form (same PMC runs; a form is recognised by its workgroup count; per COMPUTED pixel = "
+              "per owned pixel of a workgroup that ran, 30 x 62 each)", "",
+              "| launch form | workgroups | VALU instr / px | LDS instr / px | VALU busy (wave-cycles -> pipe at 2 waves/SIMD) | WAIT_ANY | "
+              "LDS conflict share | HBM B / px |", "|---|---|---|---|---|---|---|---|"]
+    by_form = {}
+    for label, items in forms:
+        if not items:
+            continue
+        c = counters_of(((items + 7) // 8 * 8) * 256)
+        if not c or "SQ_WAVE_CYCLES" not in c:
+            continue
+        pxc = items * 30.0 * 62.0
+        wc = c["SQ_WAVE_CYCLES"]
+        row = {"workgroups": items, "valu_per_px": c.get("SQ_INSTS_VALU", 0) * 64 / pxc, "lds_per_px": c.get("SQ_INSTS_LDS", 0) * 64 / pxc,
+               "valu_busy": c.get("SQ_ACTIVE_INST_VALU", 0) / wc, "wait_any": c.get("SQ_WAIT_ANY", 0) / wc,
+               "lds_conflict": c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else None,
+               "hbm_b_per_px": (c["FETCH_SIZE"] * 2048 + c["WRITE_SIZE"] * 1024) / pxc if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None}
+        by_form[label] = row
+        lines.append("| %s | %d | %.0f | %.0f | %.1f %% -> %.1f %% | %.1f %% | %s | %s |" % (
+            label, items, row["valu_per_px"], row["lds_per_px"], 100 * row["valu_busy"], 200 * row["valu_busy"], 100 * row["wait_any"],
+            "-" if row["lds_conflict"] is None else "%.1f %%" % (100 * row["lds_conflict"]),
+            "-" if row["hbm_b_per_px"] is None else "%.2f" % row["hbm_b_per_px"]))
+    traffic["by_launch_form"] = by_form
+except Exception as e:
+    lines += ["", "(per-form counter table unavailable: %r)" % (e,)]
 # ---- the other kernels of the path: durations from the trace, HBM bytes from the PMC passes ------------------------------
 def pmc_all(kernel_sub):
     """{counter: [values per dispatch, dispatch order]} over all PMC passes for kernels whose name holds kernel_sub."""

@@ -75,21 +75,23 @@ inline uint32_t dist_payload(int sym) {
 
 // Canonical Huffman code (RFC 1951 3.2.2) -> decode table indexed by the next `root` input bits (LSB first).  Codes longer
 // than `root` share a primary entry {kind kSub, value = start of their second-level table, extra = its index bits}.
-// Returns false for an over-subscribed code, or an incomplete one unless it has at most one symbol (`allow_incomplete`: the
-// distance code of a block with one distance or none, as zlib accepts).
+// Returns false for an over-subscribed code, or an incomplete one -- except, as zlib's inftrees.c has it, `allow_incomplete`
+// alphabets (literal/length and distance, not the code-length code) whose LONGEST code is one bit long (a block with a single
+// literal/length or distance symbol), and a distance alphabet without any code (a block of literals only).
 template <class Payload>
 inline bool build_table(const uint8_t *lens, int nsyms, int root, uint32_t *table, int cap, bool allow_incomplete,
                         Payload payload) {
     int count[16] = {0};
     for (int s = 0; s < nsyms; ++s) ++count[lens[s]];
     count[0] = 0;
-    int left = 1, used = 0;
+    int left = 1, used = 0, maxlen = 0;
     for (int l = 1; l <= 15; ++l) {
         left = (left << 1) - count[l];
         if (left < 0) return false;
         used += count[l];
+        if (count[l]) maxlen = l;
     }
-    if (left > 0 && !(allow_incomplete && used <= 1)) return false;
+    if (left > 0 && !(allow_incomplete && (maxlen == 1 || used == 0))) return false;
     uint32_t next_code[16];
     uint32_t code = 0;
     for (int l = 1; l <= 15; ++l) {
@@ -324,7 +326,7 @@ inline int inflate_raw(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, s
             if (nlit < 288) memmove(lens + 288, lens + nlit, (size_t)ndist);
             for (int k = nlit; k < 288; ++k) lens[k] = 0;
         }
-        if (!build_table(lens, 288, kLitlenRoot, t.litlen, kLitlenCap, false, litlen_payload)) return kCorrupt;
+        if (!build_table(lens, 288, kLitlenRoot, t.litlen, kLitlenCap, true, litlen_payload)) return kCorrupt;
         if (!build_table(lens + 288, ndist, kDistRoot, t.dist, kDistCap, true, dist_payload)) return kCorrupt;
 
         // ---- symbols of the block.  (A fully branch-free form -- distance table looked up for every symbol, bits consumed

@@ -107,6 +107,11 @@ __device__ __forceinline__ void blur_level(const double *ct, double *vb, const d
     MST_STAMP(tr, 1)
     __syncthreads();
     MST_STAMP(tr, 2)
+    if (MST_VARIANT(32)) {              // [ablation 32] axis-0 pass only (with 24 = the other half: the "roles" experiment)
+#pragma unroll
+        for (int k = 0; k < T::K; ++k) g[k] = 0.0;
+        return;
+    }
     hpass<T, R>(hsrc, w, g);
     MST_STAMP(tr, 3)
 }
@@ -426,7 +431,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
             if (tr) tr += MST_TRACE_STAMPS;
 #endif
             if (kl < 2) continue;
-            if (MST_VARIANT(1)) continue;     // [ablation 1] blur + DoG only
+            if (MST_VARIANT(1) || MST_VARIANT(32)) continue;     // [ablation 1] blur + DoG only
 
             // zero-padded 3x3 max at the owned pixels: 3-max along the row in registers, then across rows via lane shifts.
             // A pixel's maximum is only ever compared with DoG values of the SAME pixel (mustache.py:760-765, on the tested

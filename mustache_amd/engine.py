@@ -591,8 +591,8 @@ class ScaleSpaceEngine:
                                      reuse=0 if download else None, graph=download)
                 st2 = self._ss_finish(st, packed=download and select_below is None and not sort)
                 res = self._ss_results(st2, download, sort, with_value, with_q, select_below)
-            if side is not None and not download:
-                cur.wait_stream(side)
+            if side is not None:
+                cur.wait_stream(side)           # explicit: the caller's stream is ordered behind the side stream whatever the finish did
             yield res + ((torch.from_numpy(st2["nz_h"].astype(np.uint32).view(np.int32)) if download else st2["args"][2]),)
             return
         cur = torch.cuda.current_stream(self.device)

@@ -157,6 +157,10 @@ def close_hic_handle():
     with _HIC_LOCK:
         if _HIC_HANDLE[1] is not None:
             _HIC_HANDLE[1].close()
+            import sys
+            norm = sys.modules.get("mustache_amd.normalize")      # only if the GPU loader was ever imported
+            if norm is not None:
+                norm.release_slab_pool()                          # the streamed reads' page-locked slabs (up to 512 MB)
         _HIC_HANDLE[0], _HIC_HANDLE[1] = None, None
 
 

@@ -422,3 +422,65 @@ def test_raw_streamed_rows_decode_to_the_packed_read(tmp_path, version, float_co
             o = np.argsort(k)
             assert len(k) == len(key_w) > 10000 and np.array_equal(k[o], key_w[order_w]) and np.array_equal(gv[o], whole.v[order_w])
             assert int(gy.max()) + 1 == whole.n
+
+
+def test_own_inflate_accepts_the_incomplete_codes_zlib_accepts():
+    """zlib's rule for incomplete Huffman codes (inftrees.c): a literal/length or distance code may be incomplete when its
+    longest code is ONE bit long -- e.g. a dynamic block whose only symbol is end-of-block -- and a distance alphabet may hold no
+    code at all; every other incomplete code, e.g. a single distance code of two bits, is an error.  Hand-assembled streams:
+    mst_inflate.h decides each of them as zlib does."""
+    import zlib
+    from mustache_amd import hicfile
+    lib = hicfile.load()
+
+    class Bits:
+        def __init__(self):
+            self.acc, self.n, self.out = 0, 0, bytearray()
+
+        def put(self, value, nbits):                 # LSB first
+            self.acc |= value << self.n
+            self.n += nbits
+            while self.n >= 8:
+                self.out.append(self.acc & 255)
+                self.acc >>= 8
+                self.n -= 8
+
+        def code(self, code, length):                # Huffman codes go in MSB first
+            for i in range(length - 1, -1, -1):
+                self.put((code >> i) & 1, 1)
+
+        def done(self):
+            if self.n:
+                self.out.append(self.acc & 255)
+            return bytes(self.out)
+
+    def stream(dist_len):
+        """one final dynamic block: literal/length lengths = {256: 1} (incomplete, longest code one bit), distance lengths =
+        {0: dist_len}; code-length code: 18 -> 1 bit '0', 0 -> 2 bits '10', 1 -> '110', 2 -> '111'; then the end-of-block symbol"""
+        b = Bits()
+        b.put(1, 1); b.put(2, 2)                     # BFINAL, BTYPE = dynamic
+        b.put(0, 5); b.put(0, 5); b.put(14, 4)       # HLIT = 257, HDIST = 1, HCLEN = 18 code-length codes
+        cl = {18: 1, 0: 2, 1: 3, 2: 3}
+        for sym in (16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1):
+            b.put(cl.get(sym, 0), 3)
+        codes = {18: (0b0, 1), 0: (0b10, 2), 1: (0b110, 3), 2: (0b111, 3)}
+        b.code(*codes[18]); b.put(138 - 11, 7)       # 138 zeros
+        b.code(*codes[18]); b.put(118 - 11, 7)       # 118 zeros: symbols 0..255
+        b.code(*codes[1])                            # symbol 256: one bit
+        b.code(*codes[dist_len])                     # the one distance symbol
+        b.code(0, 1)                                 # end of block
+        raw = b.done()
+        return b"\x78\x01" + raw + (1).to_bytes(4, "big")        # zlib header, Adler-32 of the empty output
+
+    def ours(comp):
+        out = (ctypes.c_uint8 * 1024)()                # (the call wants 266 bytes of working margin)
+        return lib.mst_io_inflate(comp, len(comp), out, 1024)
+
+    for dist_len, ok in ((0, True), (1, True), (2, False)):
+        comp = stream(dist_len)
+        try:
+            z = zlib.decompress(comp)
+        except zlib.error:
+            z = None
+        assert (z == b"") == ok, ("zlib itself", dist_len, z)
+        assert (ours(comp) == 0) == ok and (ok or ours(comp) < 0), (dist_len, ours(comp))

@@ -48,7 +48,7 @@ extern "C" {
                                * default stream (it cannot be captured) and by PROFILE builds. */
 #define MST_FLAG_NO_WAIT 16   /* mst_found_finish only: enqueue and return -- the caller queues more work behind it (the two-sample
                                * path: pair p-values, BH, gathers), synchronises ONCE and then asks mst_found_summary_status */
-#define MST_BH_RETRY 0xFFFFFFFFu /* mst_bh_select_nowait: out_count of a block whose candidate subset exceeds 4096 records */
+#define MST_BH_RETRY 0xFFFFFFFFu /* mst_bh_select_nowait: out_count of a block whose candidate subset exceeds lds_records */
 #define MST_FLAG_FMA 2        /* OPT-IN relaxed arithmetic: fuse the multiply-add of each tap pair.  DoG values then differ
                                  from the reference's by ~1e-16 relative (instead of being bit-identical); default off */
 
@@ -175,13 +175,14 @@ int mst_bh_select_records(const mst_found *found, const double *pval, const uint
                           uint64_t workspace_bytes, void *stream);
 
 /* mst_bh_select_records (out_index may be NULL) WITHOUT the host synchronisation: the in-LDS sort is launched for every block,
- * and a block whose candidate subset exceeds 4096 records (threshold near 1) gets out_count[b] = MST_BH_RETRY instead of a
+ * sized for candidate subsets of up to `lds_records` records (a power of two <= 4096; 12 bytes of LDS each: the caller's guess,
+ * e.g. twice what its last launch needed), and a block whose subset is larger gets out_count[b] = MST_BH_RETRY instead of a
  * count -- the caller, once it has synchronised for out_count anyway, then runs mst_bh_select / mst_bh_fdr + mst_select_below
  * for the launch.  Lets a latency-bound caller (the two-sample path on a few blocks) queue everything behind the fused
  * kernels and wait once. */
 int mst_bh_select_nowait(const mst_found *found, const double *pval, const uint32_t *found_count, int32_t B,
                          uint32_t found_cap, double threshold, uint32_t out_cap, uint32_t *out_pixel, uint32_t *out_level,
-                         double *out_q, uint32_t *out_index, uint32_t *out_count, void *workspace,
+                         double *out_q, uint32_t *out_index, uint32_t *out_count, uint32_t lds_records, void *workspace,
                          uint64_t workspace_bytes, void *stream);
 
 /* mustache.py:789-797 (selection of the pixels with o < pt) on the device: the found records of each block whose q-value

@@ -60,7 +60,7 @@ _SIGNATURES = {
     "mst_scale_space_band_tiles": (ctypes.c_int, [_i32, _i32, _p, _p]),
     "mst_scale_space_band_items": (ctypes.c_int, [ctypes.POINTER(_i64), _i32, _i32, _i32, _p, _i32, _p, _p]),
     "mst_bh_select_records": (ctypes.c_int, [_p, _p, _p, _i32, _u32, ctypes.c_double, _u32, _p, _p, _p, _p, _p, _p, _u64, _p]),
-    "mst_bh_select_nowait": (ctypes.c_int, [_p, _p, _p, _i32, _u32, ctypes.c_double, _u32, _p, _p, _p, _p, _p, _p, _u64, _p]),
+    "mst_bh_select_nowait": (ctypes.c_int, [_p, _p, _p, _i32, _u32, ctypes.c_double, _u32, _p, _p, _p, _p, _p, _u32, _p, _u64, _p]),
     "mst_found_summary_status": (ctypes.c_int, [_p, _u32]),
     "mst_select_below": (ctypes.c_int, [_p, _p, _p, _i32, _u32, ctypes.c_double, _u32, _p, _p, _p, _p, _p]),
     "mst_candidate_features": (ctypes.c_int, [_p, _p, _i32, _i32, _p, _p, _i32, _p, _p, _p, _p]),

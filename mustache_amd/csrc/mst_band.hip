@@ -186,16 +186,18 @@ diag_stats_kernel(const double *__restrict__ band, int64_t n, double *__restrict
 // head (<= 15 samples) + whole aligned blocks + tail (<= 15 samples): ~150 additions instead of W = 2000, in an order
 // that depends only on the window's absolute position (deterministic, independent of how the diagonal is segmented),
 // and with the rounding behaviour of a two-level (blocked) summation.
-// Two instantiations: <16, true> (windows up to ~8400 bins: samples AND their squares staged, 16-sample blocks -- the form every
-// result so far was produced with) and <64, false> (windows up to 16384 bins, i.e. resolutions down to ~125 bp: samples only --
-// the square is formed where it is summed, the same product -- and 64-sample blocks, so that 1024 + 16384 samples and their
-// block sums fit the 160 KB of LDS).  Both stay far below 128 VGPRs: no scratch (the walking kernel's <1024, 16> form, which
-// served these windows until round 4, spilled 488 registers).
+// Two instantiations: <16, true, false> (windows up to ~8400 bins: samples AND their squares staged, 16-sample blocks -- the form
+// every result so far was produced with) and <32, false, true> (windows up to 16384 bins, i.e. resolutions down to ~125 bp:
+// samples only -- the square is formed where it is summed, the same product -- 32-sample blocks, so that 1024 + 16384 samples
+// and their block sums fit the 160 KB of LDS, and the block sums turned into exclusive PREFIX sums over the tile's <= 545
+// blocks, so that the whole blocks of a window cost one subtraction instead of up to 512 additions: head + tail <= 62 samples
+// per output).  Both stay far below 128 VGPRs: no scratch (the walking kernel's <1024, 16> form, which served these windows
+// until round 4, spilled 488 registers; this form is as fast: 9009-bin windows, 1.2e8 samples, see LABBOOK R5.6).
 constexpr int kSeg = 1024;
 constexpr int kBlk = 16;
-constexpr int kBlkWide = 64;
+constexpr int kBlkWide = 32;
 
-template <int BLK, bool STAGE_SQ>
+template <int BLK, bool STAGE_SQ, bool PREFIX>
 __global__ void __launch_bounds__(kThreads)
 normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ band_out, int64_t n, int W,
                        const double *__restrict__ diag_stats) {
@@ -211,8 +213,9 @@ normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ 
     const int64_t base = (first >= 0 ? first : first - (BLK - 1)) / BLK * BLK;      // floor to multiple of BLK
     const int tile = (int)(seg0 + kSeg - 1 - left + W - base) + 1;                     // covers the last window's end
     const int nblk = (tile + BLK - 1) / BLK;
-    double *val = lds, *sqa = val + nblk * BLK, *b1 = sqa + (STAGE_SQ ? nblk * BLK : 0), *b2 = b1 + nblk;
-    int *bc = reinterpret_cast<int *>(b2 + nblk);
+    const int nb1 = nblk + (PREFIX ? 1 : 0);
+    double *val = lds, *sqa = val + nblk * BLK, *b1 = sqa + (STAGE_SQ ? nblk * BLK : 0), *b2 = b1 + nb1;
+    int *bc = reinterpret_cast<int *>(b2 + nb1);
     auto sq = [&](int t) { return STAGE_SQ ? sqa[t] : val[t] * val[t]; };       // vals ** 2  (:649)
     const double *row = band_in + (int64_t)d * n;
     for (int t = threadIdx.x; t < nblk * BLK; t += kThreads) {
@@ -241,6 +244,33 @@ normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ 
         bc[q] = c;
     }
     __syncthreads();
+    if (PREFIX) {
+        // b1 / b2 / bc[q] -> sums of the blocks BEFORE q (nblk + 1 entries: the arrays are one longer in this form); three threads,
+        // one array each, a fixed serial order
+        if (threadIdx.x == 0) {
+            double run = 0.0;
+            for (int q = 0; q <= nblk; ++q) {
+                const double v = q < nblk ? b1[q] : 0.0;
+                b1[q] = run;
+                run = run + v;
+            }
+        } else if (threadIdx.x == 64) {
+            double run = 0.0;
+            for (int q = 0; q <= nblk; ++q) {
+                const double v = q < nblk ? b2[q] : 0.0;
+                b2[q] = run;
+                run = run + v;
+            }
+        } else if (threadIdx.x == 128) {
+            int run = 0;
+            for (int q = 0; q <= nblk; ++q) {
+                const int v = q < nblk ? bc[q] : 0;
+                bc[q] = run;
+                run += v;
+            }
+        }
+        __syncthreads();
+    }
     const double mean = diag_stats[4 * d + 0], sd = diag_stats[4 * d + 1], wgt = diag_stats[4 * d + 2];
     const double std2 = sd * sd;
     double *orow = band_out + (int64_t)d * n;
@@ -266,10 +296,16 @@ normalize_local_kernel(const double *__restrict__ band_in, double *__restrict__ 
                 }
                 s1 = h1;
                 s2 = h2;
-                for (int q = A / BLK; q < B / BLK; ++q) {   // whole aligned blocks
-                    c += bc[q];
-                    s1 = s1 + b1[q];
-                    s2 = s2 + b2[q];
+                if (PREFIX) {                              // whole aligned blocks: one difference of prefix sums
+                    c += bc[B / BLK] - bc[A / BLK];
+                    s1 = s1 + (b1[B / BLK] - b1[A / BLK]);
+                    s2 = s2 + (b2[B / BLK] - b2[A / BLK]);
+                } else {
+                    for (int q = A / BLK; q < B / BLK; ++q) {   // whole aligned blocks
+                        c += bc[q];
+                        s1 = s1 + b1[q];
+                        s2 = s2 + b2[q];
+                    }
                 }
                 double t1 = 0.0, t2 = 0.0;
                 for (int t = B; t < tb; ++t) {           // tail
@@ -982,7 +1018,7 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
         // SEG + W + 2 * 16 samples; beyond ~8400 bins: 1 double per sample and 64-sample blocks (see the kernel)
         auto lds_need = [&](size_t blk, size_t arrays) {
             const size_t nblk = (size_t)(kSeg + window + 2 * blk + blk - 1) / blk;
-            return sizeof(double) * (arrays * nblk * blk + 2 * nblk) + sizeof(int) * nblk + 16;
+            return sizeof(double) * (arrays * nblk * blk + 2 * (nblk + 1)) + sizeof(int) * (nblk + 1) + 16;
         };
         const size_t lds = window < 2 ? 0 : lds_need(kBlk, 2), lds_wide = window < 2 ? 0 : lds_need(kBlkWide, 1);
         const bool wide = lds > 160 * 1024;
@@ -996,14 +1032,14 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
         dim3 grid((unsigned)((n + kSeg - 1) / kSeg), nd);
         if (wide) {
             static unsigned long long lds_allowed_wide = 0;      // per device (mst_common.h)
-            MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&normalize_local_kernel<kBlkWide, false>), 160 * 1024,
+            MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&normalize_local_kernel<kBlkWide, false, true>), 160 * 1024,
                                            &lds_allowed_wide));
-            normalize_local_kernel<kBlkWide, false><<<grid, kThreads, lds_wide, s>>>(band_in, band_out, n, window, diag_stats);
+            normalize_local_kernel<kBlkWide, false, true><<<grid, kThreads, lds_wide, s>>>(band_in, band_out, n, window, diag_stats);
         } else {
             static unsigned long long lds_allowed = 0;
-            MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&normalize_local_kernel<kBlk, true>), 160 * 1024,
+            MST_HIP(mst::allow_dynamic_lds(reinterpret_cast<const void *>(&normalize_local_kernel<kBlk, true, false>), 160 * 1024,
                                            &lds_allowed));
-            normalize_local_kernel<kBlk, true><<<grid, kThreads, lds, s>>>(band_in, band_out, n, window, diag_stats);
+            normalize_local_kernel<kBlk, true, false><<<grid, kThreads, lds, s>>>(band_in, band_out, n, window, diag_stats);
         }
     } else {
         const int dlimit = (int64_t)dpx < n ? dpx : (int)n;     // range(min(distance_in_px, n))   (:674-675)

@@ -564,13 +564,15 @@ __global__ void __launch_bounds__(kGatherThreads)
 pair_gather_block_kernel(const mst_found *__restrict__ found, uint32_t found_cap, const uint32_t *__restrict__ found_count,
                          const double *__restrict__ ppair, int P, const uint32_t *__restrict__ sel_index,
                          const uint32_t *__restrict__ sel_pixel, const uint32_t *__restrict__ sel_count, uint32_t out_cap,
-                         double *__restrict__ out_pair, double *__restrict__ out_value, double *__restrict__ out_other, uint32_t H) {
+                         double *__restrict__ out_pair, double *__restrict__ out_value, double *__restrict__ out_other, uint32_t H,
+                         uint32_t max_selected) {
     extern __shared__ uint32_t gather_tab[];
     uint32_t *keys = gather_tab, *slots = gather_tab + H;
     constexpr uint32_t kEmpty = 0xFFFFFFFFu;               // no pixel index: CH * CH - 1 < 2^32 - 1
     const int fb = blockIdx.x, tid = threadIdx.x;
     const uint32_t sc = sel_count[fb];                     // MST_BH_RETRY: the selection of this block has not happened yet
-    const uint32_t nsel = sc == MST_BH_RETRY ? 0u : (sc < out_cap ? sc : out_cap);
+    const uint32_t lim = out_cap < max_selected ? out_cap : max_selected;      // (the table holds 2 * max_selected keys)
+    const uint32_t nsel = sc == MST_BH_RETRY ? 0u : (sc < lim ? sc : lim);
     if (nsel == 0) return;
     for (uint32_t i = tid; i < H; i += kGatherThreads) keys[i] = kEmpty;
     __syncthreads();
@@ -609,11 +611,15 @@ extern "C" int mst_pair_gather(const mst_found *found, uint32_t found_cap, const
         !out_other || P <= 0 || 2 * P > 65535 || found_cap == 0 || out_cap == 0 || max_selected > out_cap)
         return mst::fail(MST_E_ARG, "mst_pair_gather: bad argument");
     if (max_selected == 0) return MST_OK;
-    if (out_cap <= 4096) {                                  // the table fits the default 64 KB of dynamic LDS
+    if (max_selected <= 4096) {
+        // the table is sized by the largest selection, not by the capacity: in a pipelined run this kernel starts while the NEXT
+        // group's fused kernel holds 2 x 77 KB of every CU's LDS, and a workgroup asking for more than the few KB left over
+        // waits until a fused workgroup retires (a 64 KB request cost the two-sample genome run its overlap: 0.077 -> 0.094 s)
         uint32_t H = 64;
-        while (H < 2 * out_cap) H <<= 1;
+        while (H < 2 * max_selected) H <<= 1;
         pair_gather_block_kernel<<<2 * P, kGatherThreads, sizeof(uint32_t) * 2 * H, mst::as_stream(stream)>>>(
-            found, found_cap, found_count, ppair, P, sel_index, sel_pixel, sel_count, out_cap, out_pair, out_value, out_other, H);
+            found, found_cap, found_count, ppair, P, sel_index, sel_pixel, sel_count, out_cap, out_pair, out_value, out_other, H,
+            max_selected);
         MST_LAUNCH_CHECK();
         return MST_OK;
     }

@@ -363,7 +363,7 @@ namespace {
 int bh_select_impl(const mst_found *found, const double *pval, const uint32_t *count, int32_t B, uint32_t cap,
                    double threshold, uint32_t out_cap, uint32_t *out_pixel, uint32_t *out_level, double *out_q,
                    uint32_t *out_count, uint32_t *out_index, void *workspace, uint64_t workspace_bytes, void *stream,
-                   bool nowait = false) {
+                   uint32_t nowait_records = 0) {
     if (!found || !pval || !count || !out_pixel || !out_level || !out_q || !out_count || !workspace || B <= 0 ||
         B > 65535 || cap == 0 || out_cap == 0 || (size_t)B * cap > 0x7FFFFFFFull)
         return mst::fail(MST_E_ARG, "mst_bh_select: bad argument (B * cap must fit in int32)");
@@ -402,12 +402,12 @@ int bh_select_impl(const mst_found *found, const double *pval, const uint32_t *c
     compact_below_kernel<<<dim3(gx, B), 256, 0, s>>>(pval, count, cap, thr, keys_in, idx_in, k_sub);
     MST_LAUNCH_CHECK();
     // 3. sort + BH + selection: in LDS when every block's subset fits (the normal case), else the segmented radix sort
-    if (nowait) {
-        // no look at the subset sizes: the in-LDS sort sized for the largest subset it takes; a block with a larger one
-        // reports MST_BH_RETRY instead of a count
-        bh_select_lds_kernel<<<B, kBH, sort_lds_bytes(kSortMax), s>>>(keys_in, idx_in, k_sub, count, cap, found, threshold,
-                                                                     out_cap, out_pixel, out_level, out_q, out_count, out_index,
-                                                                     (uint32_t)kSortMax);
+    if (nowait_records) {
+        // no look at the subset sizes: the in-LDS sort sized for the subset the CALLER expects (its LDS request decides whether
+        // the kernel finds room next to a running fused kernel, see above); a block with a larger one reports MST_BH_RETRY
+        bh_select_lds_kernel<<<B, kBH, sort_lds_bytes(nowait_records), s>>>(keys_in, idx_in, k_sub, count, cap, found, threshold,
+                                                                           out_cap, out_pixel, out_level, out_q, out_count,
+                                                                           out_index, nowait_records);
         MST_LAUNCH_CHECK();
         return MST_OK;
     }
@@ -456,9 +456,11 @@ extern "C" int mst_bh_select_records(const mst_found *found, const double *pval,
 extern "C" int mst_bh_select_nowait(const mst_found *found, const double *pval, const uint32_t *count, int32_t B,
                                     uint32_t cap, double threshold, uint32_t out_cap, uint32_t *out_pixel,
                                     uint32_t *out_level, double *out_q, uint32_t *out_index, uint32_t *out_count,
-                                    void *workspace, uint64_t workspace_bytes, void *stream) {
+                                    uint32_t lds_records, void *workspace, uint64_t workspace_bytes, void *stream) {
+    if (lds_records < 2 || lds_records > (uint32_t)kSortMax || (lds_records & (lds_records - 1)))
+        return mst::fail(MST_E_ARG, "mst_bh_select_nowait: lds_records must be a power of two in [2, %d]", kSortMax);
     return bh_select_impl(found, pval, count, B, cap, threshold, out_cap, out_pixel, out_level, out_q, out_count, out_index,
-                          workspace, workspace_bytes, stream, true);
+                          workspace, workspace_bytes, stream, lds_records);
 }
 
 extern "C" int mst_select_below(const mst_found *found, const double *q, const uint32_t *found_count, int32_t B,

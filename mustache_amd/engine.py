@@ -328,6 +328,7 @@ class ScaleSpaceEngine:
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.levels = LevelTable(octave_values, s)
         self._select_cap = 4096
+        self._bh_lds_records = 1024     # LDS sort size of mst_bh_select_nowait (doubles when a launch reports MST_BH_RETRY)
         self._prefetch_guess = {}       # CH -> record columns mst_found_finish copies to the host speculatively
         self._buffers = {}              # small launch buffer sets kept for reuse (_carve)
         self._starts_arrays, self._ws_bytes = {}, {}
@@ -669,9 +670,12 @@ class ScaleSpaceEngine:
                     idx = torch.empty((B, cap), dtype=torch.int32, device=self.device) if pair is not None else None
                     args = (_ptr(found), _ptr(pval), _ptr(count), B, found_cap, pt, cap, _ptr(pix), _ptr(lvl), _ptr(qs),
                             None if idx is None else _ptr(idx), _ptr(n_sel), _ptr(ws), ws_bytes, _stream())
-                    _lib.check(self.lib.mst_bh_select_nowait(*args))
+                    # the sort's LDS request: 1024 records (14 KB) until a launch of this engine needed more -- this kernel runs
+                    # next to the following group's fused kernel, which leaves little LDS free
+                    _lib.check(self.lib.mst_bh_select_nowait(*(args[:12] + (self._bh_lds_records,) + args[12:])))
                 n_h = n_sel.cpu().numpy().view(np.uint32).astype(np.int64)
-                if not full_sort and (n_h == 0xFFFFFFFF).any():       # MST_BH_RETRY: the segmented radix sort takes the launch
+                if not full_sort and (n_h == 0xFFFFFFFF).any():       # MST_BH_RETRY: this launch through the synchronising form
+                    self._bh_lds_records = min(4096, self._bh_lds_records * 2)
                     if idx is not None:
                         _lib.check(self.lib.mst_bh_select_records(*args))
                     else:
@@ -981,7 +985,7 @@ class ScaleSpaceEngine:
             _lib.check(self.lib.mst_pair_pvalues_dog(_ptr(found), cap, _ptr(count), _ptr(dog), _ptr(nfit), P, CH, n_oct, tpo, off,
                                                      _ptr(ppair), _stream()))
         _lib.check(self.lib.mst_bh_select_nowait(_ptr(found), _ptr(pval), _ptr(count), B, cap, pt, sel, _ptr(pix), _ptr(lvl), _ptr(qs),
-                                                 _ptr(idx), _ptr(n_sel), _ptr(ws), ws_bytes, _stream()))
+                                                 _ptr(idx), _ptr(n_sel), self._bh_lds_records, _ptr(ws), ws_bytes, _stream()))
         _lib.check(self.lib.mst_pair_gather(_ptr(found), cap, _ptr(count), _ptr(ppair), int(P), _ptr(idx), _ptr(pix), _ptr(n_sel), sel,
                                             sel, _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _stream()))
         nfit_d.copy_(nfit)
@@ -999,6 +1003,8 @@ class ScaleSpaceEngine:
         if mx > sel:                                     # (MST_BH_RETRY = 0xFFFFFFFF included)
             if mx != 0xFFFFFFFF:
                 self._pair_sel_cap = mx * 2              # room for every selected record from the next call on
+            else:
+                self._bh_lds_records = min(4096, self._bh_lds_records * 2)
             return None
         _, nz_h, fit_h = self._parse_summary(summ, B)
         # the kernel appends in arbitrary order: ONE sort by (block, pixel) over the live slots (pixels are unique inside a block),

@@ -288,7 +288,7 @@ class Extra:
             tms.append(e0.elapsed_time(e1))
         var["normalize_window_9009"] = {"ms": round(sorted(tms)[1], 3), "samples": nw * 2002,
                                         "GB/s_on_16B_per_sample": round(16.0 * nw * 2002 / (sorted(tms)[1] * 1e-3) / 1e9, 1),
-                                        "kernel": "normalize_walk_kernel<1024,16> (128-VGPR cap, spills: correctness-only "
-                                                  "path for resolutions below ~238 bp)"}
+                                        "kernel": "normalize_local_kernel<32, samples only, prefix sums of the block sums> (windows "
+                                                  "8401-16384 bins = resolutions below ~238 bp; no scratch)"}
         del raww
         out["variants"] = var

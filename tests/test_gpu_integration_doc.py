@@ -52,3 +52,47 @@ def test_integration_md_ctypes_snippet_runs_and_matches_engine():
     assert np.array_equal((rec[:, 0] >> 32)[order], found[0]["level"].astype(np.int64))
     assert np.array_equal(rec[:, 1].view(np.float64)[order], found[0]["value"])
     assert np.array_equal(pvals, found[0]["pval"])
+
+
+def test_integration_md_raw_hic_snippet_runs_and_gives_the_packed_band(tmp_path):
+    """INTEGRATION.md section 3's RAW `.hic` read (mst_hic_rawstream_* + mst_band_scatter_hic_rows), executed as written behind
+    the section's first snippet (which opens the file) and section 2's helpers: the band it builds is the band of the host
+    decoder's packed read, bit for bit."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hic_writer import write_hic
+    from mustache_amd.hicfile import HicFile, read_intra_packed
+    from mustache_amd.normalize import band_from_packed
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec2 = text[text.index("## 2. Direct ctypes binding"):]
+    helpers = re.search(r"```python\n(.*?)```", sec2, re.S).group(1)
+    helpers = helpers[:helpers.index("# inside the reference's mustache(")]        # lib, ck, P, S
+    sec3 = text[text.index("## 3."):]
+    blocks = re.findall(r"```python\n(.*?)```", sec3, re.S)
+    opener = blocks[0][:blocks[0].index("px, py, pv =")]                           # io, h
+    raw = [b for b in blocks if "mst_hic_rawstream_open" in b]
+    assert len(raw) == 1
+    n, res, dpx = 6000, 1000, 2000
+    rng = np.random.default_rng(8)
+    x = rng.integers(0, n, 400000)
+    y = np.minimum(x + rng.integers(0, 2400, 400000), n - 2)        # the last bin holds no contact: the band is trimmed
+    key = np.unique(x * 100003 + y)
+    x, y = key // 100003, key % 100003
+    kr = rng.uniform(0.5, 2.0, n + 1)
+    kr[[7, 5000]] = np.nan
+    p = str(tmp_path / "sample.hic")
+    write_hic(p, [("All", 1), ("chr1", n * res)], {1: {res: (x, y, rng.integers(1, 50, len(x)).astype(np.float64))}},
+              {("KR", 1, res): kr}, version=8, block_bin_count=500, float_counts=False)
+    fix = lambda code: code.replace('ctypes.CDLL("mustache_amd/libmustache_hip.so")', 'ctypes.CDLL(os.path.join(ROOT, "mustache_amd", "libmustache_hip.so"))') \
+        .replace('ctypes.CDLL("mustache_amd/libmustache_io.so")', 'ctypes.CDLL(os.path.join(ROOT, "mustache_amd", "libmustache_io.so"))') \
+        .replace('b"sample.hic"', "PATH")
+    ns = dict(os=os, ROOT=ROOT, PATH=os.fsencode(p))
+    for code in (helpers, opener, raw[0]):
+        exec(compile(fix(code), "INTEGRATION.md", "exec"), ns)
+    torch.cuda.synchronize()
+    with HicFile(p) as h:
+        want = band_from_packed(read_intra_packed(h, "chr1", res, "KR", dpx, 0), dpx, torch.device("cuda", 0))
+    assert ns["n"] == want.shape[1] < n and torch.equal(ns["band"], want)
+    kept = int(ns["stats"][1])
+    assert kept == int((want != 0).sum()) > 100000 and int(ns["stats"][2]) == 0

@@ -452,9 +452,10 @@ def test_normalisation_kernel_vs_oracle_at_real_window_sizes(n, dpx, res, depth)
 
 
 def test_normalisation_window_beyond_the_blocked_kernel():
-    """Resolutions finer than ~240 bp give windows (2 Mb / res) of more than ~8400 bins, beyond what the blocked-sum kernel's
-    LDS holds; they run through the walking kernel's <1024, 16> instantiation (slow, correct) instead of being refused, as
-    the reference accepts any resolution.  Here: res = 222 bp -> window 9009 bins."""
+    """Resolutions finer than ~240 bp give windows (2 Mb / res) of more than ~8400 bins, beyond what the 16-sample-block kernel's
+    LDS holds; they run through its <32, samples only, prefix sums> form (no scratch; until round 4: a spilling instantiation
+    of the walking kernel) instead of being refused, as the reference accepts any resolution.  Here: res = 222 bp -> window
+    9009 bins, and res = 125 bp -> 16000 bins, the widest window served."""
     import oracle
     from mustache_amd.mustache import normalize_sparse
     from mustache_amd.synth import synth_coo
@@ -467,6 +468,14 @@ def test_normalisation_window_beyond_the_blocked_kernel():
     normalize_sparse(x, y, got, res, dpx)
     np.testing.assert_allclose(got, exp, rtol=1e-10, atol=1e-11)
     assert np.count_nonzero(got) > 0.9 * len(got)
+    n2, res2 = 40000, 125
+    assert int(2000000 / res2) == 16000
+    x, y, v = synth_coo(n2, 30, depth=25.0, seed=20)
+    exp = v.copy()
+    oracle.normalize_sparse(x, y, exp, res2, 30)
+    got = v.copy()
+    normalize_sparse(x, y, got, res2, 30)
+    np.testing.assert_allclose(got, exp, rtol=1e-10, atol=1e-11)
 
 
 def test_two_rank_cli_equals_one_process(golden_dir, tmp_path):

@@ -485,18 +485,18 @@ extern "C" int mst_diff_dog_band(const double *band1, const double *band2, int64
     int32_t *d_tiles = reinterpret_cast<int32_t *>(w);
     w += diff_align(sizeof(int32_t) * 2 * (size_t)diff_tiles<DiffTile28>(CH));
     double *partial = reinterpret_cast<double *>(w);
-    // the three tables the kernel reads -- levels, block origins, tile list -- lie side by side in the workspace: ONE upload
-    // (three staged copies, each with its dispatch gap, were 30 us in front of a 150 us kernel)
-    static thread_local std::vector<char> tab;
-    const size_t tab_bytes = (size_t)(reinterpret_cast<char *>(partial) - reinterpret_cast<char *>(d_lv));
-    tab.assign(tab_bytes, 0);
-    memcpy(tab.data(), &h, sizeof(h));
-    memcpy(tab.data() + (reinterpret_cast<char *>(d_starts) - reinterpret_cast<char *>(d_lv)), starts, sizeof(int64_t) * (size_t)B);
-    int32_t *h_tiles = reinterpret_cast<int32_t *>(tab.data() + (reinterpret_cast<char *>(d_tiles) - reinterpret_cast<char *>(d_lv)));
+    // three uploads, each small enough for the runtime's in-queue blit path.  (Round 5 tried ONE 26 KB upload of the three tables:
+    // 15 us less in front of the kernel of a six-pair call, but copies of that size go through the copy engine, where they
+    // queue behind this stream's fused kernels and hold up every later small copy of the OTHER streams -- the pipelined
+    // two-sample genome run lost its overlap, 0.077 -> 0.090 s; LABBOOK R5.5.)
+    static thread_local std::vector<int32_t> tiles_h;
+    tiles_h.resize(2 * (size_t)diff_tiles<DiffTile28>(CH));
     const int which = mr <= DiffTile8::RMAX ? 0 : (mr <= DiffTile14::RMAX ? 1 : 2);
-    const int m = which == 0 ? diff_tile_list<DiffTile8>(CH, dpx, h_tiles)
-                             : (which == 1 ? diff_tile_list<DiffTile14>(CH, dpx, h_tiles) : diff_tile_list<DiffTile28>(CH, dpx, h_tiles));
-    MST_HIP(mst::upload_small(d_lv, tab.data(), tab_bytes, s));
+    const int m = which == 0 ? diff_tile_list<DiffTile8>(CH, dpx, tiles_h.data())
+                             : (which == 1 ? diff_tile_list<DiffTile14>(CH, dpx, tiles_h.data()) : diff_tile_list<DiffTile28>(CH, dpx, tiles_h.data()));
+    MST_HIP(mst::upload_small(d_lv, &h, sizeof(h), s));
+    MST_HIP(mst::upload_small(d_starts, starts, sizeof(int64_t) * B, s));
+    MST_HIP(mst::upload_small(d_tiles, tiles_h.data(), sizeof(int32_t) * tiles_h.size(), s));
     MST_HIP(hipMemsetAsync(mask_count, 0, sizeof(uint32_t) * B, s));
     if (which == 0)
         return diff_dog_launch<DiffTile8>(band1, band2, n, dpx, d_starts, CH, B, d_lv, h.n_octaves, dog, partial, d_tiles, m,

@@ -75,7 +75,7 @@ def test_integration_md_raw_hic_snippet_runs_and_gives_the_packed_band(tmp_path)
     assert len(raw) == 1
     n, res, dpx = 6000, 1000, 2000
     rng = np.random.default_rng(8)
-    x = rng.integers(0, n, 400000)
+    x = rng.integers(0, n - 1, 400000)
     y = np.minimum(x + rng.integers(0, 2400, 400000), n - 2)        # the last bin holds no contact: the band is trimmed
     key = np.unique(x * 100003 + y)
     x, y = key // 100003, key % 100003

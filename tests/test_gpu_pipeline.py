@@ -468,7 +468,7 @@ def test_normalisation_window_beyond_the_blocked_kernel():
     normalize_sparse(x, y, got, res, dpx)
     np.testing.assert_allclose(got, exp, rtol=1e-10, atol=1e-11)
     assert np.count_nonzero(got) > 0.9 * len(got)
-    n2, res2 = 40000, 125
+    n2, res2 = 20000, 125                              # (the oracle's normalize_sparse is what takes the time here)
     assert int(2000000 / res2) == 16000
     x, y, v = synth_coo(n2, 30, depth=25.0, seed=20)
     exp = v.copy()

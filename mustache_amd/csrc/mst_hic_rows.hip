@@ -9,10 +9,10 @@
 //     NaN / -32768 holes) -> binX <= binY -> distance filter -> count / (norm[binX] * norm[binY]) in float64, rounded to
 //     float32 as straw does -> NaN / non-positive dropped -> chromosome-size limit -> band[binY - binX][binX] = (double)value
 // -- the arithmetic and the order of the tests of hic_reader.cpp's emit(), so the band is bit-identical to the host decode's.
-// One wavefront per row (a row of a 1 kb map holds a few hundred records: 6-byte records read as 16-bit halves, contiguous
-// across the lanes); the statistics (max binY + 1 kept, kept records, records the band cannot hold) are reduced per wave
-// with DPP and leave with one atomic each.  HBM-bound in principle, 14 bytes per record; in practice it runs under the
-// host's inflate (a 5 MB slab takes a few microseconds).
+// A workgroup per 8 rows, their records walked as one flat list (a row of a 1 kb map holds a few hundred records, some a
+// thousand: 6-byte records read as 16-bit halves, contiguous across the lanes); the statistics (max binY + 1 kept, kept records,
+// records the band cannot hold) are reduced per workgroup and leave with one atomic each.  HBM-bound in principle, 14 bytes per
+// record with the band written 8 bytes at a time into 2002 different rows; in practice it runs under the host's inflate.
 #include "mst_common.h"
 #include "../../include/mustache_hicrow.h"
 
@@ -37,36 +37,58 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 
 // VERIFY = false: scatter.  VERIFY = true: read-back -- counts the records whose pixel does not hold their value (a pixel
 // two records with different values were written to shows up for one of them whichever store won: malformed input).
+// A workgroup takes kRowsPerBlock consecutive rows and walks their records as ONE flat list (prefix of the row lengths in LDS,
+// the row of a record found by a short search): every lane has work whatever the row lengths are -- with a wavefront per row
+// (the first form) a slab took 78 us, its few 1000-record rows setting the pace and every wave paying a full reduction.
+constexpr int kRowsPerBlock = 8;
 template <bool VERIFY>
 __global__ void __launch_bounds__(kThreads)
 hic_rows_kernel(const uint8_t *__restrict__ payload, const mst_hic_row *__restrict__ rows, int n_rows,
                 const double *__restrict__ norm, long long n_norm, long long max_dist, long long y_limit, long long n, int dpx,
                 double *__restrict__ band, unsigned long long *__restrict__ stats) {
-    const int lane = threadIdx.x & 63;
-    const int waves = (int)((gridDim.x * (unsigned)kThreads) >> 6);
+    __shared__ mst_hic_row srow[kRowsPerBlock];
+    __shared__ int sbeg[kRowsPerBlock + 1];
+    __shared__ unsigned long long sred[4][kThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63;
     long long ymax1 = 0;                                  // max binY + 1 over the records this lane kept
     unsigned long long kept = 0, beyond = 0, bad = 0;
-    for (int r = (int)((blockIdx.x * (unsigned)kThreads + threadIdx.x) >> 6); r < n_rows; r += waves) {
-        const mst_hic_row e = rows[r];
-        const int cnt = (int)(e.count & MST_HIC_ROW_COUNT_MASK);
-        const bool short_c = e.count & MST_HIC_ROW_SHORT_COUNTS, int_x = e.count & MST_HIC_ROW_INT_COLUMNS,
-                   dense = e.count & MST_HIC_ROW_DENSE;
-        const int rec = (dense ? 0 : (int_x ? 4 : 2)) + (short_c ? 2 : 4);
-        const uint8_t *p = payload + e.off;
-        for (int j = lane; j < cnt; j += 64) {
-            const uint8_t *q = p + (size_t)j * rec;
+    for (int r0 = blockIdx.x * kRowsPerBlock; r0 < n_rows; r0 += gridDim.x * kRowsPerBlock) {
+        const int nr = n_rows - r0 < kRowsPerBlock ? n_rows - r0 : kRowsPerBlock;
+        __syncthreads();                                  // the previous group's tables are no longer read
+        if (tid < nr) srow[tid] = rows[r0 + tid];
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int i = 0; i < nr; ++i) {
+                sbeg[i] = run;
+                run += (int)(srow[i].count & MST_HIC_ROW_COUNT_MASK);
+            }
+            for (int i = nr; i <= kRowsPerBlock; ++i) sbeg[i] = run;
+        }
+        __syncthreads();
+        const int total = sbeg[kRowsPerBlock];
+        for (int i = tid; i < total; i += kThreads) {
+            int q = 0;
+#pragma unroll
+            for (int t = 1; t < kRowsPerBlock; ++t) q += (i >= sbeg[t]) ? 1 : 0;       // the row this record belongs to
+            const mst_hic_row e = srow[q];
+            const int j = i - sbeg[q];
+            const bool short_c = e.count & MST_HIC_ROW_SHORT_COUNTS, int_x = e.count & MST_HIC_ROW_INT_COLUMNS,
+                       dense = e.count & MST_HIC_ROW_DENSE;
+            const int rec = (dense ? 0 : (int_x ? 4 : 2)) + (short_c ? 2 : 4);
+            const uint8_t *q8 = payload + e.off + (size_t)j * rec;
             int x = j;
             if (!dense) {
-                x = int_x ? (int)ld32(q) : (int)(int16_t)ld16(q);
-                q += int_x ? 4 : 2;
+                x = int_x ? (int)ld32(q8) : (int)(int16_t)ld16(q8);
+                q8 += int_x ? 4 : 2;
             }
             float val;
             if (short_c) {
-                const int16_t s = (int16_t)ld16(q);
-                if (dense && s == -32768) continue;
-                val = (float)s;
+                const int16_t sv = (int16_t)ld16(q8);
+                if (dense && sv == -32768) continue;
+                val = (float)sv;
             } else {
-                val = __uint_as_float(ld32(q));
+                val = __uint_as_float(ld32(q8));
                 if (dense && val != val) continue;
             }
             long long bx = (long long)e.x_off + x, by = e.y;
@@ -97,15 +119,30 @@ hic_rows_kernel(const uint8_t *__restrict__ payload, const mst_hic_row *__restri
             }
         }
     }
+    // one reduction per workgroup: waves with DPP-free shuffles, then the first lanes over the waves; four atomics at most
     ymax1 = wave_max(ymax1);
     kept = wave_sum(kept);
     beyond = wave_sum(beyond);
     bad = wave_sum(bad);
     if (lane == 0) {
-        if (ymax1) atomicMax(&stats[0], (unsigned long long)ymax1);
-        if (kept) atomicAdd(&stats[1], kept);
-        if (beyond) atomicAdd(&stats[2], beyond);
-        if (bad) atomicAdd(&stats[3], bad);
+        sred[0][tid >> 6] = (unsigned long long)ymax1;
+        sred[1][tid >> 6] = kept;
+        sred[2][tid >> 6] = beyond;
+        sred[3][tid >> 6] = bad;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long m = 0, k = 0, o = 0, v = 0;
+        for (int w = 0; w < kThreads / 64; ++w) {
+            m = sred[0][w] > m ? sred[0][w] : m;
+            k += sred[1][w];
+            o += sred[2][w];
+            v += sred[3][w];
+        }
+        if (m) atomicMax(&stats[0], m);
+        if (k) atomicAdd(&stats[1], k);
+        if (o) atomicAdd(&stats[2], o);
+        if (v) atomicAdd(&stats[3], v);
     }
 }
 
@@ -119,9 +156,8 @@ extern "C" int mst_band_scatter_hic_rows(const void *payload, const void *rows, 
         return mst::fail(MST_E_ARG, "mst_band_scatter_hic_rows: bad argument (payload 2-byte, rows 4-byte aligned)");
     if (n_rows == 0) return MST_OK;
     hipStream_t s = mst::as_stream(stream);
-    const int per_block = kThreads / 64;
-    const int64_t want = ((int64_t)n_rows + per_block - 1) / per_block;
-    const int g = (int)(want < 16384 ? want : 16384);
+    const int64_t want = ((int64_t)n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
+    const int g = (int)(want < 4096 ? want : 4096);
     auto *st = reinterpret_cast<unsigned long long *>(stats);
     auto *rw = static_cast<const mst_hic_row *>(rows);
     auto *pl = static_cast<const uint8_t *>(payload);

@@ -192,7 +192,8 @@ diag_stats_kernel(const double *__restrict__ band, int64_t n, double *__restrict
 // and their block sums fit the 160 KB of LDS, and the block sums turned into exclusive PREFIX sums over the tile's <= 545
 // blocks, so that the whole blocks of a window cost one subtraction instead of up to 512 additions: head + tail <= 62 samples
 // per output).  Both stay far below 128 VGPRs: no scratch (the walking kernel's <1024, 16> form, which served these windows
-// until round 4, spilled 488 registers; this form is as fast: 9009-bin windows, 1.2e8 samples, see LABBOOK R5.6).
+// until round 4, spilled 488 registers and was 1.6 x faster all the same: 9009-bin windows on 1.2e8 samples 11.8 ms there, 19.0 ms
+// here -- the price of a kernel without scratch on a path for resolutions below 238 bp; LABBOOK R5.6).
 constexpr int kSeg = 1024;
 constexpr int kBlk = 16;
 constexpr int kBlkWide = 32;

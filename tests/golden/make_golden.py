@@ -390,6 +390,37 @@ def make_diff(name="diff_320", n=320, dpx=80, start=640, res=50000, nloops=30, p
     print(name, [len(o) for o in out], {k: v.shape for k, v in locs.items()})
 
 
+def make_diff_regulator(name="diff_regulator_5kb_3blocks", n=5200, dpx=400, res=5000, pt=0.1, pt2=0.2, st=0.8):
+    """The reference's own TWO-SAMPLE regulator() (diff_mustache.py:572-716) end to end at BASELINE config 5's geometry: two
+    text files at 5 kb, distance limit 400 bins -> both samples normalised (window 400), three blocks of 2000 x 2000 at stride
+    1600 ([0, 2000), [1600, 3600), right-aligned [3200, 5200)), diff_mustache() per block pair, the overlap masks, the four
+    tags.  ~4 min in the reference.  Stored: the generator's parameters + the sorted tagged rows [x, y, fdr, sigma, tag]."""
+    load_reference("mustache")
+    dref = load_reference("diff_mustache")
+    xa, ya, va = synth_coo(n, dpx, depth=300.0, seed=71)
+    xb, yb, vb = synth_coo(n, dpx, depth=260.0, seed=72)
+    sums = (float(va.sum()), float(vb.sum()), len(va), len(vb))
+    with tempfile.TemporaryDirectory() as td:
+        paths = []
+        for tag, (x, y, v) in (("a", (xa, ya, va)), ("b", (xb, yb, vb))):
+            fp = os.path.join(td, "s%s.txt" % tag)
+            with open(fp, "w") as f:
+                for a, b, c in zip(x, y, v):
+                    f.write("%d\t%d\t%r\n" % (a * res, b * res, float(c)))
+            paths.append(fp)
+        real = (dref.Process, dref.Manager)
+        dref.Process, dref.Manager = _InlineProcess, _PlainManager
+        try:
+            rows = dref.regulator(paths[0], paths[1], False, False, "out", res=res, pt=pt, pt2=pt2, st=st,
+                                  distance_filter=dpx * res, chromosome="S", nprocesses=1)
+        finally:
+            dref.Process, dref.Manager = real
+    out = np.array(sorted([float(r[0]), float(r[1]), float(r[2]), float(r[3]), float(r[4])] for r in rows)).reshape(-1, 5)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), n=n, dpx=dpx, res=res, pt=pt, pt2=pt2, st=st, seeds=np.array([71, 72]),
+                        depths=np.array([300.0, 260.0]), in_sums=np.array(sums), rows=out)
+    print("diff regulator rows", len(out), "per tag", [int((out[:, 4] == t).sum()) for t in (1, 2, 3, 4)])
+
+
 def make_krnorm(ref):
     """The one real data file the reference bundles, data/chr21_5kb.KRnorm (3 columns: chr21, position, KR bias of HMEC chr21
     at 5 kb; 9630 rows), through the reference's read_bias (mustache.py:218-251, the 3-column branch with `is_chr` and
@@ -549,6 +580,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if sys.argv[1:] == ["diff"]:
         make_diff()
+        sys.exit(0)
+    if sys.argv[1:] == ["diffregulator"]:   # the two-sample regulator() at config 5's geometry (~4 min in the reference)
+        make_diff_regulator()
         sys.exit(0)
     if sys.argv[1:] == ["diff2000"]:      # BASELINE config 5's block geometry (~1 min in the reference)
         make_diff("diff_2000", n=2000, dpx=400, start=3200, res=5000, nloops=None, pt=0.1, pt2=0.2, compact=True,

@@ -290,3 +290,30 @@ def test_diff_cli_from_hic_files_equals_cli_from_text(tmp_path):
             assert got == want, (name, suf, len(got), len(want))
             total += len(want)
     assert total > 30
+
+
+def test_diff_regulator_5kb_three_blocks_vs_reference(golden_dir, tmp_path):
+    """The reference's own two-sample regulator() (diff_mustache.py:572-716) at BASELINE config 5's geometry -- 5 kb, distance
+    limit 400 bins, three 2000 x 2000 block pairs at stride 1600 with a right-aligned last one, both samples normalised with
+    their 400-bin windows -- against regulator() of this package from the SAME two text files: the tagged rows (common loops of
+    each sample, differential loops of each) have identical coordinates, scales and tags, q within 1e-6."""
+    import pandas as pd
+    from mustache_amd.diff_mustache import regulator
+    from mustache_amd.synth import synth_coo
+    g = np.load(os.path.join(golden_dir, "diff_regulator_5kb_3blocks.npz"))
+    n, dpx, res = int(g["n"]), int(g["dpx"]), int(g["res"])
+    files = []
+    for k, (seed, depth) in enumerate(zip(g["seeds"], g["depths"])):
+        x, y, v = synth_coo(n, dpx, depth=float(depth), seed=int(seed))
+        assert len(v) == int(g["in_sums"][2 + k]) and float(v.sum()) == float(g["in_sums"][k]), "synthetic generator drifted"
+        f = str(tmp_path / ("s%d.txt" % k))
+        pd.DataFrame({"a": x * res, "b": y * res, "c": v}).to_csv(f, sep="\t", header=False, index=False)
+        files.append(f)
+    got = regulator(files[0], files[1], False, False, "unused", res=res, pt=float(g["pt"]), pt2=float(g["pt2"]), st=float(g["st"]),
+                    distance_filter=dpx * res, chromosome="S", verbose=False)
+    got = np.array(sorted([float(r[0]), float(r[1]), float(r[2]), float(r[3]), float(r[4])] for r in got)).reshape(-1, 5)
+    exp = g["rows"]
+    assert got.shape == exp.shape and len(exp) > 50 and all((exp[:, 4] == t).any() for t in (1, 2, 3, 4))
+    # sorted by (x, y, fdr, ...): rows that differ only in fdr digits keep their order as long as fdr agrees to 1e-6
+    assert np.array_equal(got[:, [0, 1, 3, 4]], exp[:, [0, 1, 3, 4]]), "coordinates, scales and tags must match the reference exactly"
+    np.testing.assert_allclose(got[:, 2], exp[:, 2], rtol=1e-6)

@@ -178,6 +178,32 @@ def test_regulator_headline_geometry(golden_dir):
     np.testing.assert_allclose(got[:, 2], exp[:, 2], rtol=1e-9)
 
 
+@pytest.mark.slow
+def test_diff_regulator_three_blocks(golden_dir):
+    """The oracle, block pair by block pair with the overlap masks and tags of diff_mustache.py:693-716, on the reference's own
+    two-sample regulator() run at config 5's geometry (5 kb, limit 400 bins, three 2000 x 2000 block pairs)."""
+    from mustache_amd.synth import synth_coo
+    g = _load(golden_dir, "diff_regulator_5kb_3blocks.npz")
+    n, dpx, res = int(g["n"]), int(g["dpx"]), int(g["res"])
+    coos = []
+    for seed, depth in zip(g["seeds"], g["depths"]):
+        x, y, v = synth_coo(n, dpx, depth=float(depth), seed=int(seed))
+        oracle.normalize_sparse(x, y, v, res, dpx)
+        coos.append((x, y, v))
+    CH, start, end = oracle.block_bounds(n, dpx)
+    rows = []
+    for i in range(len(start)):
+        cc = [oracle.dense_block(x, y, v, start[i], end[i], CH) for x, y, v in coos]
+        res4 = oracle.diff_block(cc[0], cc[1], start[i], dpx, OCT, float(g["st"]), float(g["pt"]), float(g["pt2"]))
+        mask = oracle.block_mask_size(i, start, end, dpx)
+        for tag, loops in enumerate(res4, start=1):
+            rows += [[float(lp[0]), float(lp[1]), float(lp[2]), float(lp[3]), float(tag)] for lp in loops
+                     if lp[0] >= start[i] + mask or lp[1] >= start[i] + mask]
+    got, exp = np.array(sorted(rows)).reshape(-1, 5), g["rows"]
+    assert got.shape == exp.shape and np.array_equal(got[:, [0, 1, 3, 4]], exp[:, [0, 1, 3, 4]])
+    np.testing.assert_allclose(got[:, 2], exp[:, 2], rtol=1e-9)
+
+
 def test_diff_block_vs_reference(golden_dir):
     """Two-sample path (diff_mustache.py:260-569): oracle == reference, every per-pixel array and all four lists."""
     g = _load(golden_dir, "diff_320.npz")

@@ -293,6 +293,15 @@ int mst_scale_space_band(const double *band, int64_t n, int32_t dpx, const int64
                          const mst_levels *lv, mst_found *found, uint32_t found_cap, uint32_t *found_count,
                          double *level_stats, uint32_t *nz_count, int32_t flags, void *workspace,
                          uint64_t workspace_bytes, void *stream);
+/* The same launch over blocks of TWO bands of one geometry (the two samples of diff_mustache.py:260-569, whose sigma loops
+ * are independent): blocks [0, split) are windows of band1, blocks [split, B) of band2; starts: host [B] (the second band's block
+ * origins usually repeat the first's; block `split` must not be a continuation of block split - 1: tiles are shared between
+ * consecutive overlapping blocks of ONE band).  One launch instead of two: one set of uploads, one launch tail -- what a
+ * latency-bound two-sample call on a few block pairs wants.  Everything else as mst_scale_space_band. */
+int mst_scale_space_band_pair(const double *band1, const double *band2, int32_t split, int64_t n, int32_t dpx,
+                              const int64_t *starts, int32_t B, int32_t CH, const mst_levels *lv, mst_found *found,
+                              uint32_t found_cap, uint32_t *found_count, double *level_stats, uint32_t *nz_count, int32_t flags,
+                              void *workspace, uint64_t workspace_bytes, void *stream);
 /* How many of a block's tiles mst_scale_space_band launches with MST_FLAG_SKIP_EMPTY (those whose pixels can reach the tested
  * band 4 <= col - row <= dpx + 1), on the block's own tile lattice; *tiles_total = all tiles of the block.  Host only. */
 int mst_scale_space_band_tiles(int32_t CH, int32_t dpx, const mst_levels *lv, int32_t *tiles_total);

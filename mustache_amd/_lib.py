@@ -75,6 +75,8 @@ _SIGNATURES = {
     "mst_blocks_from_band": (ctypes.c_int, [_p, _i64, _i32, ctypes.POINTER(_i64), _i32, _i32, _p, _p, _p, _p]),
     "mst_scale_space_band": (ctypes.c_int, [_p, _i64, _i32, ctypes.POINTER(_i64), _i32, _i32, ctypes.POINTER(MstLevels), _p,
                                             _u32, _p, _p, _p, _i32, _p, _u64, _p]),
+    "mst_scale_space_band_pair": (ctypes.c_int, [_p, _p, _i32, _i64, _i32, ctypes.POINTER(_i64), _i32, _i32, ctypes.POINTER(MstLevels),
+                                                 _p, _u32, _p, _p, _p, _i32, _p, _u64, _p]),
     "mst_candidate_features_band": (ctypes.c_int, [_p, _i64, _i32, _i64, _i32, _p, _p, _i32, _p, _p, _p, _p]),
     "mst_candidate_features_band_multi": (ctypes.c_int, [_p, _i64, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p]),
     "mst_gather_diagonals_band": (ctypes.c_int, [_p, _i64, _i32, _i64, _i32, _p, _i32, _p, _p]),

@@ -38,6 +38,7 @@
 // statistics), and with IEEE mode off v_max_f64 needs no canonicalising pre-pass; no value-changing fast-math
 // flag (reassociation, contraction, reciprocal) is enabled.
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -143,6 +144,8 @@ struct BandSrc {
     int dpx;
     const int64_t *starts;     // dev [B]: block origins
     uint32_t *nz_count;        // dev [B]: out, number of tested pixels per block
+    const double *band2;       // two-sample launches: blocks [split, B) are windows of this band (same n, dpx); else unused
+    int split;                 // first block of band2 (INT_MAX: one band)
 };
 
 // One workgroup's job: the tile whose region (interior + ring) starts at (y0, x0) of block b.  Consecutive blocks of a
@@ -252,6 +255,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
         const int64_t start = src.starts[b];
         const int64_t n = src.n;
         const int dpx = src.dpx;
+        const double *const bandp = b >= src.split ? src.band2 : src.band;       // (workgroup-uniform)
         uint8_t *nzb = reinterpret_cast<uint8_t *>(vb);      // [RGR][RGC] tested flags of the region; vb is free until the V pass
         const int Y0 = y0 - RMAX, X0 = x0 - RMAX;
         const bool inner = Y0 >= 0 && X0 >= 0 && Y0 + T::CTR <= CH && X0 + T::CTC <= CH;   // no reflection in this tile
@@ -284,7 +288,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
                     const int i_lo = dd < 0 ? -dd : 0;
                     const int i_hi = T::CTC - dd < T::CTR ? T::CTC - dd : T::CTR;
                     const bool in_band = q < ND && off >= 0 && off <= dpx + 1;
-                    const double *brow = src.band + (int64_t)(in_band ? off : 0) * n + start + Y0;
+                    const double *brow = bandp + (int64_t)(in_band ? off : 0) * n + start + Y0;
 #pragma unroll
                     for (int e = 0; e < PER; ++e) {
                         const int i = i_lo + (tid & 63) + 64 * e;
@@ -321,7 +325,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
                 const int by = reflect_idx(uy, CH), bx = reflect_idx(ux, CH);
                 const int off = bx - by;
                 double raw = 0.0;
-                if (off >= 0 && off <= dpx + 1 && start + bx < n) raw = src.band[(int64_t)off * n + start + by];
+                if (off >= 0 && off <= dpx + 1 && start + bx < n) raw = bandp[(int64_t)off * n + start + by];
                 ct[j * T::CTP + i] = (off <= 4 || off >= dpx + 1) ? 2.0 : raw;
                 const int ri = i - RMAX, rj = j - RMAX;
                 if (ri >= 0 && ri < RGR && rj >= 0 && rj < RGC) {
@@ -983,11 +987,11 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
         MST_HIP(hipGetDevice(&dev));
         std::vector<int64_t> sig;
         sig.reserve((size_t)B + 16);
-        for (const void *p : {(const void *)src.band, (const void *)found, (const void *)found_count, (const void *)level_stats,
-                              (const void *)src.nz_count, (const void *)workspace})
+        for (const void *p : {(const void *)src.band, (const void *)src.band2, (const void *)found, (const void *)found_count,
+                              (const void *)level_stats, (const void *)src.nz_count, (const void *)workspace})
             sig.push_back((int64_t)(intptr_t)p);
-        for (int64_t v : {(int64_t)src.n, (int64_t)src.dpx, (int64_t)B, (int64_t)CH, (int64_t)found_cap, (int64_t)flags,
-                          (int64_t)workspace_bytes, (int64_t)dev})
+        for (int64_t v : {(int64_t)src.n, (int64_t)src.dpx, (int64_t)src.split, (int64_t)B, (int64_t)CH, (int64_t)found_cap,
+                          (int64_t)flags, (int64_t)workspace_bytes, (int64_t)dev})
             sig.push_back(v);
         sig.insert(sig.end(), starts_host, starts_host + B);
         GraphEntry *ge = nullptr;
@@ -1178,7 +1182,7 @@ extern "C" int mst_scale_space(const double *c, const uint8_t *nz, int32_t B, in
                                mst_found *found, uint32_t found_cap, uint32_t *found_count, double *level_stats,
                                int32_t flags, void *workspace, uint64_t workspace_bytes, void *stream) {
     if (!c || !nz) return mst::fail(MST_E_ARG, "mst_scale_space: bad argument");
-    BandSrc none = {nullptr, 0, 0, nullptr, nullptr};
+    BandSrc none = {nullptr, 0, 0, nullptr, nullptr, nullptr, INT_MAX};
     return scale_space_impl<false>(c, nz, none, nullptr, B, CH, lv, found, found_cap, found_count, level_stats, flags,
                                    workspace, workspace_bytes, stream, "mst_scale_space");
 }
@@ -1189,7 +1193,21 @@ extern "C" int mst_scale_space_band(const double *band, int64_t n, int32_t dpx, 
                                     void *workspace, uint64_t workspace_bytes, void *stream) {
     if (!band || !starts || !nz_count || n <= 0 || dpx < 0)
         return mst::fail(MST_E_ARG, "mst_scale_space_band: bad argument");
-    BandSrc src = {band, n, dpx, nullptr, nz_count};
+    BandSrc src = {band, n, dpx, nullptr, nz_count, nullptr, INT_MAX};
     return scale_space_impl<true>(nullptr, nullptr, src, starts, B, CH, lv, found, found_cap, found_count, level_stats,
                                   flags, workspace, workspace_bytes, stream, "mst_scale_space_band");
+}
+
+extern "C" int mst_scale_space_band_pair(const double *band1, const double *band2, int32_t split, int64_t n, int32_t dpx,
+                                         const int64_t *starts, int32_t B, int32_t CH, const mst_levels *lv, mst_found *found,
+                                         uint32_t found_cap, uint32_t *found_count, double *level_stats, uint32_t *nz_count,
+                                         int32_t flags, void *workspace, uint64_t workspace_bytes, void *stream) {
+    if (!band1 || !band2 || !starts || !nz_count || n <= 0 || dpx < 0 || split < 1 || split >= B)
+        return mst::fail(MST_E_ARG, "mst_scale_space_band_pair: bad argument (0 < split < B)");
+    if (starts[split] > starts[split - 1] && starts[split] - starts[split - 1] < CH)
+        return mst::fail(MST_E_ARG, "mst_scale_space_band_pair: block %d (the second band's first) must not continue block %d "
+                         "(tiles are shared between CONSECUTIVE overlapping blocks of one band only)", split, split - 1);
+    BandSrc src = {band1, n, dpx, nullptr, nz_count, band2, split};
+    return scale_space_impl<true>(nullptr, nullptr, src, starts, B, CH, lv, found, found_cap, found_count, level_stats,
+                                  flags, workspace, workspace_bytes, stream, "mst_scale_space_band_pair");
 }

@@ -412,10 +412,12 @@ class ScaleSpaceEngine:
         packed = download and select_below is None and not sort
         return self._ss_results(self._ss_finish(st, packed=packed), download, sort, with_value, with_q, select_below)
 
-    def _ss_launch(self, c, nz, nz_count, skip_empty, found_cap, timing, fma, band_src, reuse=None, graph=False, out=None):
+    def _ss_launch(self, c, nz, nz_count, skip_empty, found_cap, timing, fma, band_src, reuse=None, graph=False, out=None, band2=None):
         """Allocate the outputs and enqueue the fused kernel on the current stream (no synchronisation).  `reuse`: see _carve.
         `out`: the caller's own buffers instead (dict ws, stats, fit, count, found, pval -- e.g. one sample's rows of buffers
-        that hold both samples of a two-sample call, so that ONE mst_found_finish serves both launches)."""
+        that hold both samples of a two-sample call, so that ONE mst_found_finish serves both launches).
+        `band2` = (second band, split): ONE launch over the blocks of two bands (the two samples of a two-sample call; band_src's
+        starts list holds all B origins, blocks [split, B) read the second band)."""
         if band_src is not None:
             band, bn, bdpx, bstarts, CH = band_src
             B = len(bstarts)
@@ -449,7 +451,12 @@ class ScaleSpaceEngine:
             # MST_FLAG_NO_SHARE (4): every tile once per block; default: tiles inside two consecutive blocks computed once
             # MST_FLAG_GRAPH (8): a launch that repeats with identical arguments is replayed as one hipGraph
             flags = (1 if skip_empty else 0) | (2 if fma else 0) | (0 if self.share_tiles else 4) | (8 if graph else 0)
-            if band_src is not None:
+            if band2 is not None:
+                # two-sample launch: blocks [split, B) are windows of the second band (mst_scale_space_band_pair)
+                _lib.check(self.lib.mst_scale_space_band_pair(_ptr(band), _ptr(band2[0]), int(band2[1]), bn, bdpx, st_arr, B, CH, lv,
+                                                              _ptr(found), found_cap, _ptr(count), _ptr(stats), _ptr(nz_count),
+                                                              flags, _ptr(ws), ws_bytes, _stream()))
+            elif band_src is not None:
                 _lib.check(self.lib.mst_scale_space_band(_ptr(band), bn, bdpx, st_arr, B, CH, lv, _ptr(found),
                                                          found_cap, _ptr(count), _ptr(stats), _ptr(nz_count), flags,
                                                          _ptr(ws), ws_bytes, _stream()))
@@ -880,14 +887,14 @@ class ScaleSpaceEngine:
         starts_i = [int(v) for v in starts]
         st_arr = (ctypes.c_int64 * P)(*starts_i)
         cap = self._found_cap.get(CH, max(4096, (CH * CH) // 32))
-        ws_bytes = self._ws_bytes.get((P, CH))
+        ws_bytes = self._ws_bytes.get((2 * P, CH))
         if ws_bytes is None:
-            ws_bytes = self._ws_bytes[(P, CH)] = int(self.lib.mst_scale_space_workspace_bytes(P, CH, lv))
+            ws_bytes = self._ws_bytes[(2 * P, CH)] = int(self.lib.mst_scale_space_workspace_bytes(2 * P, CH, lv))
         # A SMALL call (its buffers are kept between calls, _carve) repeats with identical arguments when the caller repeats it: the
         # two fused launches are then replayed as hipGraphs (MST_FLAG_GRAPH: uploads, counter zeroing, kernel, reduction in one
         # launch each, no dispatch gaps -- ~40 us of idle device before each kernel otherwise).  A graph cannot be captured on the
         # legacy default stream: such a call runs on the first side stream.
-        small = 2 * P * cap * 24 + 2 * ws_bytes < (200 << 20)
+        small = 2 * P * cap * 24 + ws_bytes < (200 << 20)
         cur = torch.cuda.current_stream(self.device)
         side = None
         if small and cur.cuda_stream == 0:
@@ -899,16 +906,15 @@ class ScaleSpaceEngine:
                 # ONE set of record buffers for both samples (sample 1 in rows [0, P), sample 2 in [P, 2P)): the two fused
                 # launches write their halves, one mst_found_finish (one synchronisation) serves both, and nothing has to be
                 # concatenated afterwards.  Small sets are kept between calls (_carve).
-                found, pval, count, stats, fit, nzc, ws1, ws2 = self._carve(
+                found, pval, count, stats, fit, nzc, ws = self._carve(
                     (2 * P * cap * 16, torch.int64, (2 * P, cap, 2)), (2 * P * cap * 8, torch.float64, (2 * P, cap)),
                     (2 * P * 4, torch.int32, (2 * P,)), (2 * P * T * 16, torch.float64, (2 * P, T, 2)),
                     (2 * P * T * 16, torch.float64, (2 * P, T, 2)), (2 * P * 4, torch.int32, (2 * P,)),
-                    (ws_bytes, torch.uint8, (ws_bytes,)), (ws_bytes, torch.uint8, (ws_bytes,)), reuse=("pairs", 0))
-                for k, (bd, ws) in enumerate(zip(bands, (ws1, ws2))):
-                    sl = slice(k * P, (k + 1) * P)
-                    self._ss_launch(None, None, nzc[sl], skip_empty, cap, None, False, (bd, int(n), int(dpx), starts_i, int(CH)),
-                                    out=dict(ws=ws, stats=stats[sl], fit=fit[sl], count=count[sl], found=found[sl], pval=pval[sl]),
-                                    graph=small)
+                    (ws_bytes, torch.uint8, (ws_bytes,)), reuse=("pairs", 0))
+                # ... filled by ONE fused launch over the 2P blocks (mst_scale_space_band_pair: sample 2's blocks read its own band)
+                self._ss_launch(None, None, nzc, skip_empty, cap, None, False, (bands[0], int(n), int(dpx), starts_i + starts_i, int(CH)),
+                                out=dict(ws=ws, stats=stats, fit=fit, count=count, found=found, pval=pval), graph=small,
+                                band2=(bands[1], P))
                 if dog is None:
                     # the difference kernel needs the bands only: queued behind the sigma loops, before anything is waited for
                     dog = torch.empty((n_oct, P, CH, CH), dtype=torch.float64, device=self.device)

@@ -317,3 +317,42 @@ def test_diff_regulator_5kb_three_blocks_vs_reference(golden_dir, tmp_path):
     # sorted by (x, y, fdr, ...): rows that differ only in fdr digits keep their order as long as fdr agrees to 1e-6
     assert np.array_equal(got[:, [0, 1, 3, 4]], exp[:, [0, 1, 3, 4]]), "coordinates, scales and tags must match the reference exactly"
     np.testing.assert_allclose(got[:, 2], exp[:, 2], rtol=1e-6)
+
+
+def test_pair_launch_equals_each_samples_own_launch():
+    """mst_scale_space_band_pair (ONE fused launch over both samples' blocks, what run_band_pairs queues) == mst_scale_space_band
+    on each sample alone: same records per block, same tested-pixel counts -- on overlapping blocks, where tiles are shared
+    inside a sample and must not be across the split.  And the entry refuses a split inside a run of overlapping blocks."""
+    import ctypes
+    import torch
+    from mustache_amd import _lib
+    from mustache_amd.engine import ScaleSpaceEngine
+    from mustache_amd.normalize import band_from_coo
+    from mustache_amd.synth import synth_coo
+    n, dpx, CH = 4300, 300, 2000
+    starts = [0, 1000, 2000, 2300]
+    dev = torch.device("cuda:0")
+    bands = []
+    for seed, depth in ((71, 300.0), (72, 240.0)):
+        x, y, v = synth_coo(n, dpx, depth=depth, seed=seed)
+        bands.append(band_from_coo(torch.as_tensor(x, device=dev), torch.as_tensor(y, device=dev), torch.as_tensor(v, device=dev), n, dpx))
+    eng = ScaleSpaceEngine(OCT)
+    pair = eng.run_band_pairs(bands, n, dpx, starts, CH)
+    P = len(starts)
+    total = 0
+    for k, band in enumerate(bands):
+        recs, fits, nzc = eng.sigma_loop_band(band, n, dpx, starts, CH)
+        assert np.array_equal(nzc.cpu().numpy(), np.asarray(pair.nz_count[k * P:(k + 1) * P]))
+        for b in range(P):
+            one, two = recs[b], pair.found[k * P + b]
+            assert np.array_equal(one["pixel"], two["pixel"]) and np.array_equal(one["level"], two["level"])
+            assert np.array_equal(one["value"], two["value"])
+            total += len(one["pixel"])
+    assert total > 2000
+    assert eng.band_items(starts, CH, dpx, skip_empty=True)[2] > 0          # sharing was on inside each sample
+    lib = _lib.load()
+    st = (ctypes.c_int64 * 4)(0, 1000, 2000, 3000)
+    nzc = torch.zeros(4, dtype=torch.int32, device=dev)
+    rc = lib.mst_scale_space_band_pair(bands[0].data_ptr(), bands[1].data_ptr(), 2, n, dpx, st, 4, CH, ctypes.byref(eng._lv_struct),
+                                       None, 0, None, None, nzc.data_ptr(), 0, None, 0, None)
+    assert rc == _lib.MST_E_ARG and b"split" in lib.mst_last_error()

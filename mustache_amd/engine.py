@@ -466,7 +466,7 @@ class ScaleSpaceEngine:
             if ev is not None:
                 ev[1].record()
         return dict(args=(c, nz, nz_count, skip_empty, timing, fma, band_src), B=B, CH=CH, found_cap=found_cap, ws=ws,
-                    stats=stats, fit=fit, count=count, found=found, pval=pval, ev=ev, reuse=reuse, graph=graph)
+                    stats=stats, fit=fit, count=count, found=found, pval=pval, ev=ev, reuse=reuse, graph=graph, band2=band2)
 
     def _carve(self, *parts, reuse=None):
         """Device buffers for one launch: parts = (bytes, dtype, shape).  `reuse` (a hashable key, or None): SMALL sets (< 256 MB)
@@ -544,7 +544,8 @@ class ScaleSpaceEngine:
                     c, nz, nz_count, skip_empty, timing, fma, band_src = st["args"]
                     cap = st["found_cap"] * 4   # rare: a block with an unusually dense set of local maxima
                     self._found_cap[st["CH"]] = cap
-                    st = self._ss_launch(c, nz, nz_count, skip_empty, cap, timing, fma, band_src, reuse=st.get("reuse"))
+                    st = self._ss_launch(c, nz, nz_count, skip_empty, cap, timing, fma, band_src, reuse=st.get("reuse"),
+                                         band2=st.get("band2"))
         if st["ev"] is not None:
             st["args"][4].append(st["ev"])      # mst_found_finish synchronised the stream: the events are complete
         st["count_h"], st["nz_h"], st["fit_h"] = self._parse_summary(summ, B)
@@ -1057,10 +1058,11 @@ class ScaleSpaceEngine:
             P = len(starts)
             with torch.cuda.stream(s), torch.cuda.device(self.device):
                 cap = self._found_cap.get(CH, max(4096, (CH * CH) // 32))
-                nzcs = [torch.empty(P, dtype=torch.int32, device=self.device) for _ in bands]
-                sts = [self._ss_launch(None, None, nzc, skip_empty, cap, None, False,
-                                       (bd, int(n), int(dpx), [int(v) for v in starts], int(CH)))
-                       for bd, nzc in zip(bands, nzcs)]
+                nzc = torch.empty(2 * P, dtype=torch.int32, device=self.device)
+                st2 = [int(v) for v in starts]
+                # both samples' blocks in ONE fused launch (rows [0, P) sample 1, [P, 2P) sample 2: mst_scale_space_band_pair)
+                sst = self._ss_launch(None, None, nzc, skip_empty, cap, None, False, (bands[0], int(n), int(dpx), st2 + st2, int(CH)),
+                                      band2=(bands[1], P))
                 # the difference kernel needs the bands only: queue it behind the sigma loops right away
                 st_arr = (ctypes.c_int64 * P)(*[int(v) for v in starts])
                 dog = torch.empty((n_oct, P, CH, CH), dtype=torch.float64, device=self.device)
@@ -1071,27 +1073,24 @@ class ScaleSpaceEngine:
                 _lib.check(self.lib.mst_diff_dog_band(_ptr(bands[0]), _ptr(bands[1]), int(n), int(dpx), st_arr, P, CH, lv,
                                                       _ptr(dog), _ptr(nfit), _ptr(mcount), _ptr(ws), ws_bytes, _stream()))
                 launch.prev_done = s.record_event()
-            return dict(stream=s, starts=starts, cap=cap, nzcs=nzcs, sts=sts, dog=dog, nfit=nfit, keep=(ws, mcount, st_arr))
+            return dict(stream=s, starts=starts, cap=cap, nzc=nzc, sst=sst, dog=dog, nfit=nfit, keep=(ws, mcount, st_arr))
 
         def collect(g):
             P = len(g["starts"])
             with torch.cuda.stream(g["stream"]), torch.cuda.device(self.device):
-                sts = [self._ss_finish(st) for st in g["sts"]]
-                if {st["found_cap"] for st in sts} != {g["cap"]}:
-                    # a record-capacity overflow re-ran a sample with more room: redo this group the plain way
+                st = self._ss_finish(g["sst"])
+                if st["found_cap"] != g["cap"]:
+                    # a record-capacity overflow re-ran the launch with more room: redo this group the plain way
                     return self.run_band_pairs(bands, n, dpx, g["starts"], CH, skip_empty=skip_empty, select_below=select_below)
                 cap = g["cap"]
-                found = torch.cat([st["found"] for st in sts])
-                pval = torch.cat([st["pval"] for st in sts])
-                count = torch.cat([st["count"] for st in sts])
-                fit = torch.cat([st["fit"] for st in sts])
+                found, pval, count, fit = st["found"], st["pval"], st["count"], st["fit"]
                 ppair = torch.empty((2 * P, cap), dtype=torch.float64, device=self.device)
                 for off in (0, P):
                     _lib.check(self.lib.mst_pair_pvalues_dog(_ptr(found), cap, _ptr(count), _ptr(g["dog"]), _ptr(g["nfit"]), P, CH,
                                                              n_oct, tpo, off, _ptr(ppair), _stream()))
                 recs, fits = self._download_selected(found, pval, count, fit, self.levels.n_tested, cap, float(select_below),
                                                      pair=(ppair, P))
-                nz_h = np.concatenate([st["nz_h"] for st in sts])
+                nz_h = st["nz_h"]
                 norm_fit = g["nfit"].cpu().numpy()
             batch = PairBandBatch(self, bands, n, dpx, g["starts"], CH, nz_h, recs, fits)
             batch.norm_fit = norm_fit

@@ -338,13 +338,15 @@ def test_pair_launch_equals_each_samples_own_launch():
         bands.append(band_from_coo(torch.as_tensor(x, device=dev), torch.as_tensor(y, device=dev), torch.as_tensor(v, device=dev), n, dpx))
     eng = ScaleSpaceEngine(OCT)
     pair = eng.run_band_pairs(bands, n, dpx, starts, CH)
+    pair_found = [{k: np.array(v) for k, v in r.items()} for r in pair.found]      # (views of staging memory that the engine's
+    pair_nz = np.array(pair.nz_count)                                              #  second-next download reuses: keep copies)
     P = len(starts)
     total = 0
     for k, band in enumerate(bands):
         recs, fits, nzc = eng.sigma_loop_band(band, n, dpx, starts, CH)
-        assert np.array_equal(nzc.cpu().numpy(), np.asarray(pair.nz_count[k * P:(k + 1) * P]))
+        assert np.array_equal(nzc.cpu().numpy(), pair_nz[k * P:(k + 1) * P])
         for b in range(P):
-            one, two = recs[b], pair.found[k * P + b]
+            one, two = recs[b], pair_found[k * P + b]
             assert np.array_equal(one["pixel"], two["pixel"]) and np.array_equal(one["level"], two["level"])
             assert np.array_equal(one["value"], two["value"])
             total += len(one["pixel"])
@@ -355,4 +357,23 @@ def test_pair_launch_equals_each_samples_own_launch():
     nzc = torch.zeros(4, dtype=torch.int32, device=dev)
     rc = lib.mst_scale_space_band_pair(bands[0].data_ptr(), bands[1].data_ptr(), 2, n, dpx, st, 4, CH, ctypes.byref(eng._lv_struct),
                                        None, 0, None, None, nzc.data_ptr(), 0, None, 0, None)
-    assert rc == _lib.MST_E_ARG and b"split" in lib.mst_last_error()
+    assert rc == _lib.MST_E_ARG and b"must not continue" in lib.mst_last_error()
+    # a record capacity that is far too small: the pair launch is re-run with more room (both bands again), single call and
+    # pipelined groups alike
+    small = ScaleSpaceEngine(OCT)
+    small._found_cap[CH] = 128
+    again = small.run_band_pairs(bands, n, dpx, starts, CH)
+    assert small._found_cap[CH] > 128
+    for b in range(2 * P):
+        assert np.array_equal(again.found[b]["pixel"], pair_found[b]["pixel"]) and np.array_equal(again.found[b]["q"], pair_found[b]["q"])
+    groups = [starts[:2], starts[2:]]
+    want = []
+    for g in groups:
+        w = eng.run_band_pairs(bands, n, dpx, g, CH, select_below=0.5)
+        want.append([{k: np.array(v) for k, v in r.items()} for r in w.found])
+    small = ScaleSpaceEngine(OCT)
+    small._found_cap[CH] = 128
+    for got, ref in zip(small.run_band_pairs_overlapped(bands, n, dpx, groups, CH, select_below=0.5), want):
+        assert len(got.found) == len(ref)
+        for a, b in zip(got.found, ref):
+            assert len(a["pixel"]) > 0 and np.array_equal(a["pixel"], b["pixel"]) and np.array_equal(a["pair"], b["pair"])

@@ -4,6 +4,7 @@ PyTorch is plumbing here (device memory, streams); every number is produced by l
 library or a missing GPU is an error -- there is no CPU path in this package.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -319,6 +320,24 @@ class PairBandBatch(_MultiGather):
                                                        ks, m, out, _stream()))
 
 
+_GC_SETTLED = False
+
+
+def settle_gc():
+    """Once per process: move everything alive now (the modules of torch, numpy, this package: ~10^6 objects that never die) out
+    of the cyclic collector's reach (`gc.freeze()`).  A chromosome's host tail makes ~2 * 10^4 short-lived containers (one
+    4-element list per loop, as the reference returns them), so CPython ran a full collection every third chromosome and each
+    one walked all of those objects: +27-38 ms on a 55-75 ms step, exactly periodic (scripts/pair_genome_jitter.py,
+    scripts/file_leg_cpu.py; LABBOOK R5.8).  Results do not depend on it; MUSTACHE_GC_FREEZE=0 leaves the collector alone."""
+    global _GC_SETTLED
+    if _GC_SETTLED or os.environ.get("MUSTACHE_GC_FREEZE", "1") == "0":
+        return
+    import gc
+    gc.collect()
+    gc.freeze()
+    _GC_SETTLED = True
+
+
 class ScaleSpaceEngine:
     """Owns the level table and runs rows 2-7 of SURVEY.md section 8a on the GPU."""
 
@@ -337,6 +356,7 @@ class ScaleSpaceEngine:
         self._found_cap = {}
         self._pin = {}
         self._pin_flip = 0
+        settle_gc()
 
     # ---- host queries of the launch geometry (no GPU work) --------------------------------------------------------
     def band_tile_fraction(self, CH, dpx):

@@ -31,6 +31,14 @@ def main():
     from mustache_amd.normalize import band_from_packed, normalize_band, read_hic_stream_to_device
     passes = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     dev = torch.device("cuda:0")
+    import gc
+    mode = os.environ.get("MST_GC", "")
+    if mode == "off":
+        gc.disable()
+    elif mode == "freeze":
+        gc.collect()
+        gc.freeze()
+    print("gc mode:", mode or "default", "thresholds", gc.get_threshold(), "tracked objects", len(gc.get_objects()))
     print("torch threads", torch.get_num_threads(), "cpu.max", open("/sys/fs/cgroup/cpu.max").read().strip())
     w = bench.Workload("chr1@1kb synthetic", 248957, 2000, 1000, 400.0, 8000, 1, dev, 0, 1)
     tmp = tempfile.mkdtemp(prefix="mst_flc_")

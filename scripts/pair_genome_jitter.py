@@ -27,6 +27,14 @@ def main():
     from mustache_amd.diff_mustache import run_pair_layout
     calls = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     dev = torch.device("cuda:0")
+    import gc
+    mode = os.environ.get("MST_GC", "")
+    if mode == "off":
+        gc.disable()
+    elif mode == "freeze":
+        gc.collect()
+        gc.freeze()
+    print("gc mode:", mode or "default", "thresholds", gc.get_threshold(), "tracked objects", len(gc.get_objects()))
     print("torch threads", torch.get_num_threads(), "OMP_NUM_THREADS", os.environ.get("OMP_NUM_THREADS"))
     wg = bench_extra.genome_workload(bench, "hg19-shaped genome @5kb synthetic", 5000, 400, 300.0, 1000, dev, two_samples=True)
     for _ in range(3):

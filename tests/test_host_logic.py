@@ -304,3 +304,25 @@ def test_work_list_of_a_launch_matches_the_sharing_rule():
     t, s = ctypes.c_int64(0), ctypes.c_int64(0)
     it = lib.mst_scale_space_band_items(st, len(start), CH, 2000, ctypes.byref(lv), 0, ctypes.byref(t), ctypes.byref(s))
     assert 0.20 < s.value / t.value < 0.25 and it + s.value <= t.value
+
+
+def test_settle_gc_freezes_once_and_can_be_switched_off(monkeypatch):
+    """engine.settle_gc: everything alive at the first engine's construction leaves the cyclic collector's generations
+    (gc.freeze), once per process; MUSTACHE_GC_FREEZE=0 leaves the collector alone."""
+    import gc
+    from mustache_amd import engine
+    monkeypatch.setattr(engine, "_GC_SETTLED", False)
+    monkeypatch.setenv("MUSTACHE_GC_FREEZE", "0")
+    before = gc.get_freeze_count()
+    engine.settle_gc()
+    assert gc.get_freeze_count() == before and engine._GC_SETTLED is False
+    monkeypatch.setenv("MUSTACHE_GC_FREEZE", "1")
+    try:
+        engine.settle_gc()
+        frozen = gc.get_freeze_count()
+        assert frozen > before and engine._GC_SETTLED is True
+        junk = [[i] for i in range(1000)]               # objects made afterwards are collected as ever
+        engine.settle_gc()
+        assert gc.get_freeze_count() == frozen and len(junk) == 1000
+    finally:
+        gc.unfreeze()                                   # leave the test process as it was

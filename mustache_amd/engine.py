@@ -870,30 +870,6 @@ class ScaleSpaceEngine:
                                                      P, CH, n_oct, tpo, off, _ptr(ppair), _stream()))
         return ppair, fit
 
-    def pair_pvalues_band(self, band1, band2, n, dpx, starts, CH, found, found_cap, count):
-        """Band-direct form of pair_pvalues: the difference image and its G_2 / G_3 never reach HBM -- mst_diff_dog_band
-        writes D_2 = G_2 - G_3 of the difference image per octave and the norm.fit sums; found / count are the device records
-        of the two samples' sigma loops, sample 1 in [0, P), sample 2 in [P, 2P).  Returns (ppair [2P, found_cap], fit)."""
-        P = len(starts)
-        lt = self.levels
-        n_oct, tpo = len(lt.octave_values), lt.s - 1
-        dev = self.device
-        lv = ctypes.byref(self._lv_struct)
-        st_arr = (ctypes.c_int64 * P)(*[int(s) for s in starts])
-        with torch.cuda.device(dev):
-            dog = torch.empty((n_oct, P, CH, CH), dtype=torch.float64, device=dev)
-            fit = torch.empty((n_oct, P, 2), dtype=torch.float64, device=dev)
-            mcount = torch.empty(P, dtype=torch.int32, device=dev)
-            ws_bytes = int(self.lib.mst_diff_dog_workspace_bytes(P, CH, lv))
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            _lib.check(self.lib.mst_diff_dog_band(_ptr(band1), _ptr(band2), int(n), int(dpx), st_arr, P, CH, lv, _ptr(dog),
-                                                  _ptr(fit), _ptr(mcount), _ptr(ws), ws_bytes, _stream()))
-            ppair = torch.empty((2 * P, found_cap), dtype=torch.float64, device=dev)
-            for off in (0, P):
-                _lib.check(self.lib.mst_pair_pvalues_dog(_ptr(found), found_cap, _ptr(count), _ptr(dog), _ptr(fit), P, CH,
-                                                         n_oct, tpo, off, _ptr(ppair), _stream()))
-        return ppair, fit
-
     def run_band_pairs(self, bands, n, dpx, starts, CH, skip_empty=True, select_below=None):
         """Both samples' sigma loops straight from their bands + the pair p-values: PairBandBatch over 2P blocks whose
         records carry `pair` and `q`.  select_below = pt (what the per-chromosome driver passes): BH, the selection q < pt and

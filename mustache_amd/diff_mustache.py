@@ -115,12 +115,14 @@ def diff_mustache(c1, c2, chromosome, chromosome2, res, start, end, mask_size, d
     if c1.shape != c2.shape or c1.ndim != 2 or c1.shape[0] != c1.shape[1] or c1.dtype != np.float64 or c2.dtype != np.float64:
         raise ValueError("diff_mustache(): c1 and c2 must be square float64 arrays of the same shape")
     intra = chromosome == chromosome2
-    dev = torch.from_numpy(np.stack([c1, c2])).to(eng.device)
+    dev = torch.empty((2,) + c1.shape, dtype=torch.float64, device=eng.device)
+    dev[0].copy_(torch.from_numpy(np.ascontiguousarray(c1)))
+    dev[1].copy_(torch.from_numpy(np.ascontiguousarray(c2)))
     batch = eng.run_block_pairs(dev, distance_in_px, intra=intra)
     if batch.nz_count[0] >= 50 and batch.nz_count[1] >= 50:               # the reference returns before filling (:266-273)
-        filled = batch.c.cpu().numpy()
-        c1[...] = filled[0]
-        c2[...] = filled[1]
+        from .mustache import fill_like_reference                          # the same fills the device copies hold, on the host
+        fill_like_reference(c1, distance_in_px, intra)
+        fill_like_reference(c2, distance_in_px, intra)
     return _pair_tail(batch, 0, 1, start, pt, pt2, st, intra)
 
 

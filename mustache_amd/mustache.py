@@ -50,12 +50,30 @@ def mustache(c, chromosome, chromosome2, res, pval_weights, start, end, mask_siz
     c = np.asarray(c)
     if c.ndim != 2 or c.shape[0] != c.shape[1] or c.dtype != np.float64:
         raise ValueError("mustache(): c must be a square float64 array")
+    from .engine import BlockBatch
+    intra = chromosome == chromosome2
+    n = c.shape[0]
     dev = torch.from_numpy(np.ascontiguousarray(c)).to(eng.device).unsqueeze(0)
-    batch = eng.run_blocks(dev, distance_in_px, intra=(chromosome == chromosome2))
+    nz, nzc = eng.prologue(dev, distance_in_px, intra)
+    # BH and the selection q < pt on the device, only the selected records come back (what the per-chromosome driver does)
+    found, fits = eng.sigma_loop(dev, nz, nzc, with_value=False, select_below=pt)
+    batch = BlockBatch(eng, dev, nz, n, 1, nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
     if int(batch.nz_count[0]) < 50:
         return []                            # mustache.py:701-702 returns before the fills of :703-706: `c` stays untouched
-    c[...] = batch.c[0].cpu().numpy()
-    return block_tail(batch, 0, start, pt, st, intra=(chromosome == chromosome2))
+    # the caller's block gets the fills of mustache.py:703-706 written on the host -- the same values the device copy holds
+    # (tests/test_gpu_block.py), without 128 MB coming back over PCIe per 4000 x 4000 block
+    fill_like_reference(c, distance_in_px, intra)
+    return block_tail(batch, 0, start, pt, st, intra=intra)
+
+
+def fill_like_reference(c, distance_in_px, intra):
+    """The in-place fills of mustache.py:703-706 on the caller's host block: 2 on and below diagonal 4 and, within a
+    chromosome, from diagonal distance_in_px + 1 outwards."""
+    n = c.shape[0]
+    for r in range(n):
+        c[r, :min(n, r + 5)] = 2.0
+        if intra:
+            c[r, r + distance_in_px + 1:] = 2.0
 
 
 def process_block(i, start, end, overlap_size, cc, chromosome, chromosome2, res, pval_weights, distance_in_px,

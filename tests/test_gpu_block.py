@@ -93,6 +93,11 @@ def test_mustache_dropin_vs_reference_fixture(golden_dir, name):
     n, dpx, start = int(g["n"]), int(g["dpx"]), int(g["start"])
     loops = mustache(c, "1", "1", 5000, [], start, start + n, 0, dpx, OCT, float(g["st"]), float(g["pt"]))
     assert c.sum() == float(g["c_after_sum"]), "block must be mutated in place like the reference does"
+    import torch
+    from mustache_amd.engine import ScaleSpaceEngine
+    ref = torch.from_numpy(_dense(g)[None].copy()).cuda()
+    ScaleSpaceEngine(OCT).prologue(ref, dpx, True)
+    assert np.array_equal(ref[0].cpu().numpy(), c), "host-side fills == the device copy's fills (mst_block_prologue)"
     exp = g["loops"]
     assert len(loops) == len(exp) > 0
     got = np.array([[float(a), float(b), q, s] for a, b, q, s in loops])

@@ -140,6 +140,13 @@ def test_diff_mustache_dropin_vs_reference(golden_dir):
     out = diff_mustache(c1, c2, "1", "1", 5000, start, start + n, 0, dpx, OCT, float(g["st"]), float(g["pt"]),
                         float(g["pt2"]))
     assert c1[0, 0] == 2 and c2[5, 5] == 2, "both blocks are filled in place like the reference does"
+    # ... with exactly the values the device copies hold after mst_block_prologue (the fills are written on the host)
+    import torch
+    from mustache_amd.engine import ScaleSpaceEngine
+    r1, r2 = _blocks(g)
+    dev = torch.from_numpy(np.stack([r1, r2])).cuda()
+    ScaleSpaceEngine(OCT).prologue(dev, dpx, True)
+    assert np.array_equal(dev[0].cpu().numpy(), c1) and np.array_equal(dev[1].cpu().numpy(), c2)
     for got, key in zip(out, ("loops1", "diff1", "loops2", "diff2")):
         exp = g[key]
         arr = np.array([[float(a), float(b), q, s] for a, b, q, s in got]).reshape(-1, 4)

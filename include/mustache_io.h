@@ -180,6 +180,12 @@ int mst_hic_rawstream_close(mst_hic_rawstream *s, int64_t *rows_total, int64_t *
 int64_t mst_text_read_contacts(const char *path, char sep, const char *chrom, int32_t n_threads, int32_t *n_cols,
                                double **pos1, double **pos2, double **count);
 
+/* The in-place fills the reference's mustache() applies to its caller's dense block (mustache.py:703-706: `c[col - row <= 4] = 2`,
+ * and for chromosome == chromosome2 `c[col - row >= distance_in_px + 1] = 2`), written into a HOST block of n x n float64 whose rows
+ * are `row_stride` doubles apart -- so that the drop-in mustache(c, ...) does not have to bring the filled block back over PCIe
+ * (the device copy gets the same fills from mst_block_prologue; tests hold the two equal element for element). */
+int mst_host_fill_block(double *c, int64_t n, int64_t row_stride, int32_t dpx, int32_t intra, int32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

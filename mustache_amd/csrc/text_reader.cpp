@@ -349,3 +349,25 @@ extern "C" int64_t mst_text_read_contacts(const char *path, char sep, const char
     close(fd);
     return result;
 }
+
+// The in-place fills of the reference's mustache() on a caller's dense host block (mustache.py:703-706): 2 on and below
+// diagonal 4, and (within a chromosome) from diagonal dpx + 1 outwards.  Rows are `row_stride` doubles apart.
+extern "C" int mst_host_fill_block(double *c, int64_t n, int64_t row_stride, int32_t dpx, int32_t intra, int32_t n_threads) {
+    if (!c || n <= 0 || row_stride < n || dpx < 0) return mst_io::fail(MST_IO_E_ARG, "mst_host_fill_block: bad argument");
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads > 0 ? n_threads : 8, n / 256 + 1));
+    auto work = [&](int t) {
+        for (int64_t r = t; r < n; r += nt) {           // interleaved rows: the filled length grows with r
+            double *row = c + r * row_stride;
+            const int64_t lo = std::min<int64_t>(n, r + 5);
+            for (int64_t j = 0; j < lo; ++j) row[j] = 2.0;
+            if (intra)
+                for (int64_t j = r + (int64_t)dpx + 1; j < n; ++j) row[j] = 2.0;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    return MST_IO_OK;
+}
+

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "mst_text_read_contacts": (ctypes.c_int64, [ctypes.c_char_p, ctypes.c_char, ctypes.c_char_p, ctypes.c_int32,
                                                 ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_P), ctypes.POINTER(_P),
                                                 ctypes.POINTER(_P)]),
+    "mst_host_fill_block": (ctypes.c_int, [_P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
 }
 
 

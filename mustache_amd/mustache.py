@@ -70,7 +70,12 @@ def fill_like_reference(c, distance_in_px, intra):
     """The in-place fills of mustache.py:703-706 on the caller's host block: 2 on and below diagonal 4 and, within a
     chromosome, from diagonal distance_in_px + 1 outwards."""
     n = c.shape[0]
-    for r in range(n):
+    if c.strides[1] == 8 and c.strides[0] % 8 == 0 and c.strides[0] >= 8 * n and c.flags.writeable:
+        from . import hicfile                       # rows of contiguous doubles: the threaded form in libmustache_io.so
+        lib = hicfile.load()
+        hicfile._check(lib, lib.mst_host_fill_block(c.ctypes.data, n, c.strides[0] // 8, int(distance_in_px), 1 if intra else 0, 8))
+        return
+    for r in range(n):                              # any other layout (a transposed view, ...): NumPy row slices
         c[r, :min(n, r + 5)] = 2.0
         if intra:
             c[r, r + distance_in_px + 1:] = 2.0

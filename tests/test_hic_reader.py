@@ -34,8 +34,8 @@ def _sorted(x, y, v):
 def test_io_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(ROOT, "mustache_amd", "libmustache_io.so"))
     header = open(os.path.join(ROOT, "include", "mustache_io.h")).read()
-    names = set(re.findall(r"\b(mst_(?:io|hic|text)_\w+)\s*\(", header))
-    assert len(names) == 28
+    names = set(re.findall(r"\b(mst_(?:io|hic|text|host)_\w+)\s*\(", header))
+    assert len(names) == 29
     for n in names:
         assert hasattr(lib, n), n
     assert lib.mst_io_abi_version() == 3

@@ -326,3 +326,35 @@ def test_settle_gc_freezes_once_and_can_be_switched_off(monkeypatch):
         assert gc.get_freeze_count() == frozen and len(junk) == 1000
     finally:
         gc.unfreeze()                                   # leave the test process as it was
+
+
+def test_fill_like_reference_equals_numpy_row_slices():
+    """mustache.fill_like_reference (mst_host_fill_block for C-contiguous rows, NumPy slices otherwise) == the fills of
+    mustache.py:703-706 spelled as row slices, incl. views with a larger row stride and non-contiguous layouts."""
+    from mustache_amd.mustache import fill_like_reference
+
+    def spelled(c, dpx, intra):
+        n = c.shape[0]
+        for r in range(n):
+            c[r, :min(n, r + 5)] = 2.0
+            if intra:
+                c[r, r + dpx + 1:] = 2.0
+
+    rng = np.random.default_rng(5)
+    for n, dpx, intra in ((1, 0, True), (5, 0, True), (7, 2, False), (300, 50, True), (300, 500, True), (1025, 333, True)):
+        a = rng.uniform(size=(n, n))
+        b = a.copy()
+        fill_like_reference(a, dpx, intra)
+        spelled(b, dpx, intra)
+        assert np.array_equal(a, b), (n, dpx, intra)
+    big = rng.uniform(size=(80, 100))
+    view, rest = big[:, :80], big[:, 80:].copy()
+    want = view.copy()
+    fill_like_reference(view, 10, True)                 # rows 100 doubles apart
+    spelled(want, 10, True)
+    assert np.array_equal(view, want) and np.array_equal(big[:, 80:], rest)
+    f = np.asfortranarray(rng.uniform(size=(50, 50)))   # column-major: the NumPy form
+    want = np.ascontiguousarray(f)
+    fill_like_reference(f, 10, True)
+    spelled(want, 10, True)
+    assert np.array_equal(f, want)

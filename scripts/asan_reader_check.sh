@@ -12,7 +12,7 @@ cd "$REPO"
 # libstdc++ has to be loaded before the sanitizer runtime resolves __cxa_throw (python itself does not link it)
 LD_PRELOAD="$(g++ -print-file-name=libasan.so) $(g++ -print-file-name=libstdc++.so.6)" ASAN_OPTIONS=detect_leaks=0 \
     MUSTACHE_IO_LIB="$OUT" python -m pytest tests/test_hic_reader.py tests/test_hic_two_readings.py tests/test_text_reader.py \
-    tests/test_readers_ref.py -x -q -s -m "not gpu" 2>&1 | tee "${TMPDIR:-/tmp}/asan_reader_check.log" | tail -3
+    tests/test_readers_ref.py "tests/test_host_logic.py::test_fill_like_reference_equals_numpy_row_slices" -x -q -s -m "not gpu" 2>&1 | tee "${TMPDIR:-/tmp}/asan_reader_check.log" | tail -3
 if grep -q "runtime error\|AddressSanitizer" "${TMPDIR:-/tmp}/asan_reader_check.log"; then
     echo "SANITIZER REPORTS:"; grep "runtime error\|AddressSanitizer" "${TMPDIR:-/tmp}/asan_reader_check.log" | sort | uniq -c
     exit 1

@@ -133,39 +133,8 @@ def test_device_rows_random_files_equal_the_host_decoded_band(tmp_path):
     the band of the raw streamed read (rows decoded on the device) equals the band of the packed streamed read (host decoder),
     bit for bit, with the same n and record count."""
     import torch
-    from hic_writer import write_hic
-    from mustache_amd.hicfile import HicFile
-    from mustache_amd.normalize import band_from_packed, read_hic_stream_to_device
+    import fuzz_cases
     rng = np.random.default_rng(20505)
     dev = torch.device("cuda", 0)
-    total = 0
-    for case in range(14):
-        n = int(rng.integers(300, 5000))
-        res = int(rng.choice([1000, 5000, 25000]))
-        spread = int(rng.integers(20, 600))
-        dpx = int(rng.integers(10, spread + 20))
-        m = int(rng.integers(500, 150000))
-        x = rng.integers(0, n, m)
-        y = np.minimum(x + rng.integers(0, spread, m), n - 1 - int(rng.integers(0, 3)))
-        key = np.unique(np.minimum(x, y) * 1000003 + np.maximum(x, y))
-        x, y = key // 1000003, key % 1000003
-        floats = bool(rng.integers(2))
-        c = rng.uniform(0.25, 40, len(x)).astype(np.float32).astype(np.float64) if floats else rng.integers(1, 900, len(x)).astype(np.float64)
-        version = int(rng.choice([8, 9]))
-        norm = rng.uniform(0.5, 2.0, n + 1)
-        norm[rng.integers(0, n, 4)] = np.nan
-        p = str(tmp_path / ("f%d.hic" % case))
-        write_hic(p, [("All", 7500), ("chr1", n * res)], {1: {res: (x, y, c)}}, {("KR", 1, res): norm}, version=version,
-                  block_bin_count=int(rng.choice([16, 64, 128, 500])), float_counts=floats, dense_blocks=bool(rng.integers(4) == 0),
-                  short_coords=bool(rng.integers(2)) if version == 9 else True)
-        size_bp = 0 if rng.integers(2) else int((n - rng.integers(1, 40)) * res)
-        norm_name = "KR" if rng.integers(3) else "NONE"
-        slab = int(rng.choice([410, 1000, 20000, 1 << 19]))
-        with HicFile(p) as h:
-            a = read_hic_stream_to_device(h, "chr1", res, norm_name, dpx, size_bp, dev, threads=int(rng.integers(1, 6)), slab_records=slab, raw=True)
-            b = read_hic_stream_to_device(h, "chr1", res, norm_name, dpx, size_bp, dev, threads=3, slab_records=4096, raw=False)
-        assert a.device_band is not None and b.device_parts is not None
-        ba, bb = band_from_packed(a, dpx, dev), band_from_packed(b, dpx, dev)
-        assert a.count == b.count and ba.shape == bb.shape and torch.equal(ba, bb), (case, n, dpx, version, floats, slab)
-        total += a.count
+    total = sum(fuzz_cases.hic_rows_case(rng, str(tmp_path / ("f%d.hic" % case)), dev) for case in range(14))
     assert total > 100000

@@ -122,6 +122,30 @@ def test_bench_two_ranks_self_launched_with_file_leg():
     assert f1["ranks"] == 1 and f1["records"] == f["records"] and f1["loops"] == f["loops"] > 0 and f1["n"] == f["n"]
 
 
+def test_bench_four_ranks_self_launched_strong_split_and_file_leg():
+    """The driver's N = 4 on this box's one GPU over gloo (`--small`: 12 blocks in four contiguous ranges of three, the `.hic`
+    inflated in four shares and exchanged): same megapixels per step, same records and loops as one rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(MST_BENCH_BACKEND="gloo", MST_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1", "--small", "--no-cpu"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 4 and j["steps"] == 2 and j["warmup"] == 1 and j["value"] > 0 and 0 < j["roofline"]["frac"] < 1
+    assert j["scaling"] == "strong" and j["config"]["partition"] == "blocks"
+    assert "rank 0 = [0, 3), rank 1 = [3, 6), rank 2 = [6, 9), rank 3 = [9, 12)" in j["config"]["sharding"]
+    assert j["ranks"]["blocks_per_rank_max"] == j["ranks"]["blocks_per_rank_min"] == 3
+    assert abs(j["config"]["megapixels_per_step"] - 12 * 16.0) < 1e-6
+    f = j["end_to_end_from_file"]
+    assert f["ranks"] == 4 and len(f["records_per_rank"]) == 4 and all(c > 0 for c in f["records_per_rank"])
+    assert sum(f["records_per_rank"]) == f["records"] and f["loops"] > 0
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "1", "--warmup", "0", "--small", "--no-cpu"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert one.returncode == 0, one.stderr[-3000:]
+    f1 = _last_json(one.stdout)["end_to_end_from_file"]
+    assert f1["records"] == f["records"] and f1["loops"] == f["loops"] and f1["n"] == f["n"]
+
+
 def test_bench_two_ranks_rccl_one_device_if_rccl_allows_it():
     """bench.py --gpus 2 with the REAL backend (nccl = RCCL) and both ranks on this box's one GPU.  RCCL may refuse two ranks
     on one device ("Duplicate GPU detected" / invalid usage) -- then this test says so and skips: the gloo run above keeps

@@ -233,9 +233,15 @@ __device__ double np_pairwise_leaf(const double *a, int n) {
     return res;
 }
 
-__device__ double np_pairwise_sum(const double *a, int n) {
+// the recursion's stack lives in LDS (one lane runs this; as private arrays the compiler put it into scratch memory)
+struct PairwiseStack {
     int off[24], len[24], state[24];
     double left[24];
+};
+
+__device__ double np_pairwise_sum(const double *a, int n, PairwiseStack &st) {
+    int *off = st.off, *len = st.len, *state = st.state;
+    double *left = st.left;
     int sp = 1;
     off[0] = 0;
     len[0] = n;
@@ -280,6 +286,7 @@ __global__ void __launch_bounds__(64)
 diag_mean_kernel(const double *__restrict__ src, int64_t n, int dpx, int64_t start, const int64_t *__restrict__ starts,
                  int CH, int b, const int32_t *__restrict__ diag_k, double *__restrict__ mean_out) {
     extern __shared__ double dm_buf[];
+    __shared__ PairwiseStack pw_stack;
     const int i = blockIdx.x, lane = threadIdx.x;
     const int k = diag_k[i];
     if (BAND && starts) start = starts[i];             // one launch for the diagonals of many blocks
@@ -299,14 +306,14 @@ diag_mean_kernel(const double *__restrict__ src, int64_t n, int dpx, int64_t sta
         base += __popcll(bal);
     }
     __syncthreads();
-    if (lane == 0) mean_out[i] = np_pairwise_sum(dm_buf, base) / (double)base;
+    if (lane == 0) mean_out[i] = np_pairwise_sum(dm_buf, base, pw_stack) / (double)base;
 }
 
 template <bool BAND>
 int diag_means_launch(const double *src, int64_t n, int dpx, int64_t start, const int64_t *starts, int CH, int b,
                       const int32_t *diag_k, int nd, double *mean_out, hipStream_t s) {
     const size_t lds = (size_t)CH * sizeof(double);
-    if (lds > 160 * 1024 - 256) return mst::fail(MST_E_ARG, "diagonal means: CH %d does not fit the LDS", CH);
+    if (lds > 160 * 1024 - 1024) return mst::fail(MST_E_ARG, "diagonal means: CH %d does not fit the LDS", CH);
     if (lds > 64 * 1024)
         MST_HIP(hipFuncSetAttribute((const void *)diag_mean_kernel<BAND>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));

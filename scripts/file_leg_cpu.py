@@ -30,6 +30,17 @@ def main():
     from mustache_amd.hicfile import HicFile
     from mustache_amd.normalize import band_from_packed, normalize_band, read_hic_stream_to_device
     passes = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    if os.environ.get("MST_AFFINITY"):          # "first": one hardware thread per core (the lower half of the CPU numbers); "a-b": that range
+        spec = os.environ["MST_AFFINITY"]
+        ncpu = os.cpu_count()
+        cpus = range(ncpu // 2) if spec == "first" else range(int(spec.split("-")[0]), int(spec.split("-")[1]) + 1)
+        os.sched_setaffinity(0, cpus)
+        print("affinity:", spec, "->", len(os.sched_getaffinity(0)), "CPUs")
+    try:
+        sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
+        print("cpu0 thread siblings:", sib)
+    except OSError:
+        pass
     dev = torch.device("cuda:0")
     import gc
     mode = os.environ.get("MST_GC", "")

@@ -413,11 +413,13 @@ def main(argv=None):
         counts = {1: 0, 2: 0, 3: 0, 4: 0}
         files = {t: open(args.outdir + suf, 'a') for t, suf in SUFFIX.items()}
         try:
+            from .mustache import _scalar_text           # the reference's str() of NumPy scalars, same text (mustache.write_loops)
+            c1, c2, rs = str(chromosome), str(chromosome2), int(res)
             for r in o:
                 counts[r[4]] += 1
-                files[r[4]].write(str(chromosome) + '\t' + str(r[0] * res) + '\t' + str((r[0] + 1) * res) + '\t' +
-                                  str(chromosome2) + '\t' + str(r[1] * res) + '\t' + str((r[1] + 1) * res) + '\t' +
-                                  str(r[2]) + '\t' + str(r[3]) + '\n')
+                x, y = int(r[0]), int(r[1])
+                files[r[4]].write("%s\t%d\t%d\t%s\t%d\t%d\t%s\t%s\n" % (c1, x * rs, (x + 1) * rs, c2, y * rs, (y + 1) * rs,
+                                                                       _scalar_text(r[2]), _scalar_text(r[3])))
         finally:
             for fh in files.values():
                 fh.close()

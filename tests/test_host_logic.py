@@ -358,3 +358,25 @@ def test_fill_like_reference_equals_numpy_row_slices():
     fill_like_reference(f, 10, True)
     spelled(want, 10, True)
     assert np.array_equal(f, want)
+
+
+def test_write_loops_text_equals_the_references_str_of_numpy_scalars(tmp_path):
+    """write_loops formats rows with int() / repr(float()); the reference concatenates str() of NumPy scalars
+    (mustache.py:1098-1103).  Same bytes, incl. tiny and huge q-values, integer-valued floats and large coordinates."""
+    from mustache_amd.mustache import write_loops
+    rng = np.random.default_rng(11)
+    q = np.concatenate([rng.uniform(0, 0.2, 3000), 10.0 ** rng.uniform(-300, -3, 3000), [0.0, 1.0, 1e-5, 1e-4, 9.999e-05, 5e-324, 0.1]])
+    m = len(q)
+    xs, ys = rng.integers(0, 3_000_000, m), rng.integers(0, 3_000_000, m)
+    sig = rng.choice([1.8379173679952558, 2.111212657236631, 3.2, 6.4, 4.0], m)
+    loops = [[np.int64(a), np.int64(b), np.float64(c), np.float64(d)] for a, b, c, d in zip(xs, ys, q, sig)]
+    res = 1000
+    for chrom in ("chr1", 21):
+        p = str(tmp_path / ("out_%s.tsv" % chrom))
+        write_loops(p, chrom, chrom, res, loops, first=True)
+        want = "BIN1_CHR\tBIN1_START\tBIN1_END\tBIN2_CHROMOSOME\tBIN2_START\tBIN2_END\tFDR\tDETECTION_SCALE\n" + "".join(
+            str(chrom) + '\t' + str(lp[0] * res) + '\t' + str((lp[0] + 1) * res) + '\t' + str(chrom) + '\t' + str(lp[1] * res) + '\t' +
+            str((lp[1] + 1) * res) + '\t' + str(lp[2]) + '\t' + str(lp[3]) + '\n' for lp in loops)
+        assert open(p).read() == want
+    vals = np.concatenate([rng.uniform(0, 1, 20000), 10.0 ** rng.uniform(-320, 308, 20000), rng.uniform(1e15, 1e17, 2000)])
+    assert all(repr(float(v)) == str(np.float64(v)) for v in vals)

@@ -5,9 +5,12 @@ it against the CPU oracle (oracle/), which only tests, smoke() and bench.py's CP
 Each *_case(rng, ...) draws one case from `rng`, runs it and returns (ok, n_loops, description); ok = coordinates, scales
 (and for the block case the complete found set, DoG values, levels, `loc`) identical to the oracle, p / q within the stated
 tolerance."""
+import os
+
 import numpy as np
 
-OCT = [1.6, 3.2]
+# FUZZ_OCT="3.2,6.4" / "1.6,3.2,6.4": the sweeps on the wide-radius instantiations (-sz 3.2, -oc 3)
+OCT = [float(t) for t in os.environ["FUZZ_OCT"].split(",")] if os.environ.get("FUZZ_OCT") else [1.6, 3.2]
 
 
 def _same_loops(got, exp, qtol=1e-6):

@@ -422,6 +422,8 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    from mustache_amd.engine import settle_gc
+    settle_gc()      # as the command-line entry points do (the library itself never freezes the collector)
     # MST_BENCH_FORCE_DIST=1: a process group even with one rank, so that the RCCL calls of the N > 1 path run on a 1-GPU box
     force_dist = bool(os.environ.get("MST_BENCH_FORCE_DIST")) and world == 1
     grouped = world > 1 or force_dist

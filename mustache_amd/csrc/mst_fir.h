@@ -8,7 +8,9 @@
 
 // Timing ablations (blur only, no wave reductions, staging only) exist in PROFILE builds only (make PROFILE=1 ->
 // libmustache_hip_profile.so); the product library has no run-time switch that could change a result.
-#ifdef MST_PROFILE
+#if defined(MST_PROFILE) && defined(MST_ABLATE_CT)     /* the ablation fixed at compile time (variant builds): dead phases cost no registers */
+#define MST_VARIANT(bit_) ((MST_ABLATE_CT) & (bit_))
+#elif defined(MST_PROFILE)
 #define MST_VARIANT(bit_) (variant & (bit_))
 #else
 #define MST_VARIANT(bit_) 0
@@ -33,6 +35,37 @@
 #endif
 
 namespace {
+
+// Pricing experiment of round 6 (variant builds with -DMST_PROFILE -DMST_INJECT=1|2 only; never in the product): a block of
+// VALU work that depends on nothing but its own registers -- INJ_DP v_max_f64 and INJ_INT 32-bit operations per thread, 8
+// independent chains each, the mix of the max / sieve / statistics phase (scripts/isa_census.py) -- placed either INSIDE the
+// axis-0 pass's main basic block (1: where an intra-wave overlap of level l's sieve with level l + 1's axis-0 pass would put
+// the sieve's instructions) or in a block of its own behind the level's second barrier (2: where the sieve is today).
+// Non-volatile asm: the optimiser cannot fold it, the scheduler may place it anywhere in its basic block.
+#if defined(MST_INJECT)
+#ifndef MST_INJ_DP
+#define MST_INJ_DP 96
+#endif
+#ifndef MST_INJ_INT
+#define MST_INJ_INT 224
+#endif
+struct Inject {
+    double q[8];
+    uint32_t u[8];
+};
+template <int NDP = MST_INJ_DP, int NINT = MST_INJ_INT>
+__device__ __forceinline__ void inject_work(Inject &z) {
+#pragma unroll
+    for (int i = 0; i < NDP; ++i) asm("v_max_f64 %0, %1, %2" : "=v"(z.q[i & 7]) : "v"(z.q[i & 7]), "v"(z.q[(i + 1 + i / 8) & 7]));
+#pragma unroll
+    for (int i = 0; i < NINT; ++i) asm("v_xor_b32 %0, %1, %2" : "=v"(z.u[i & 7]) : "v"(z.u[i & 7]), "v"(z.u[(i + 3 + i / 8) & 7]));
+}
+#define MST_INJECT_ARG , Inject &inj
+#define MST_INJECT_PASS , inj
+#else
+#define MST_INJECT_ARG
+#define MST_INJECT_PASS
+#endif
 
 struct DevLevels {
     int n_octaves;
@@ -130,8 +163,15 @@ struct Chunk {
 // loads in flight are live at a time instead of all KC + 2R, and the LDS latency hides under the FP64 work.
 // For each tap the KC adds / muls / accumulates are adjacent in program order: KC independent chains keep the FP64
 // pipe issuing (a sample-major order is one serial add->mul->add chain).
-template <int KC, int R, int OFF, bool FMA>
-__device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const double (&w)[R + 1], double (&t)[KC]) {
+#if defined(MST_INJECT)
+#define MST_FIR_INJ_TPARAM , int INJ = 0
+#define MST_FIR_INJ_PARAM , Inject *inj = nullptr
+#else
+#define MST_FIR_INJ_TPARAM
+#define MST_FIR_INJ_PARAM
+#endif
+template <int KC, int R, int OFF, bool FMA MST_FIR_INJ_TPARAM>
+__device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const double (&w)[R + 1], double (&t)[KC] MST_FIR_INJ_PARAM) {
     constexpr int NP = (KC + 2 * R + OFF + 1) / 2;                       // 16-byte pairs spanned by the window
     constexpr int QC0 = (R + OFF) >> 1, QC1 = (R + KC - 1 + OFF) >> 1;   // pairs holding the centre run
     const double2 *p2 = reinterpret_cast<const double2 *>(p);
@@ -154,6 +194,13 @@ __device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const do
 #endif
 #pragma unroll
     for (int q = QC0; q <= QC1; ++q) MST_LD(q)
+#if defined(MST_INJECT)
+    if constexpr (INJ == 3) {           // the whole block behind the chunk's first window loads, pinned there
+        __builtin_amdgcn_sched_barrier(0);
+        inject_work<>(*inj);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     int lq_hi = -1, rq_lo = NP;         // left pairs <= lq_hi and right pairs >= rq_lo are loaded (folds at compile time)
 #pragma unroll
     for (int k = 0; k < KC; ++k) t[k] = x[R + k + OFF] * w[0];
@@ -167,6 +214,13 @@ __device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const do
         }
         lq_hi = lq1 > lq_hi ? lq1 : lq_hi;
         rq_lo = rq0 < rq_lo ? rq0 : rq_lo;
+#if defined(MST_INJECT)
+        if constexpr (INJ == 4) {       // an R-th of the block behind every tap's window loads, pinned there
+            __builtin_amdgcn_sched_barrier(0);
+            inject_work<(MST_INJ_DP + R - 1) / R, (MST_INJ_INT + R - 1) / R>(*inj);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
 #if defined(MST_PROFILE) && defined(MST_ABL_NOMATH)  /* timing ablation (PROFILE builds): loads only */
         if (j & 1) t[j % KC] = t[j % KC] + (x[R - j + OFF] + x[R + KC - 1 + j + OFF]);
 #else
@@ -196,7 +250,7 @@ __device__ __forceinline__ void fir_chunk(const double *__restrict__ p, const do
 template <class T, int R>
 __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__restrict__ vb,
                                       const double (&wall)[T::RMAX + 1], int ptid, const double *__restrict__ vsrc,
-                                      double *__restrict__ vdst, int variant) {
+                                      double *__restrict__ vdst, int variant MST_INJECT_ARG) {
     constexpr int K = T::K, KC = Chunk<T::K, R>::KC;
     constexpr int NC = T::RGC + 2 * R;               // columns to produce
     constexpr int NRG = T::RGR / K;                  // 8-row groups
@@ -214,10 +268,17 @@ __device__ __forceinline__ void vpass(const double *__restrict__ ct, double *__r
 #pragma unroll
         for (int h = 0; h < K / KC; ++h) {
             double t[KC];
+#if defined(MST_INJECT) && (MST_INJECT == 3 || MST_INJECT == 4)
+            if (h == 0) fir_chunk<KC, R, OFF, T::FMA, MST_INJECT>(p + h * KC, w, t, &inj);
+            else
+#endif
             fir_chunk<KC, R, OFF, T::FMA>(p + h * KC, w, t);
 #pragma unroll
             for (int k = 0; k < KC; ++k) q[(h * KC + k) * T::VP] = t[k];
         }
+#if defined(MST_INJECT) && MST_INJECT == 1
+        inject_work<>(inj);
+#endif
     }
     if constexpr (MAINC < NC) if (!MST_VARIANT(8)) {  // [ablation 8] no leftover pieces
         constexpr int PR = 4;                        // rows per leftover piece (2-row pieces halve the skew between the waves

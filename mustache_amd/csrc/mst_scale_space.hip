@@ -47,6 +47,7 @@
 
 #include "mst_fir.h"
 
+
 namespace {
 
 __device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }
@@ -103,8 +104,8 @@ __device__ __forceinline__ void wave_reduce_min_sum(double &mn, double &sm) {
 template <class T, int R>
 __device__ __forceinline__ void blur_level(const double *ct, double *vb, const double (&w)[T::RMAX + 1], int tid,
                                            const double *vsrc, double *vdst, const double *hsrc, double (&g)[T::K],
-                                           int variant, unsigned long long *tr) {
-    vpass<T, R>(ct, vb, w, tid, vsrc, vdst, variant);
+                                           int variant, unsigned long long *tr MST_INJECT_ARG) {
+    vpass<T, R>(ct, vb, w, tid, vsrc, vdst, variant MST_INJECT_PASS);
     MST_STAMP(tr, 1)
     __syncthreads();
     MST_STAMP(tr, 2)
@@ -120,10 +121,10 @@ __device__ __forceinline__ void blur_level(const double *ct, double *vb, const d
 template <class T>
 __device__ __forceinline__ void blur_dispatch(int r, const double *ct, double *vb, const double (&wg)[T::RMAX + 1],
                                               int tid, const double *vsrc, double *vdst, const double *hsrc,
-                                              double (&g)[T::K], int variant, unsigned long long *tr) {
+                                              double (&g)[T::K], int variant, unsigned long long *tr MST_INJECT_ARG) {
 #define MST_CASE(R_)                                                  \
     case R_:                                                          \
-        if constexpr (R_ <= T::RMAX) blur_level<T, R_>(ct, vb, wg, tid, vsrc, vdst, hsrc, g, variant, tr); \
+        if constexpr (R_ <= T::RMAX) blur_level<T, R_>(ct, vb, wg, tid, vsrc, vdst, hsrc, g, variant, tr MST_INJECT_PASS); \
         break;
     switch (r) {
         MST_CASE(1) MST_CASE(2) MST_CASE(3) MST_CASE(4) MST_CASE(5) MST_CASE(6) MST_CASE(7)
@@ -386,6 +387,14 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
     const int n_oct = MST_VARIANT(4) ? 0 : lv->n_octaves, lpo = lv->levels_per_octave;   // [ablation 4: staging + epilogue only]
     const int prot = (int)(blockIdx.x >> 3) * 2 + (int)(blockIdx.x >> 11);
     int tested = 0;
+#if defined(MST_INJECT)
+    Inject inj;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        inj.q[k] = (double)(tid + k);
+        inj.u[k] = (uint32_t)(tid * 7 + k);
+    }
+#endif
     unsigned long long *tr = nullptr;
 #ifdef MST_PROFILE
     // timeline sample: MST_TRACE_WGS consecutive slots of block 0, starting at 3/8 of the grid (tiles inside the band)
@@ -412,7 +421,7 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
             // the leftover V-pass pieces occupy the first ceil(R/4) waves of a rotated wave order, so that over the
             // levels (and between the workgroups sharing a CU) every SIMD carries the same share of them
             const int ptid = (tid + 64 * ((l + prot) & 3)) & (T::NT - 1);
-            blur_dispatch<T>(r, ct, vb, taps, ptid, vsrc, vdst, hsrc, g, variant, tr);
+            blur_dispatch<T>(r, ct, vb, taps, ptid, vsrc, vdst, hsrc, g, variant, tr MST_INJECT_PASS);
             double d[K];
             if (kl >= 2) {
 #pragma unroll
@@ -433,6 +442,9 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
 #ifdef MST_PROFILE
             unsigned long long *tr_lvl = tr;
             if (tr) tr += MST_TRACE_STAMPS;
+#endif
+#if defined(MST_INJECT) && MST_INJECT == 2
+            inject_work<>(inj);
 #endif
             if (kl < 2) continue;
             if (MST_VARIANT(1) || MST_VARIANT(32)) continue;     // [ablation 1] blur + DoG only
@@ -472,20 +484,22 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
                 const uint32_t code = (uint32_t)tested + 1u;
                 // the reference evaluates the sieve and expon.fit on the tested pixels only (Lc[nz], mustache.py:755-768);
                 // a wave that owns none has nothing to do here
-                if (wave_has_nz)
+                if (wave_has_nz) {
+                    // branch-free form: the five terms fold into ONE floating-point comparison per pixel (D_c > best and
+                    // D_c > M_n <=> D_c > max(best, M_n): no NaN reaches here) and one bit of a mask that is combined for all
+                    // K pixels at once; updates and statistics are selects, so the K pixels are independent instruction streams
+                    // instead of K nested exec-mask branches in a row
+                    const uint32_t flags = nz_mask & ec & (ep | en) & gp;
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const bool tz = (nz_mask >> k) & 1u;
-                    const bool upd = tz && (Dc[k] > best[k]) && ((ec >> k) & 1u) && (((ep | en) >> k) & 1u) &&
-                                     ((gp >> k) & 1u) && (Dc[k] > m[k]);
-                    if (upd) {
-                        best[k] = Dc[k];
-                        lvl[k] = code;
-                    }
-                    if (tz) {
+                    for (int k = 0; k < K; ++k) {
+                        const bool bit = (flags & (1u << k)) != 0;
+                        const bool upd = bool(int(Dc[k] > dmax(best[k], m[k])) & int(bit));
+                        best[k] = upd ? Dc[k] : best[k];
+                        lvl[k] = upd ? code : lvl[k];
+                        const bool tz = (nz_mask & (1u << k)) != 0;
                         const double a = fabs(Dc[k]);
-                        lmin = a < lmin ? a : lmin;
-                        lsum = lsum + a;
+                        lmin = __builtin_fmin(lmin, tz ? a : INFINITY);      // a >= 0, lmin >= 0: the order of the operands is immaterial
+                        lsum = lsum + (tz ? a : 0.0);                          // x + 0.0 == x for every x >= +0.0: the sum's bits are unchanged
                     }
                 }
                 // fixed-order DPP reduction inside the wave (total lands in lane 63), one slot per (level, wave); a wave without
@@ -530,6 +544,18 @@ scale_space_kernel(const double *__restrict__ c, const uint8_t *__restrict__ nz,
         e_delta2 = again.delta2;
         e_CH = ka->CH;
     }
+#if defined(MST_INJECT)
+    {
+        double qs = 0.0;
+        uint32_t us = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            qs += inj.q[k];
+            us ^= inj.u[k];
+        }
+        if (qs == -1.0 && us == 0x12345u) part[0] = qs;      // never true: keeps the injected chains alive
+    }
+#endif
     uint32_t my_total = 0;
     uint32_t before[K];                 // records of this wave that precede mine for the same k
     uint32_t kbase[K];                  // records of this wave for smaller k

@@ -474,6 +474,8 @@ def main(argv=None):
         if pipe is None:
             from .pipeline import ChromosomePipeline
             pipe = ChromosomePipeline([args.s_z * (2 ** o_) for o_ in range(args.octaves)])
+            from .engine import settle_gc
+            settle_gc()                           # the command-line process only; the library leaves the collector alone
         coo1, coo2, res_c = got
         dpx = int(math.ceil(distFilter // res_c))
         if args.verbose:

@@ -328,7 +328,11 @@ def settle_gc():
     of the cyclic collector's reach (`gc.freeze()`).  A chromosome's host tail makes ~2 * 10^4 short-lived containers (one
     4-element list per loop, as the reference returns them), so CPython ran a full collection every third chromosome and each
     one walked all of those objects: +27-38 ms on a 55-75 ms step, exactly periodic (scripts/pair_genome_jitter.py,
-    scripts/file_leg_cpu.py; LABBOOK R5.8).  Results do not depend on it; MUSTACHE_GC_FREEZE=0 leaves the collector alone."""
+    scripts/file_leg_cpu.py; LABBOOK R5.8).  Results do not depend on it.
+    A process-global, irreversible change, so the LIBRARY never makes it on its own: the command-line entry points
+    (mustache.main, diff_mustache.main) and bench.py call this; a host application that imports mustache() / regulator() keeps
+    its collector untouched unless it calls settle_gc() itself or exports MUSTACHE_GC_FREEZE=1 (then the first engine does).
+    MUSTACHE_GC_FREEZE=0 leaves the collector alone everywhere."""
     global _GC_SETTLED
     if _GC_SETTLED or os.environ.get("MUSTACHE_GC_FREEZE", "1") == "0":
         return
@@ -356,7 +360,8 @@ class ScaleSpaceEngine:
         self._found_cap = {}
         self._pin = {}
         self._pin_flip = 0
-        settle_gc()
+        if os.environ.get("MUSTACHE_GC_FREEZE") == "1":      # library use: opt-in only (settle_gc's docstring)
+            settle_gc()
 
     # ---- host queries of the launch geometry (no GPU work) --------------------------------------------------------
     def band_tile_fraction(self, CH, dpx):

@@ -550,6 +550,8 @@ def main(argv=None):
                 if pipe is None:
                     from .pipeline import ChromosomePipeline
                     pipe = ChromosomePipeline([args.s_z * (2 ** o_) for o_ in range(args.octaves)])
+                    from .engine import settle_gc
+                    settle_gc()                   # the command-line process only; the library leaves the collector alone
                 _check_pair(f, chromosome, chromosome2)
                 from .hicfile import PackedContacts
                 is_packed = isinstance(contacts, PackedContacts)

@@ -13,8 +13,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from mustache_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "mustache_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|uint64_t|const char \*)\s*\*?\s*(mst_[a-z_0-9]+)\s*\(", hdr, flags=re.M))
-    assert len(declared) >= 14
+    tagged = re.findall(r"^(MST_STABLE|MST_INTERNAL) (?:int|uint64_t|const char \*)\s*\*?\s*(mst_[a-z_0-9]+)\s*\(", hdr, flags=re.M)
+    declared = set(name for _tag, name in tagged)
+    assert len(declared) == len(tagged) >= 14
+    # every entry point carries exactly one stability tag; no untagged declaration is left
+    assert not re.findall(r"^(?:int|uint64_t|const char \*)\s*\*?\s*mst_[a-z_0-9]+\s*\(", hdr, flags=re.M)
+    internal = set(name for tag, name in tagged if tag == "MST_INTERNAL")
+    assert internal == {"mst_bh_select_nowait", "mst_band_scatter_packed", "mst_band_scatter_hic_rows",
+                        "mst_band_verify_packed", "mst_scale_space_band_tiles", "mst_scale_space_band_items",
+                        "mst_candidate_features_band_multi", "mst_diag_means_band_multi"}
+    # the five of SURVEY 8(b) and the band forms the per-chromosome driver uses are on the stable side
+    for name in ("mst_normalize_band", "mst_scatter_blocks", "mst_gauss_blur", "mst_scale_space", "mst_found_pvalues",
+                 "mst_found_finish", "mst_scale_space_band", "mst_bh_select", "mst_cluster_representatives", "mst_diff_dog_band"):
+        assert name in declared - internal, name
     lib = _lib.load()                      # raises if any bound symbol is missing
     for name in declared:
         assert hasattr(lib, name), name
@@ -380,3 +391,26 @@ def test_write_loops_text_equals_the_references_str_of_numpy_scalars(tmp_path):
         assert open(p).read() == want
     vals = np.concatenate([rng.uniform(0, 1, 20000), 10.0 ** rng.uniform(-320, 308, 20000), rng.uniform(1e15, 1e17, 2000)])
     assert all(repr(float(v)) == str(np.float64(v)) for v in vals)
+
+
+def test_engine_constructor_leaves_the_collector_alone(monkeypatch):
+    """Library use (a maintainer changes imports only): constructing the engine must not freeze the
+    host application's garbage collector; only the command-line entry points and bench.py call settle_gc(), and
+    MUSTACHE_GC_FREEZE=1 is the library's opt-in."""
+    import gc
+    import inspect
+    from mustache_amd import engine, mustache as mm, diff_mustache as dm
+    monkeypatch.setattr(engine, "_GC_SETTLED", False)
+    monkeypatch.setattr(engine, "require_gpu", lambda: object())
+    monkeypatch.delenv("MUSTACHE_GC_FREEZE", raising=False)
+    before = gc.get_freeze_count()
+    engine.ScaleSpaceEngine((1.6, 3.2), device="cpu")
+    assert gc.get_freeze_count() == before and engine._GC_SETTLED is False
+    monkeypatch.setenv("MUSTACHE_GC_FREEZE", "1")
+    try:
+        engine.ScaleSpaceEngine((1.6, 3.2), device="cpu")
+        assert gc.get_freeze_count() > before and engine._GC_SETTLED is True
+    finally:
+        gc.unfreeze()
+    assert "settle_gc()" in inspect.getsource(mm.main) and "settle_gc()" in inspect.getsource(dm.main)
+    assert "settle_gc()" not in inspect.getsource(mm.mustache) and "settle_gc()" not in inspect.getsource(mm.regulator)

@@ -8,7 +8,8 @@ Workload (config.workload): the synthetic HFFc6-like chr1 at 1 kb of SURVEY.md s
 limit 2,000 bins, 124 overlapping dense blocks of 4000 x 4000 float64 (1,984 Mpix).  One "step" = one pass of rows 2-7
 of SURVEY.md section 8a over ALL blocks of the chromosome: normalised band resident in HBM -> fused kernel (blocks cut out
 of the band, filled and masked while the tile is staged; sigma-stack / DoG / 3x3 max / sieve / level statistics) ->
-p-values of the found pixels -> compacted found records on the host.
+p-values of the found pixels -> compacted found records on the host.  The step is ONE launch in two or three stages
+(Workload.step): the records of one stage's blocks are finished and downloaded under the next stage's kernel.
 
 N ranks = STRONG scaling, the reference's own partition (one process per block of ONE chromosome, mustache.py:913-937):
 the 124 blocks are split into N contiguous ranges, no data-path collective; the step time is the MAX over ranks between
@@ -17,9 +18,11 @@ rank, the genome partition; the mode that is not the headline is timed in the sa
 
 On the same JSON line: `roofline` (the fused kernel, HIP events on the launch stream, against the FP64 vector pipe WITHOUT
 FMA -- bit-exactness with SciPy forbids contraction: 1152 flops per pixel over 39.3 TFLOP/s; `hbm_model` = SURVEY 8d's
-592 B / pixel model beside the PMC traffic), `cpu_baseline` (the CPU oracle on one block, 1 core), `band_skip` (empty tiles
-skipped: the product mode) and `tile_sharing` / `no_share` (separate speed-ups), `chr21_5kb` / `diff_chr21_5kb`,
-`end_to_end` / `end_to_end_from_file`, `ranks`.  `--extra` adds the side legs of scripts/bench_extra.py.
+592 B / pixel model beside the PMC traffic), `cpu_baseline` (the CPU oracle: one block on 1 core, `p4` = 8 blocks in 4 processes
+as the reference's default -p 4, and the first / middle / last block's whole found sets checked against the HIP path),
+`band_skip` (empty tiles skipped: the product mode) and `tile_sharing` / `no_share` (separate speed-ups), `chr21_5kb` /
+`diff_chr21_5kb`, `end_to_end` / `end_to_end_from_file`, `ranks` (at N = 1 with a labelled single-GPU projection of the strong
+split: every rank's block range of N = 2, 4, 8 timed alone on this GPU).  `--extra` adds the side legs of scripts/bench_extra.py.
 """
 import argparse
 import json
@@ -36,7 +39,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6          # FMA-counted vector FP64 peak (256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
 FLOPS_PER_PIXEL = 1152.0         # 24 blurs x 2 axes x (1 + 3 r) non-fusable flops, sum of r = 184
 PEAK_TF = FP64_PEAK_TFLOPS / 2   # add / mul rate without FMA
-OVERLAP = int(os.environ.get("MST_BENCH_OVERLAP", "4"))   # launches per step (copy/compute overlap), see Workload.step
+OVERLAP = int(os.environ.get("MST_BENCH_OVERLAP", "3"))   # most stages per step (copy/compute overlap), see Workload.step
 
 
 def executed_flops_per_pixel():
@@ -55,8 +58,46 @@ def executed_flops_per_pixel():
 def work_items(w, skip_empty, share=True):
     """(workgroups launched, tiles the blocks would run one by one, tiles computed once for two blocks, workgroups per
     launch) over the launches of one step of workload w -- asked of the library (engine.band_items)."""
+    if w.pipe.engine.staged_launches:      # the groups are stages of ONE work list: sharing crosses them
+        p = w.pipe.engine.band_items([w.start[i] for g in w.groups for i in g], w.CH, w.dpx, skip_empty, share)
+        return p[0], p[1], p[2], [p[0]]
     per = [w.pipe.engine.band_items([w.start[i] for i in g], w.CH, w.dpx, skip_empty, share) for g in w.groups]
     return sum(p[0] for p in per), sum(p[1] for p in per), sum(p[2] for p in per), [p[0] for p in per]
+
+
+def share_projection(w, one_rank_ms, steps=3):
+    """While no multi-GPU node is at hand: the step of EVERY rank's contiguous block range at N = 2, 4, 8, each timed alone on
+    this GPU exactly like the headline step (the strong split has no data-path collective, so a rank's step IS its range's
+    step); projected step at N = the slowest range.  A single-GPU share timing, not a multi-GPU run: xGMI, the host's PCIe
+    sharing and clock differences between GPUs are not in it."""
+    import torch
+    keep = (w.rank, w.world, w.scaling)
+    proj, eff, per_rank = {}, {}, {}
+    try:
+        for n in (2, 4, 8):
+            times = []
+            for r in range(n):
+                w.rank, w.world = r, n
+                w.set_scaling("strong")
+                for _ in range(2):
+                    w.step(False)
+                torch.cuda.synchronize()
+                t0 = time.time()
+                for _ in range(steps):
+                    w.step(False)
+                torch.cuda.synchronize()
+                times.append((time.time() - t0) / steps * 1e3)
+            proj[str(n)], per_rank[str(n)] = round(max(times), 3), [round(t, 3) for t in times]
+            eff[str(n)] = round(one_rank_ms / (n * max(times)), 4)
+    finally:
+        w.rank, w.world = keep[0], keep[1]
+        w.set_scaling(keep[2])
+        w.kernel_ms.clear()
+    return {"projected_step_ms_at": proj, "projected_efficiency_at": eff, "projected_step_ms_per_rank": per_rank,
+            "projected_n_x_share_over_one_rank_at": {k: round(int(k) * v / one_rank_ms, 4) for k, v in proj.items()},
+            "kind": "single-GPU share timing, not a multi-GPU run",
+            "projection_note": "every rank's block range of the strong split timed alone on this GPU, %d steps each; projected step = "
+                               "the slowest range; efficiency = one-rank step / (N x projected step)" % steps}
 
 
 def parse():
@@ -129,22 +170,32 @@ class Workload:
 
     def step(self, skip_empty=False, download=True, fma=False):
         """rows 2-7 for this rank's blocks; returns the found records per group of blocks.  The blocks go through the fused
-        kernel in OVERLAP consecutive launches on alternating streams, so the p-values and the pinned download of one part
-        run under the kernel of the next (same total work; the launches never run concurrently)."""
-        if getattr(self, "_groups_for", None) != (tuple(self.mine), OVERLAP):
+        kernel as ONE launch in two or three STAGES (mst_scale_space_band_stage: one work list, so tiles shared by consecutive
+        blocks are computed once across the stages too): the p-values and the pinned download of one stage's blocks run on a
+        second stream under the next stage's kernel.  Only the LAST stage's download is exposed, so it is the small one: 6 % of
+        the blocks, at least two (its kernel must still cover the download of the stage before it); measured splits:
+        scripts/share_split_time.py, LABBOOK R6.2."""
+        key = (tuple(self.mine), OVERLAP, os.environ.get("MST_BENCH_SHARES"))
+        if getattr(self, "_groups_for", None) != key:
             groups = []
             for batch in self.pipe.batches(self.mine, self.CH, dense=False):
-                # launches of at least ~120 Mpix: smaller ones pay more in launch tails than the overlap wins back
-                k = max(1, min(OVERLAP, len(batch), int(len(batch) * self.CH * self.CH / 120e6)))
-                # the last launch's post-processing is the only one not hidden under a kernel: make that launch the smallest
-                share = {1: [1.0], 2: [0.6, 0.4], 3: [0.4, 0.35, 0.25], 4: [0.29, 0.29, 0.29, 0.13]}.get(k, [1.0 / k] * k)
-                cuts = [0]
-                for f in share[:-1]:
-                    cuts.append(min(len(batch) - 1, max(cuts[-1] + 1, int(round(cuts[-1] + f * len(batch))))))
-                cuts.append(len(batch))
+                nb = len(batch)
+                last = max(2, int(round(0.06 * nb)))
+                if os.environ.get("MST_BENCH_SHARES"):       # experiments (scripts/share_split_time.py): another split
+                    share = [float(x) for x in os.environ["MST_BENCH_SHARES"].split(",")]
+                    cuts = [0]
+                    for f in share[:-1]:
+                        cuts.append(min(nb - 1, max(cuts[-1] + 1, int(round(cuts[-1] + f * nb)))))
+                    cuts.append(nb)
+                elif nb < 4 or OVERLAP < 2:
+                    cuts = [0, nb]
+                elif nb < 24 or OVERLAP < 3:
+                    cuts = [0, nb - last, nb]
+                else:
+                    cuts = [0, (nb - last + 1) // 2, nb - last, nb]
                 groups += [batch[a:b] for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
-            self.groups = groups                             # the split of the blocks into launches is fixed between steps
-            self._groups_for = (tuple(self.mine), OVERLAP)
+            self.groups = groups                             # the split of the blocks into stages is fixed between steps
+            self._groups_for = key
             self._group_starts = [[self.start[i] for i in g] for g in groups]
         # blocks are windows of the band: cut, filled (mustache.py:703-706) and masked (:699) inside the fused kernel
         return list(self.pipe.engine.sigma_loop_band_overlapped(
@@ -299,31 +350,69 @@ def _oracle_block(args):
     # (after the clock) the found set in the GPU records' terms: row-major pixel index, 1-based tested level, vAll, p-value
     hit = ss.pval != 2
     if not want_set:
-        return dt, int(hit.sum()), int(nz.sum()), None
+        return dt, int(hit.sum()), int(nz.sum()), None, t0
     pix = np.flatnonzero(nz.ravel())[hit].astype(np.uint32)
-    return dt, int(hit.sum()), int(nz.sum()), (pix, ss.level[hit].astype(np.uint32), ss.best[hit], ss.pval[hit])
+    return dt, int(hit.sum()), int(nz.sum()), (pix, ss.level[hit].astype(np.uint32), ss.best[hit], ss.pval[hit]), t0
+
+
+def _compare_block(w, bi, cset):
+    """block bi of the workload through the HIP path -- launched with a neighbour, so that it RECEIVES the tiles it shares with the
+    block before it and / or GIVES those it shares with the block after it -- against the oracle's found set of the same block:
+    (pixels, levels and values identical, largest relative p-value difference, GPU found count)"""
+    import numpy as np
+    nb = len(w.start)
+    idx = [i for i in (bi - 1, bi, bi + 1) if 0 <= i < nb]
+    g = w.pipe.engine.sigma_loop_band(w.band, w.n, w.dpx, [w.start[i] for i in idx], w.CH, skip_empty=False, with_q=False)[0][idx.index(bi)]
+    cpix, clvl, cval, cp = cset
+    same = (len(g["pixel"]) == len(cpix) and np.array_equal(g["pixel"], cpix) and np.array_equal(g["level"], clvl)
+            and np.array_equal(g["value"], cval))
+    p_err = float(np.max(np.abs(g["pval"] - cp) / np.maximum(cp, 1e-300))) if same and len(cpix) else None
+    return bool(same), p_err, len(g["pixel"])
 
 
 def cpu_baseline(w, value):
-    """The oracle (reference arithmetic: SciPy gaussian_filter / maximum_filter / expm1) on the middle block, 1 core, and the
-    same block's found set from the HIP path, launched with its two neighbours so that it RECEIVES the tiles it shares with
-    the block before it and GIVES those it shares with the block after it: the whole found set is compared."""
-    import numpy as np
-    bi = len(w.start) // 2
-    cpu_s, cpu_found, cpu_nz, (cpix, clvl, cval, cp) = _oracle_block((_dense_raw_block(w, bi), w.dpx, True))
-    g = w.pipe.engine.sigma_loop_band(w.band, w.n, w.dpx, [w.start[bi - 1], w.start[bi], w.start[bi + 1]], w.CH,
-                                      skip_empty=False, with_q=False)[0][1]
-    same = (len(g["pixel"]) == cpu_found and np.array_equal(g["pixel"], cpix) and np.array_equal(g["level"], clvl)
-            and np.array_equal(g["value"], cval))
-    p_err = float(np.max(np.abs(g["pval"] - cp) / np.maximum(cp, 1e-300))) if same and cpu_found else None
-    cpu = {"value": round(w.CH * w.CH / 1e6 / cpu_s, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
+    """The oracle (reference arithmetic: SciPy gaussian_filter / maximum_filter / expm1), rows 3-7, beside the GPU step:
+    (a) the middle block in this process, nothing else running: the 1-core timing sample;
+    (b) 8 blocks in 4 worker processes at once -- the reference's default `-p 4` (mustache.py:146), what BASELINE.md's
+        ">= 50 x" is stated against -- timed from the first worker's start to the last worker's end (process start-up and the
+        hand-over of the blocks are outside), scaled linearly to the chromosome.
+    Three of those blocks are also CHECKED against the HIP path at full size: the first (mask_size -1), the middle one and the
+    last (right-aligned, mask_size > the distance limit, mustache.py:909-910, :948-953) -- whole found sets, levels and
+    values with array_equal, p-values to 1e-9."""
+    import multiprocessing as mp
+    nb = len(w.start)
+    bi = nb // 2
+    cpu_s, cpu_found, cpu_nz, cset, _ = _oracle_block((_dense_raw_block(w, bi), w.dpx, True))
+    checks = {bi: _compare_block(w, bi, cset)}
+    edge = [0, nb - 1] if nb >= 5 else []
+    inner = [i for i in (nb // 8, nb // 4, 3 * nb // 8, 5 * nb // 8, 3 * nb // 4, 7 * nb // 8) if i not in (0, bi, nb - 1)]
+    sub = edge + sorted(set(inner))[:8 - len(edge)]
+    with mp.get_context("spawn").Pool(4) as pool:
+        res = pool.map(_oracle_block, [(_dense_raw_block(w, i), w.dpx, i in edge) for i in sub], chunksize=1)
+    wall4 = max(r[4] + r[0] for r in res) - min(r[4] for r in res)
+    for i, r in zip(sub, res):
+        if i in edge:
+            checks[i] = _compare_block(w, i, r[3])
+    compared = sorted(checks)
+    perr = [checks[i][1] for i in compared if checks[i][1] is not None]
+    one = w.CH * w.CH / 1e6 / cpu_s
+    p4 = len(sub) * w.CH * w.CH / 1e6 / wall4
+    cpu = {"value": round(one, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
            "sample": "block %d of the same workload (one 4000x4000 block, %.1f s), rows 3-7 of the oracle = the reference's "
                      "SciPy calls, single process.  NOT in this baseline: the reference's normalize_sparse (row 1) and its "
                      "tail (rows 8-9); the GPU side of the ratio (`value`) is rows 2-7" % (bi, cpu_s),
-           "found_pixels_cpu": cpu_found, "found_pixels_gpu": len(g["pixel"]),
-           "found_set_pixels_levels_values_identical": bool(same), "pvalue_max_rel_err": p_err,
+           "found_pixels_cpu": cpu_found, "found_pixels_gpu": checks[bi][2],
+           "blocks_compared": compared,
+           "found_set_pixels_levels_values_identical": all(checks[i][0] for i in compared),
+           "found_pixels_per_block_compared": [checks[i][2] for i in compared],
+           "pvalue_max_rel_err": max(perr) if perr else None,
+           "p4": {"value": round(p4, 4), "unit": "Mpix/s", "procs": 4, "blocks": len(sub), "block_indices": sub,
+                  "scaled": "rate of %d of the %d blocks, taken as the chromosome's" % (len(sub), nb),
+                  "wall_s": round(wall4, 2), "core_s_per_block": round(sum(r[0] for r in res) / len(res), 2),
+                  "sample": "the reference's default -p 4 (mustache.py:146): %d blocks in 4 worker processes, two rounds; first "
+                            "worker start -> last worker end, same rows 3-7 per block as the 1-core leg" % len(sub)},
            "cpu_model": _cpu_model(), "host_cores": os.cpu_count()}
-    return cpu, round(value / cpu["value"], 1)
+    return cpu, round(value / cpu["value"], 1), round(value / cpu["p4"]["value"], 1)
 
 
 def _cpu_model():
@@ -538,8 +627,8 @@ def main():
                           nb, world, ", ".join("rank %d = [%d, %d)" % (r, b[0], b[-1] + 1) for r, b in enumerate(ranges) if b)))
                       if strong else ("one whole chromosome (%d blocks) per rank, %d rank(s)" % (nb, world)),
                       "timed_region": "normalised band in HBM -> fused kernel (blocks cut, filled, masked in-kernel; sigma loop, sieve, "
-                                      "level statistics) -> p-values -> found records of every block on the host; %d launches per "
-                                      "step, the download of one under the kernel of the next" % OVERLAP},
+                                      "level statistics) -> p-values -> found records of every block on the host; one launch in %d "
+                                      "stages per step, the download of one stage's blocks under the kernel of the next" % len(w.groups)},
            "ranks": {"ms_per_step_max": round(max(owns) / args.steps * 1e3, 3), "ms_per_step_min": round(min(owns) / args.steps * 1e3, 3),
                      "blocks_per_rank_max": max(per_rank), "blocks_per_rank_min": min(per_rank),
                      "imbalance_bound": round(max(per_rank) * world / float(sum(per_rank)), 4),
@@ -563,6 +652,8 @@ def main():
         w.set_scaling(args.scaling)
 
     solo = rank == 0 and world == 1
+    if solo:
+        out["ranks"].update(share_projection(w, ms_per_step))
     if solo:
         # informational: the whole per-chromosome run from the normalised band (rows 2-9, product mode) -- NOT part of `value`
         w.pipe.run_band(w.band, w.n, w.dpx, 0.88, 0.1, distributed=False)      # first call: staging buffers, allocator
@@ -588,7 +679,7 @@ def main():
         out["end_to_end_from_file"] = fl = file_leg(cx, on_band=extra.sparse_step if extra else None)
         out["ranks"]["read_s"] = fl["read_s_per_rank"]
     if solo and not args.no_cpu:
-        out["cpu_baseline"], out["speedup_vs_cpu_1core"] = cpu_baseline(w, value)
+        out["cpu_baseline"], out["speedup_vs_cpu_1core"], out["speedup_vs_cpu_p4"] = cpu_baseline(w, value)
         if extra:
             extra.cpu_pools()
     if rank == 0:

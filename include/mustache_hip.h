@@ -278,7 +278,7 @@ MST_STABLE int mst_band_to_coo(const double *band, const int64_t *x, const int64
  *   local != 0 : branch A (:628-669), taken by the caller when (n - dpx) * res > 2e6; `window` = int(2e6 / res).
  *                (local == 1: the library picks the kernel -- the walking kernel (blocks of `window` samples along each
  *                diagonal, one scan per sample) for windows up to 4096, blocked sums (16-sample blocks) up to ~8400 and
- *                (64-sample blocks, samples only in LDS) up to 16384, an error beyond.  PROFILE builds additionally accept
+ *                (32-sample blocks, samples only in LDS) up to 16384, an error beyond.  PROFILE builds additionally accept
  *                local == 2 (blocked sums whatever the window) and local == 3 (round 1's segment kernel) as cross-checks;
  *                the product library refuses them.)
  *                Per diagonal d <= dpx+1: vals = v + 0.001; counts / sum / sum of squares over the zero-padded
@@ -314,6 +314,17 @@ MST_STABLE int mst_scale_space_band_pair(const double *band1, const double *band
                               const int64_t *starts, int32_t B, int32_t CH, const mst_levels *lv, mst_found *found,
                               uint32_t found_cap, uint32_t *found_count, double *level_stats, uint32_t *nz_count, int32_t flags,
                               void *workspace, uint64_t workspace_bytes, void *stream);
+/* mst_scale_space_band in STAGES (this package's engine; identical results): cuts[0 .. n_cuts) are ascending block indices in
+ * (0, B); stage i (0 <= i <= n_cuts) enqueues the work items of blocks [cuts[i-1], cuts[i]) of the launch's ONE work list -- tile
+ * sharing crosses the cuts, which separate launches over the same ranges would lose -- followed by the level statistics of
+ * those blocks.  Call the stages in ascending order on one stream with identical arguments; stage 0 also uploads the tables
+ * and zeroes the counters.  After stage i the outputs of the blocks below cuts[i] are final, so their mst_found_finish can
+ * run on another stream (behind an event) while stage i + 1 executes.  MST_FLAG_GRAPH is ignored. */
+MST_INTERNAL int mst_scale_space_band_stage(const double *band, int64_t n, int32_t dpx, const int64_t *starts, int32_t B, int32_t CH,
+                                            const mst_levels *lv, mst_found *found, uint32_t found_cap, uint32_t *found_count,
+                                            double *level_stats, uint32_t *nz_count, int32_t flags, void *workspace,
+                                            uint64_t workspace_bytes, const int32_t *cuts, int32_t n_cuts, int32_t stage,
+                                            void *stream);
 /* How many of a block's tiles mst_scale_space_band launches with MST_FLAG_SKIP_EMPTY (those whose pixels can reach the tested
  * band 4 <= col - row <= dpx + 1), on the block's own tile lattice; *tiles_total = all tiles of the block.  Host only. */
 MST_INTERNAL int mst_scale_space_band_tiles(int32_t CH, int32_t dpx, const mst_levels *lv, int32_t *tiles_total);

@@ -75,6 +75,8 @@ _SIGNATURES = {
     "mst_blocks_from_band": (ctypes.c_int, [_p, _i64, _i32, ctypes.POINTER(_i64), _i32, _i32, _p, _p, _p, _p]),
     "mst_scale_space_band": (ctypes.c_int, [_p, _i64, _i32, ctypes.POINTER(_i64), _i32, _i32, ctypes.POINTER(MstLevels), _p,
                                             _u32, _p, _p, _p, _i32, _p, _u64, _p]),
+    "mst_scale_space_band_stage": (ctypes.c_int, [_p, _i64, _i32, ctypes.POINTER(_i64), _i32, _i32, ctypes.POINTER(MstLevels), _p,
+                                                  _u32, _p, _p, _p, _i32, _p, _u64, ctypes.POINTER(_i32), _i32, _i32, _p]),
     "mst_scale_space_band_pair": (ctypes.c_int, [_p, _p, _i32, _i64, _i32, ctypes.POINTER(_i64), _i32, _i32, ctypes.POINTER(MstLevels),
                                                  _p, _u32, _p, _p, _p, _i32, _p, _u64, _p]),
     "mst_candidate_features_band": (ctypes.c_int, [_p, _i64, _i32, _i64, _i32, _p, _p, _i32, _p, _p, _p, _p]),
@@ -142,3 +144,36 @@ def check(rc):
     if rc == MST_E_OVERFLOW:
         raise MstOverflow(rc, msg)
     raise MstError(rc, msg)
+
+
+# ---- stage markers (observability).  MUSTACHE_ROCTX=1: the host stages of a run (read / normalise / scale-space /
+# tail) are pushed as roctx ranges through librocprofiler-sdk-roctx, so `rocprofv3 --marker-trace --kernel-trace` shows them above
+# the kernels (the PROFILE library marks its entry points the same way).  Off by default: no library is loaded, no call is made.
+_ROCTX = None
+
+
+class stage:
+    """with stage("read"): ...   -- a roctx range when MUSTACHE_ROCTX=1, nothing otherwise"""
+    __slots__ = ("name", "on")
+
+    def __init__(self, name):
+        self.name, self.on = name, False
+
+    def __enter__(self):
+        global _ROCTX
+        if os.environ.get("MUSTACHE_ROCTX") == "1":
+            if _ROCTX is None:
+                try:
+                    _ROCTX = ctypes.CDLL("librocprofiler-sdk-roctx.so")
+                    _ROCTX.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                except OSError:
+                    _ROCTX = False
+            if _ROCTX:
+                _ROCTX.roctxRangePushA(("mustache: " + self.name).encode())
+                self.on = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _ROCTX.roctxRangePop()
+        return False

@@ -876,6 +876,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" int mst_band_from_coo(const int64_t *x, const int64_t *y, const double *v, int64_t nnz, int64_t n,
                                  int32_t dpx, double *band, void *stream) {
+    MST_RANGE("read: mst_band_from_coo");
     if (!band || n <= 0 || dpx < 0 || nnz < 0 || (nnz > 0 && (!x || !y || !v)))
         return mst::fail(MST_E_ARG, "mst_band_from_coo: bad argument");
     hipStream_t s = mst::as_stream(stream);
@@ -889,6 +890,7 @@ extern "C" int mst_band_from_coo(const int64_t *x, const int64_t *y, const doubl
 
 extern "C" int mst_band_from_packed(const int32_t *x, const int32_t *dist, const float *v, int64_t nnz, int64_t n,
                                     int32_t dpx, double *band, void *stream) {
+    MST_RANGE("read: mst_band_from_packed");
     if (!band || n <= 0 || dpx < 0 || nnz < 0 || (nnz > 0 && (!x || !dist || !v)))
         return mst::fail(MST_E_ARG, "mst_band_from_packed: bad argument");
     hipStream_t s = mst::as_stream(stream);
@@ -902,6 +904,7 @@ extern "C" int mst_band_from_packed(const int32_t *x, const int32_t *dist, const
 
 extern "C" int mst_band_scatter_packed(const int32_t *x, const void *dist, int32_t dist_bytes, const float *v, int64_t nnz,
                                        int64_t n, int32_t dpx, double *band, void *stream) {
+    MST_RANGE("read: mst_band_scatter_packed");
     if (!band || n <= 0 || dpx < 0 || nnz < 0 || (nnz > 0 && (!x || !dist || !v)) || (dist_bytes != 2 && dist_bytes != 4) ||
         (dist_bytes == 2 && dpx + 1 > 65535))
         return mst::fail(MST_E_ARG, "mst_band_scatter_packed: bad argument (dist_bytes 2 or 4; 2 needs dpx + 1 <= 65535)");
@@ -949,6 +952,7 @@ extern "C" int mst_band_to_coo(const double *band, const int64_t *x, const int64
 
 extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64_t n, int32_t dpx, int32_t window,
                                   int32_t local, double *diag_stats, void *stream) {
+    MST_RANGE("normalise: mst_normalize_band");
     if (!band_in || !band_out || !diag_stats || band_in == band_out || n <= 0 || dpx < 0 || dpx + 2 > 65535)
         return mst::fail(MST_E_ARG, "mst_normalize_band: bad argument (out of place, dpx + 2 <= 65535)");
 #ifndef MST_PROFILE
@@ -1016,7 +1020,7 @@ extern "C" int mst_normalize_band(const double *band_in, double *band_out, int64
 #endif
     if (local) {
         // wide windows: blocked-sum kernel.  LDS: 2 doubles per staged sample + 2 doubles and an int per 16-sample block, for up to
-        // SEG + W + 2 * 16 samples; beyond ~8400 bins: 1 double per sample and 64-sample blocks (see the kernel)
+        // SEG + W + 2 * 16 samples; beyond ~8400 bins: 1 double per sample and 32-sample blocks (kBlkWide; see the kernel)
         auto lds_need = [&](size_t blk, size_t arrays) {
             const size_t nblk = (size_t)(kSeg + window + 2 * blk + blk - 1) / blk;
             return sizeof(double) * (arrays * nblk * blk + 2 * (nblk + 1)) + sizeof(int) * (nblk + 1) + 16;

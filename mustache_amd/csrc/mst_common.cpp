@@ -196,3 +196,11 @@ void dump_notes() {
 
 extern "C" int mst_abi_version(void) { return MST_ABI_VERSION; }
 extern "C" const char *mst_last_error(void) { return mst::error_buffer(); }
+
+#ifdef MST_PROFILE
+#include <rocprofiler-sdk-roctx/roctx.h>
+namespace mst {
+Range::Range(const char *name) { (void)roctxRangePushA(name); }
+Range::~Range() { (void)roctxRangePop(); }
+}  // namespace mst
+#endif

@@ -61,6 +61,19 @@ struct PinnedList {
     hipError_t upload(void *dst, hipStream_t s);
 };
 
+// PROFILE builds mark the stage every entry point belongs to (read / normalise / launch / finish / tail) as a roctx range, so
+// that `rocprofv3 --marker-trace` shows the stages of a run next to its kernels (profiles/r06_marker_trace.md); the product
+// library carries no marker and does not link the roctx library.
+#ifdef MST_PROFILE
+struct Range {
+    explicit Range(const char *name);
+    ~Range();
+};
+#define MST_RANGE(name_) mst::Range mst_range_scope_(name_)
+#else
+#define MST_RANGE(name_)
+#endif
+
 // diagnostics (MUSTACHE_GRAPH_DEBUG set): a short in-memory ring of notes about recent launches, printed when a call fails
 void note(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 void dump_notes();

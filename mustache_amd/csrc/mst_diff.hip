@@ -467,6 +467,7 @@ extern "C" uint64_t mst_diff_dog_workspace_bytes(int32_t B, int32_t CH, const ms
 extern "C" int mst_diff_dog_band(const double *band1, const double *band2, int64_t n, int32_t dpx, const int64_t *starts,
                                  int32_t B, int32_t CH, const mst_levels *lv, double *dog, double *fit,
                                  uint32_t *mask_count, void *workspace, uint64_t workspace_bytes, void *stream) {
+    MST_RANGE("launch: mst_diff_dog_band");
     if (!band1 || !band2 || !starts || !dog || !fit || !mask_count || !workspace || n <= 0 || dpx < 0 || B <= 0 ||
         B > 65535 || CH <= 0)
         return mst::fail(MST_E_ARG, "mst_diff_dog_band: bad argument");
@@ -511,6 +512,7 @@ extern "C" int mst_diff_dog_band(const double *band1, const double *band2, int64
 extern "C" int mst_pair_pvalues_dog(const mst_found *found, uint32_t found_cap, const uint32_t *found_count,
                                     const double *dog, const double *fit, int32_t B, int32_t CH, int32_t n_octaves,
                                     int32_t tested_per_octave, int32_t sample_offset, double *ppair, void *stream) {
+    MST_RANGE("finish: mst_pair_pvalues_dog");
     if (!found || !found_count || !dog || !fit || !ppair || B <= 0 || B > 65535 || CH <= 0 || n_octaves <= 0 ||
         tested_per_octave <= 0 || sample_offset < 0)
         return mst::fail(MST_E_ARG, "mst_pair_pvalues_dog: bad argument");
@@ -607,6 +609,7 @@ extern "C" int mst_pair_gather(const mst_found *found, uint32_t found_cap, const
                                int32_t P, const uint32_t *sel_index, const uint32_t *sel_pixel, const uint32_t *sel_count,
                                uint32_t out_cap, uint32_t max_selected, double *out_pair, double *out_value,
                                double *out_other, void *stream) {
+    MST_RANGE("tail: mst_pair_gather");
     if (!found || !found_count || !ppair || !sel_index || !sel_pixel || !sel_count || !out_pair || !out_value ||
         !out_other || P <= 0 || 2 * P > 65535 || found_cap == 0 || out_cap == 0 || max_selected > out_cap)
         return mst::fail(MST_E_ARG, "mst_pair_gather: bad argument");

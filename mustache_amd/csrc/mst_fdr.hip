@@ -440,6 +440,7 @@ int bh_select_impl(const mst_found *found, const double *pval, const uint32_t *c
 extern "C" int mst_bh_select(const mst_found *found, const double *pval, const uint32_t *count, int32_t B, uint32_t cap,
                              double threshold, uint32_t out_cap, uint32_t *out_pixel, uint32_t *out_level, double *out_q,
                              uint32_t *out_count, void *workspace, uint64_t workspace_bytes, void *stream) {
+    MST_RANGE("tail: mst_bh_select");
     return bh_select_impl(found, pval, count, B, cap, threshold, out_cap, out_pixel, out_level, out_q, out_count, nullptr,
                           workspace, workspace_bytes, stream);
 }
@@ -448,6 +449,7 @@ extern "C" int mst_bh_select_records(const mst_found *found, const double *pval,
                                      uint32_t cap, double threshold, uint32_t out_cap, uint32_t *out_pixel,
                                      uint32_t *out_level, double *out_q, uint32_t *out_index, uint32_t *out_count,
                                      void *workspace, uint64_t workspace_bytes, void *stream) {
+    MST_RANGE("tail: mst_bh_select_records");
     if (!out_index) return mst::fail(MST_E_ARG, "mst_bh_select_records: bad argument");
     return bh_select_impl(found, pval, count, B, cap, threshold, out_cap, out_pixel, out_level, out_q, out_count, out_index,
                           workspace, workspace_bytes, stream);
@@ -457,6 +459,7 @@ extern "C" int mst_bh_select_nowait(const mst_found *found, const double *pval, 
                                     uint32_t cap, double threshold, uint32_t out_cap, uint32_t *out_pixel,
                                     uint32_t *out_level, double *out_q, uint32_t *out_index, uint32_t *out_count,
                                     uint32_t lds_records, void *workspace, uint64_t workspace_bytes, void *stream) {
+    MST_RANGE("tail: mst_bh_select_nowait");
     if (lds_records < 2 || lds_records > (uint32_t)kSortMax || (lds_records & (lds_records - 1)))
         return mst::fail(MST_E_ARG, "mst_bh_select_nowait: lds_records must be a power of two in [2, %d]", kSortMax);
     return bh_select_impl(found, pval, count, B, cap, threshold, out_cap, out_pixel, out_level, out_q, out_count, out_index,
@@ -466,6 +469,7 @@ extern "C" int mst_bh_select_nowait(const mst_found *found, const double *pval, 
 extern "C" int mst_select_below(const mst_found *found, const double *q, const uint32_t *found_count, int32_t B,
                                 uint32_t found_cap, double threshold, uint32_t out_cap, uint32_t *out_pixel,
                                 uint32_t *out_level, double *out_q, uint32_t *out_count, void *stream) {
+    MST_RANGE("tail: mst_select_below");
     if (!found || !q || !found_count || !out_pixel || !out_level || !out_q || !out_count || B <= 0 || B > 65535 ||
         found_cap == 0 || out_cap == 0)
         return mst::fail(MST_E_ARG, "mst_select_below: bad argument");
@@ -489,6 +493,7 @@ extern "C" uint64_t mst_bh_workspace_bytes(int32_t B, uint32_t cap) {
 
 extern "C" int mst_bh_fdr(const double *pval, const uint32_t *count, int32_t B, uint32_t cap, double *q, void *workspace,
                           uint64_t workspace_bytes, void *stream) {
+    MST_RANGE("tail: mst_bh_fdr");
     if (!pval || !count || !q || !workspace || B <= 0 || B > 65535 || cap == 0 || (size_t)B * cap > 0x7FFFFFFFull)
         return mst::fail(MST_E_ARG, "mst_bh_fdr: bad argument (B * cap must fit in int32)");
     if (workspace_bytes < mst_bh_workspace_bytes(B, cap))

@@ -151,6 +151,7 @@ hic_rows_kernel(const uint8_t *__restrict__ payload, const mst_hic_row *__restri
 extern "C" int mst_band_scatter_hic_rows(const void *payload, const void *rows, int32_t n_rows, const double *norm,
                                          int64_t n_norm, int64_t max_dist, int64_t y_limit, int64_t n, int32_t dpx, double *band,
                                          uint64_t *stats, int32_t verify, void *stream) {
+    MST_RANGE("read: mst_band_scatter_hic_rows");
     if (!band || !stats || n <= 0 || dpx < 0 || n_rows < 0 || (n_rows > 0 && (!payload || !rows)) || (norm && n_norm < 0) ||
         (reinterpret_cast<uintptr_t>(payload) & 1) || (reinterpret_cast<uintptr_t>(rows) & 3))
         return mst::fail(MST_E_ARG, "mst_band_scatter_hic_rows: bad argument (payload 2-byte, rows 4-byte aligned)");

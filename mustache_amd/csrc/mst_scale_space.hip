@@ -723,9 +723,13 @@ int64_t floor_div(int64_t a, int64_t b) { return a >= 0 ? a / b : -((-a + b - 1)
 // Order: a block's items row-major; without band_only the tile ROWS are dealt to eight buckets in turn (the kernel gives each
 // XCD a contiguous eighth of the list): the upper rows of a block hold the wide part of the band, whose tiles cost more than
 // the constant ones, and the dispatcher hands out workgroups in order, so an XCD that got only upper rows would set the pace.
+//   cuts / stage_begin (staged launches, mst_scale_space_band_stage): stage i holds the items of blocks [cuts[i - 1], cuts[i]); the
+//               list is ordered stage by stage (each stage dealt on its own) and stage_begin[i] is its first item.  The list
+//               itself -- which tile is computed for which blocks -- is that of the whole launch: sharing crosses the cuts.
 template <class T>
 void build_items(const int64_t *starts, int B, int CH, int dpx, bool share, bool band_only, std::vector<WorkItem> &items,
-                 std::vector<int32_t> &slot_of_pos, int *tiles_total_out) {
+                 std::vector<int32_t> &slot_of_pos, int *tiles_total_out, const int32_t *cuts = nullptr, int n_cuts = 0,
+                 std::vector<int32_t> *stage_begin = nullptr) {
     const int npos = grid_positions<T>(CH), gcols = grid_cols<T>(CH);
     slot_of_pos.assign((size_t)B * npos, -1);
     std::vector<WorkItem> list;
@@ -788,15 +792,27 @@ void build_items(const int64_t *starts, int B, int CH, int dpx, bool share, bool
     items.reserve(n);
     std::vector<size_t> order;
     order.reserve(n);
-    if (band_only) {
-        for (size_t i = 0; i < n; ++i) order.push_back(i);
-    } else {
-        size_t at[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (size_t i = 0; i < n; ++i) ++at[row_of[i] % 8 + 1];
-        for (int x = 0; x < 8; ++x) at[x + 1] += at[x];
-        order.assign(n, 0);
-        for (size_t i = 0; i < n; ++i) order[at[row_of[i] % 8]++] = i;
+    if (stage_begin) stage_begin->clear();
+    // `list` is in block order, so a stage is a contiguous run [lo, hi) of it
+    size_t lo = 0;
+    for (int sgi = 0; sgi <= n_cuts; ++sgi) {
+        const int b_end = sgi < n_cuts ? cuts[sgi] : B;
+        size_t hi = lo;
+        while (hi < n && list[hi].b < b_end) ++hi;
+        if (stage_begin) stage_begin->push_back((int32_t)order.size());
+        if (band_only) {
+            for (size_t i = lo; i < hi; ++i) order.push_back(i);
+        } else {
+            size_t at[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t i = lo; i < hi; ++i) ++at[row_of[i] % 8 + 1];
+            for (int x = 0; x < 8; ++x) at[x + 1] += at[x];
+            const size_t base = order.size();
+            order.resize(base + (hi - lo));
+            for (size_t i = lo; i < hi; ++i) order[base + at[row_of[i] % 8]++] = i;
+        }
+        lo = hi;
     }
+    if (stage_begin) stage_begin->push_back((int32_t)order.size());
     for (size_t k = 0; k < n; ++k) {
         const size_t i = order[k];
         items.push_back(list[i]);
@@ -942,7 +958,12 @@ template <bool BAND>
 static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, const int64_t *starts_host, int32_t B,
                             int32_t CH, const mst_levels *lv, mst_found *found, uint32_t found_cap,
                             uint32_t *found_count, double *level_stats, int32_t flags, void *workspace,
-                            uint64_t workspace_bytes, void *stream, const char *who) {
+                            uint64_t workspace_bytes, void *stream, const char *who, const int32_t *cuts = nullptr,
+                            int32_t n_cuts = 0, int32_t stage = -1) {
+    // staged form (mst_scale_space_band_stage): stage >= 0 enqueues only the items of blocks [cuts[stage - 1], cuts[stage]) of the
+    // launch's ONE work list and the level statistics of those blocks; stage 0 also uploads the tables and zeroes the counters
+    const bool staged = stage >= 0;
+    if (staged) flags &= ~MST_FLAG_GRAPH;
     const int skip_empty = (flags & MST_FLAG_SKIP_EMPTY) ? 1 : 0;
     const bool fma = (flags & MST_FLAG_FMA) != 0;
     int mr = 0, nt = 0;
@@ -1056,7 +1077,27 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
         std::vector<int64_t> key;
         std::vector<WorkItem> items;
         std::vector<int32_t> sop;
+        std::vector<int32_t> stage_begin;        // staged lists: first item of every stage, then the item count
         mst::PinnedList pin_items, pin_sop;      // page-locked copies the launches upload from (no host memcpy per launch)
+        // ... and a DEVICE copy, uploaded once per list: a step that repeats its launch (a benchmark loop, the second sample, the
+        // same chromosome again) does not send the list -- 17 MB for the 124 blocks of chr1 at 1 kb, 0.4 ms in front of the
+        // kernel -- again.  The buffer belongs to the cache entry and only grows; `used` lies behind the last launch that read it.
+        char *dbuf = nullptr;
+        size_t dcap = 0;
+        int ddev = -1;
+        bool on_device = false;
+        hipEvent_t up = nullptr, used = nullptr;
+        bool used_pending = false;
+        void wait_used() {
+            if (used_pending && used) (void)hipEventSynchronize(used);
+            used_pending = false;
+        }
+        ~Cached() {
+            wait_used();
+            if (up) (void)hipEventDestroy(up);
+            if (used) (void)hipEventDestroy(used);
+            if (dbuf) (void)hipFree(dbuf);
+        }
     };
     static thread_local Cached cache[4];
     static thread_local unsigned cache_turn = 0;
@@ -1069,11 +1110,17 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
     key.push_back(BAND ? src.dpx : -1);
     key.push_back((share ? 1 : 0) | (band_only ? 2 : 0) | (wide ? 4 : 0));
     if (share) key.insert(key.end(), starts_host, starts_host + B);     // without sharing the list does not depend on the origins
+    if (staged) {
+        key.push_back(-7);
+        key.insert(key.end(), cuts, cuts + n_cuts);
+    }
     Cached *hit = nullptr;
     for (Cached &cd : cache)
         if (cd.key == key) hit = &cd;
     if (!hit) {
         hit = &cache[cache_turn++ % 4];
+        hit->wait_used();                   // (a launch four lists ago: long done) its device copy is about to be replaced
+        hit->on_device = false;
         hit->key = key;
         std::vector<int64_t> zeros;
         const int64_t *st = starts_host;
@@ -1081,8 +1128,10 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
             zeros.assign((size_t)B, 0);
             st = zeros.data();
         }
-        if (wide) build_items<TileWide>(st, B, CH, BAND ? src.dpx : 0, share, band_only, hit->items, hit->sop, nullptr);
-        else build_items<TileDefault>(st, B, CH, BAND ? src.dpx : 0, share, band_only, hit->items, hit->sop, nullptr);
+        if (wide) build_items<TileWide>(st, B, CH, BAND ? src.dpx : 0, share, band_only, hit->items, hit->sop, nullptr,
+                                        staged ? cuts : nullptr, staged ? n_cuts : 0, &hit->stage_begin);
+        else build_items<TileDefault>(st, B, CH, BAND ? src.dpx : 0, share, band_only, hit->items, hit->sop, nullptr,
+                                      staged ? cuts : nullptr, staged ? n_cuts : 0, &hit->stage_begin);
         hipError_t pe = hit->pin_items.assign(hit->items.data(), sizeof(WorkItem) * hit->items.size());
         if (pe == hipSuccess) pe = hit->pin_sop.assign(hit->sop.data(), sizeof(int32_t) * (size_t)B * npos);
         if (pe != hipSuccess) {
@@ -1092,6 +1141,10 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
     }
     const int n_items = (int)hit->items.size();
     const size_t items_bytes = sizeof(WorkItem) * (size_t)n_items, sop_bytes = sizeof(int32_t) * (size_t)B * npos;
+    // this call's share of the list and of the blocks (everything, unless staged)
+    const int it0 = staged ? hit->stage_begin[stage] : 0, it1 = staged ? hit->stage_begin[stage + 1] : n_items;
+    const int blk0 = staged && stage > 0 ? cuts[stage - 1] : 0, blk1 = staged && stage < n_cuts ? cuts[stage] : B;
+    const bool first = !staged || stage == 0;
 
     if (gent) {
         // everything the graph's copy nodes will read, in page-locked memory the entry owns; then the capture begins
@@ -1137,42 +1190,89 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
             }
             gent->image_used = n_items ? o3 + sop_bytes : o2;
             MST_HIP(hipMemcpyAsync(d_lv, img, gent->image_used, hipMemcpyHostToDevice, s));
-        } else {
+        } else if (first) {
             MST_HIP(up(d_lv, &h, sizeof(h)));
         }
-        zero_counts_kernel<<<(B + 255) / 256, 256, 0, s>>>(found_count, BAND ? src.nz_count : nullptr, B);
-        MST_LAUNCH_CHECK();
+        if (first) {
+            zero_counts_kernel<<<(B + 255) / 256, 256, 0, s>>>(found_count, BAND ? src.nz_count : nullptr, B);
+            MST_LAUNCH_CHECK();
+        }
         if (BAND) {
-            if (!gent) MST_HIP(up(d_starts, starts_host, sizeof(int64_t) * B));
+            if (!gent && first) MST_HIP(up(d_starts, starts_host, sizeof(int64_t) * B));
             src.starts = d_starts;
         }
         if (n_items == 0) {          // no tile reaches the band: nothing is tested, nothing is found
-            fill_stats_kernel<<<(B * MST_MAX_TESTED + 255) / 256, 256, 0, s>>>(level_stats, B * MST_MAX_TESTED);
-            MST_LAUNCH_CHECK();
+            if (first) {
+                fill_stats_kernel<<<(B * MST_MAX_TESTED + 255) / 256, 256, 0, s>>>(level_stats, B * MST_MAX_TESTED);
+                MST_LAUNCH_CHECK();
+            }
             return MST_OK;
         }
         if (!gent) {
-            MST_HIP(hit->pin_items.upload(d_items, s));
-            MST_HIP(hit->pin_sop.upload(d_sop, s));
+            // the list's device copy (struct Cached): uploaded by the first launch that uses the list, read in place afterwards
+            int dev = 0;
+            MST_HIP(hipGetDevice(&dev));
+            const size_t off_sop = align_up(items_bytes, 256), need_dev = off_sop + sop_bytes;
+            if (hit->on_device && hit->ddev != dev) hit->on_device = false;
+            if (!hit->on_device) {
+                hit->wait_used();
+                if (hit->dcap < need_dev || hit->ddev != dev) {
+                    if (hit->dbuf) (void)hipFree(hit->dbuf);
+                    hit->dbuf = nullptr;
+                    hit->dcap = 0;
+                    if (hit->up) (void)hipEventDestroy(hit->up);
+                    if (hit->used) (void)hipEventDestroy(hit->used);
+                    hit->up = hit->used = nullptr;
+                    const size_t want = need_dev + need_dev / 4;
+                    MST_HIP(hipMalloc((void **)&hit->dbuf, want));
+                    hit->dcap = want;
+                    hit->ddev = dev;
+                    MST_HIP(hipEventCreateWithFlags(&hit->up, hipEventDisableTiming));
+                    MST_HIP(hipEventCreateWithFlags(&hit->used, hipEventDisableTiming));
+                }
+                MST_HIP(hit->pin_items.upload(hit->dbuf, s));
+                MST_HIP(hit->pin_sop.upload(hit->dbuf + off_sop, s));
+                MST_HIP(hipEventRecord(hit->up, s));
+                hit->on_device = true;
+            } else {
+                MST_HIP(hipStreamWaitEvent(s, hit->up, 0));          // uploaded on another stream, perhaps
+            }
+            d_items = reinterpret_cast<WorkItem *>(hit->dbuf);
+            d_sop = reinterpret_cast<int32_t *>(hit->dbuf + off_sop);
         }
-        int lrc;
-        if (fma)
-            lrc = launch_scale_space<TileDefaultFma, BAND>(c, nz, src, CH, d_lv, found, found_cap, found_count, partial, nt,
-                                                           skip_empty, d_items, n_items, s);
+        // (staged: this stage's run of the list; its items' slots in `partial` keep their positions in the WHOLE list, which is
+        //  what the position map refers to -- both pointers are simply advanced)
+        const WorkItem *li = d_items + it0;
+        double *lp = partial + (size_t)it0 * nt * 2;
+        const int ln = it1 - it0;
+        int lrc = MST_OK;
+        if (ln == 0)
+            ;
+        else if (fma)
+            lrc = launch_scale_space<TileDefaultFma, BAND>(c, nz, src, CH, d_lv, found, found_cap, found_count, lp, nt,
+                                                           skip_empty, li, ln, s);
 #ifdef MST_EXP_TILE7
         else if (mr <= 7 && getenv("MST_EXP_USE_TILE7"))
-            lrc = launch_scale_space<TileOct1, BAND>(c, nz, src, CH, d_lv, found, found_cap, found_count, partial, nt,
-                                                     skip_empty, d_items, n_items, s);
+            lrc = launch_scale_space<TileOct1, BAND>(c, nz, src, CH, d_lv, found, found_cap, found_count, lp, nt,
+                                                     skip_empty, li, ln, s);
 #endif
         else if (!wide)
-            lrc = launch_scale_space<TileDefault, BAND>(c, nz, src, CH, d_lv, found, found_cap, found_count, partial, nt,
-                                                        skip_empty, d_items, n_items, s);
+            lrc = launch_scale_space<TileDefault, BAND>(c, nz, src, CH, d_lv, found, found_cap, found_count, lp, nt,
+                                                        skip_empty, li, ln, s);
         else
-            lrc = launch_scale_space<TileWide, BAND>(c, nz, src, CH, d_lv, found, found_cap, found_count, partial, nt,
-                                                     skip_empty, d_items, n_items, s);
+            lrc = launch_scale_space<TileWide, BAND>(c, nz, src, CH, d_lv, found, found_cap, found_count, lp, nt,
+                                                     skip_empty, li, ln, s);
         if (lrc != MST_OK) return lrc;
-        stats_reduce_kernel<<<dim3(nt, B), 256, 0, s>>>(partial, npos, d_sop, nt, level_stats);
-        MST_LAUNCH_CHECK();
+        // a block's tiles are its own items and shared ones of the block before it: complete once its stage has run
+        if (blk1 > blk0) {
+            stats_reduce_kernel<<<dim3(nt, blk1 - blk0), 256, 0, s>>>(partial, npos, d_sop + (size_t)blk0 * npos, nt,
+                                                                    level_stats + (size_t)blk0 * MST_MAX_TESTED * 2);
+            MST_LAUNCH_CHECK();
+        }
+        if (!gent) {
+            MST_HIP(hipEventRecord(hit->used, s));
+            hit->used_pending = true;
+        }
         return MST_OK;
     };
     if (!(flags & MST_FLAG_GRAPH))
@@ -1207,6 +1307,7 @@ static int scale_space_impl(const double *c, const uint8_t *nz, BandSrc src, con
 extern "C" int mst_scale_space(const double *c, const uint8_t *nz, int32_t B, int32_t CH, const mst_levels *lv,
                                mst_found *found, uint32_t found_cap, uint32_t *found_count, double *level_stats,
                                int32_t flags, void *workspace, uint64_t workspace_bytes, void *stream) {
+    MST_RANGE("launch: mst_scale_space");
     if (!c || !nz) return mst::fail(MST_E_ARG, "mst_scale_space: bad argument");
     BandSrc none = {nullptr, 0, 0, nullptr, nullptr, nullptr, INT_MAX};
     return scale_space_impl<false>(c, nz, none, nullptr, B, CH, lv, found, found_cap, found_count, level_stats, flags,
@@ -1217,6 +1318,7 @@ extern "C" int mst_scale_space_band(const double *band, int64_t n, int32_t dpx, 
                                     int32_t CH, const mst_levels *lv, mst_found *found, uint32_t found_cap,
                                     uint32_t *found_count, double *level_stats, uint32_t *nz_count, int32_t flags,
                                     void *workspace, uint64_t workspace_bytes, void *stream) {
+    MST_RANGE("launch: mst_scale_space_band");
     if (!band || !starts || !nz_count || n <= 0 || dpx < 0)
         return mst::fail(MST_E_ARG, "mst_scale_space_band: bad argument");
     BandSrc src = {band, n, dpx, nullptr, nz_count, nullptr, INT_MAX};
@@ -1224,10 +1326,27 @@ extern "C" int mst_scale_space_band(const double *band, int64_t n, int32_t dpx, 
                                   flags, workspace, workspace_bytes, stream, "mst_scale_space_band");
 }
 
+extern "C" int mst_scale_space_band_stage(const double *band, int64_t n, int32_t dpx, const int64_t *starts, int32_t B,
+                                          int32_t CH, const mst_levels *lv, mst_found *found, uint32_t found_cap,
+                                          uint32_t *found_count, double *level_stats, uint32_t *nz_count, int32_t flags,
+                                          void *workspace, uint64_t workspace_bytes, const int32_t *cuts, int32_t n_cuts,
+                                          int32_t stage, void *stream) {
+    MST_RANGE("launch: mst_scale_space_band_stage");
+    if (!band || !starts || !nz_count || n <= 0 || dpx < 0 || n_cuts < 0 || (n_cuts > 0 && !cuts) || stage < 0 || stage > n_cuts)
+        return mst::fail(MST_E_ARG, "mst_scale_space_band_stage: bad argument");
+    for (int i = 0; i < n_cuts; ++i)
+        if (cuts[i] <= (i ? cuts[i - 1] : 0) || cuts[i] >= B)
+            return mst::fail(MST_E_ARG, "mst_scale_space_band_stage: cuts must be ascending block indices in (0, B)");
+    BandSrc src = {band, n, dpx, nullptr, nz_count, nullptr, INT_MAX};
+    return scale_space_impl<true>(nullptr, nullptr, src, starts, B, CH, lv, found, found_cap, found_count, level_stats,
+                                  flags, workspace, workspace_bytes, stream, "mst_scale_space_band_stage", cuts, n_cuts, stage);
+}
+
 extern "C" int mst_scale_space_band_pair(const double *band1, const double *band2, int32_t split, int64_t n, int32_t dpx,
                                          const int64_t *starts, int32_t B, int32_t CH, const mst_levels *lv, mst_found *found,
                                          uint32_t found_cap, uint32_t *found_count, double *level_stats, uint32_t *nz_count,
                                          int32_t flags, void *workspace, uint64_t workspace_bytes, void *stream) {
+    MST_RANGE("launch: mst_scale_space_band_pair");
     if (!band1 || !band2 || !starts || !nz_count || n <= 0 || dpx < 0 || split < 1 || split >= B)
         return mst::fail(MST_E_ARG, "mst_scale_space_band_pair: bad argument (0 < split < B)");
     if (starts[split] > starts[split - 1] && starts[split] - starts[split - 1] < CH)

@@ -334,6 +334,7 @@ extern "C" int mst_diag_means(const double *c, int32_t CH, int32_t b, const int3
 
 extern "C" int mst_diag_means_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,
                                    const int32_t *diag_k, int32_t nd, double *mean_out, void *stream) {
+    MST_RANGE("tail: mst_diag_means_band");
     if (nd == 0) return MST_OK;
     if (!band || !diag_k || !mean_out || CH <= 0 || n <= 0 || dpx < 0 || nd < 0)
         return mst::fail(MST_E_ARG, "mst_diag_means_band: bad argument");
@@ -342,6 +343,7 @@ extern "C" int mst_diag_means_band(const double *band, int64_t n, int32_t dpx, i
 
 extern "C" int mst_diag_means_band_multi(const double *band, int64_t n, int32_t dpx, const int64_t *starts, int32_t CH,
                                          const int32_t *diag_k, int32_t nd, double *mean_out, void *stream) {
+    MST_RANGE("tail: mst_diag_means_band_multi");
     if (nd == 0) return MST_OK;
     if (!band || !starts || !diag_k || !mean_out || CH <= 0 || n <= 0 || dpx < 0 || nd < 0)
         return mst::fail(MST_E_ARG, "mst_diag_means_band_multi: bad argument");
@@ -351,6 +353,7 @@ extern "C" int mst_diag_means_band_multi(const double *band, int64_t n, int32_t 
 extern "C" int mst_candidate_features_band(const double *band, int64_t n, int32_t dpx, int64_t start, int32_t CH,
                                            const uint32_t *pixel, const int32_t *half, int32_t ncand, uint32_t *cnt1,
                                            uint32_t *cnt2, double *cval, void *stream) {
+    MST_RANGE("tail: mst_candidate_features_band");
     if (ncand == 0) return MST_OK;
     if (!band || !pixel || !half || !cnt1 || !cnt2 || !cval || CH <= 0 || n <= 0 || dpx < 0 || ncand < 0)
         return mst::fail(MST_E_ARG, "mst_candidate_features_band: bad argument");
@@ -363,6 +366,7 @@ extern "C" int mst_candidate_features_band(const double *band, int64_t n, int32_
 extern "C" int mst_candidate_features_band_multi(const double *band, int64_t n, int32_t dpx, const int64_t *starts, int32_t CH,
                                                  const uint32_t *pixel, const int32_t *half, int32_t ncand, uint32_t *cnt1,
                                                  uint32_t *cnt2, double *cval, void *stream) {
+    MST_RANGE("tail: mst_candidate_features_band_multi");
     if (ncand == 0) return MST_OK;
     if (!band || !starts || !pixel || !half || !cnt1 || !cnt2 || !cval || n <= 0 || dpx < 0 || CH <= 0 || ncand < 0)
         return mst::fail(MST_E_ARG, "mst_candidate_features_band_multi: bad argument");
@@ -385,6 +389,7 @@ extern "C" int mst_gather_diagonals_band(const double *band, int64_t n, int32_t 
 extern "C" int mst_found_pvalues(const mst_found *found, uint32_t found_cap, const uint32_t *found_count,
                                  const uint32_t *nz_count, const double *level_stats, int32_t B, int32_t n_tested,
                                  double *pval, double *fit, void *stream) {
+    MST_RANGE("finish: mst_found_pvalues");
     if (!found || !found_count || !nz_count || !level_stats || !pval || !fit || B <= 0 || B > 65535 ||
         n_tested <= 0 || n_tested > MST_MAX_TESTED)
         return mst::fail(MST_E_ARG, "mst_found_pvalues: bad argument");
@@ -429,6 +434,7 @@ extern "C" int mst_found_finish(const mst_found *found, uint32_t found_cap, cons
                                 double *fit, uint32_t pack_pitch, int32_t *pix_out, uint8_t *lvl_out, double *pv_out,
                                 void *scratch_dev, void *summary_host, int32_t *pix_host, uint8_t *lvl_host, double *pv_host,
                                 int32_t flags, void *stream) {
+    MST_RANGE("finish: mst_found_finish");
     if (!found || !found_count || !nz_count || !level_stats || !pval || !fit || !scratch_dev || !summary_host || B <= 0 ||
         B > 65535 || n_tested <= 0 || n_tested > MST_MAX_TESTED)
         return mst::fail(MST_E_ARG, "mst_found_finish: bad argument");
@@ -764,6 +770,7 @@ extern "C" int mst_cluster_representatives(const uint32_t *sel_pix, const double
                                            const uint32_t *cand_pos, const uint32_t *cand_off, int32_t B, int32_t CH,
                                            uint32_t n_candidates, uint32_t *rep_pos, uint32_t *rep_count, void *workspace,
                                            uint64_t workspace_bytes, void *stream) {
+    MST_RANGE("tail: mst_cluster_representatives");
     if (B <= 0) return MST_OK;
     if (!sel_pix || !sel_q || !sel_off || !cand_pos || !cand_off || !rep_pos || !rep_count || !workspace || CH <= 0 ||
         (int64_t)CH * CH > 0xFFFFFFFFLL)

@@ -348,6 +348,9 @@ class ScaleSpaceEngine:
     def __init__(self, octave_values=(1.6, 3.2), s=10, device=None):
         self.lib = require_gpu()
         self.share_tiles = True      # band source: compute the tiles two consecutive blocks have in common once (identical records)
+        # several groups of blocks with host results: one launch in stages (mst_scale_space_band_stage) instead of a launch per
+        # group; MUSTACHE_STAGED=0 keeps the launch-per-group form (the cross-check of tests/test_gpu_pipeline.py)
+        self.staged_launches = os.environ.get("MUSTACHE_STAGED", "1") != "0"
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.levels = LevelTable(octave_values, s)
         self._select_cap = 4096
@@ -493,6 +496,58 @@ class ScaleSpaceEngine:
         return dict(args=(c, nz, nz_count, skip_empty, timing, fma, band_src), B=B, CH=CH, found_cap=found_cap, ws=ws,
                     stats=stats, fit=fit, count=count, found=found, pval=pval, ev=ev, reuse=reuse, graph=graph, band2=band2)
 
+    def _ss_launch_staged(self, groups, band_src_all, skip_empty, found_cap, timing, fma):
+        """ONE fused launch over the blocks of all `groups` (consecutive lists of block origins), enqueued on the current stream
+        in one stage per group (mst_scale_space_band_stage): the work list is the whole launch's, so tiles shared by the last
+        block of a group and the first block of the next are still computed once -- separate launches per group recompute them
+        (0.4 ms per cut on 4000 x 4000 blocks) -- and after stage i the blocks of groups 0 .. i are final.  Returns one state
+        per group in the form _ss_finish takes: views of the launch's buffers for the group's blocks, with `done` = the event
+        behind the group's stage."""
+        band, bn, bdpx, CH = band_src_all
+        starts = [int(v) for g in groups for v in g]
+        B = len(starts)
+        cuts, acc = [], 0
+        for g in groups[:-1]:
+            acc += len(g)
+            cuts.append(acc)
+        st_arr = (ctypes.c_int64 * B)(*starts)
+        cut_arr = (ctypes.c_int32 * max(1, len(cuts)))(*cuts)
+        if found_cap is None:
+            found_cap = self._found_cap.get(CH, max(4096, (CH * CH) // 32))
+        lv = ctypes.byref(self._lv_struct)
+        ws_bytes = self._ws_bytes.get((B, CH))
+        if ws_bytes is None:
+            ws_bytes = self._ws_bytes[(B, CH)] = int(self.lib.mst_scale_space_workspace_bytes(B, CH, lv))
+        T = _lib.MST_MAX_TESTED
+        flags = (1 if skip_empty else 0) | (2 if fma else 0) | (0 if self.share_tiles else 4)
+        out = []
+        with torch.cuda.device(self.device):
+            ws, stats, fit, count, found, pval, nzc = self._carve(
+                (ws_bytes, torch.uint8, (ws_bytes,)), (B * T * 16, torch.float64, (B, T, 2)),
+                (B * T * 16, torch.float64, (B, T, 2)), (B * 4, torch.int32, (B,)),
+                (B * found_cap * 16, torch.int64, (B, found_cap, 2)), (B * found_cap * 8, torch.float64, (B, found_cap)),
+                (B * 4, torch.int32, (B,)), reuse=("staged", 0))
+            cur = torch.cuda.current_stream(self.device)
+            b0 = 0
+            for gi, g in enumerate(groups):
+                ev = None
+                if timing is not None:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                _lib.check(self.lib.mst_scale_space_band_stage(_ptr(band), bn, bdpx, st_arr, B, CH, lv, _ptr(found), found_cap,
+                                                               _ptr(count), _ptr(stats), _ptr(nzc), flags, _ptr(ws), ws_bytes,
+                                                               cut_arr, len(cuts), gi, _stream()))
+                if ev is not None:
+                    ev[1].record()
+                b1 = b0 + len(g)
+                sub_src = (band, bn, bdpx, [int(v) for v in g], CH)
+                out.append(dict(args=(None, None, nzc[b0:b1], skip_empty, timing, fma, sub_src), B=b1 - b0, CH=CH,
+                                found_cap=found_cap, ws=ws, stats=stats[b0:b1], fit=fit[b0:b1], count=count[b0:b1],
+                                found=found[b0:b1], pval=pval[b0:b1], ev=ev, reuse=1 + gi % 2, graph=False, band2=None,
+                                done=cur.record_event(), staged=True))
+                b0 = b1
+        return out
+
     def _carve(self, *parts, reuse=None):
         """Device buffers for one launch: parts = (bytes, dtype, shape).  `reuse` (a hashable key, or None): SMALL sets (< 256 MB)
         are kept and handed out again for the same key -- a launch of six 2000 x 2000 blocks is 1.75 ms of kernel, and a dozen
@@ -633,6 +688,34 @@ class ScaleSpaceEngine:
         ready = cur.record_event()              # the band was produced on the caller's stream
         if self._side_streams is None:
             self._side_streams = list(device_streams(self.device)[:2])
+        if self.staged_launches and download:
+            # ONE launch in one stage per group on the first side stream; the p-values / selection / download of group i run on
+            # the second one behind stage i's event, while stage i + 1 executes.  Same records as separate launches.
+            ks, fs = self._side_streams
+            ks.wait_event(ready)
+            cap = None
+            done_groups = 0
+            while True:
+                with torch.cuda.stream(ks), _lib.stage("scale-space launch"):
+                    sts = self._ss_launch_staged(groups, (band, int(n), int(dpx), int(CH)), skip_empty, cap, timing, fma)
+                try:
+                    for gi in range(done_groups, len(groups)):
+                        st = sts[gi]
+                        fs.wait_event(st["done"])
+                        with torch.cuda.stream(fs), _lib.stage("scale-space finish"):
+                            st2 = self._ss_finish(st, packed=select_below is None and not sort, relaunch=False)
+                            res = self._ss_results(st2, download, sort, with_value, with_q, select_below)
+                        yield res + (torch.from_numpy(st2["nz_h"].astype(np.uint32).view(np.int32)),)
+                        done_groups = gi + 1
+                    break
+                except _lib.MstOverflow:
+                    # rare (a block with an unusually dense set of local maxima): the whole launch again with four times the
+                    # record capacity; the groups already handed out stay as they are (their records were complete)
+                    ks.synchronize()
+                    cap = self._found_cap[int(CH)] = sts[0]["found_cap"] * 4
+            cur.wait_stream(ks)
+            cur.wait_stream(fs)
+            return
 
         def finish(st):
             with torch.cuda.stream(st["stream"]):

@@ -425,7 +425,7 @@ def write_loops(path, chromosome, chromosome2, res, loops, first):
 
 def _scalar_text(v):
     """str(v) for what a loop row holds: np.float64 / float -> repr(float(v)) (the same text), anything else -> str(v)."""
-    return repr(float(v)) if isinstance(v, (float, np.floating)) else str(v)
+    return repr(float(v)) if isinstance(v, (float, np.float64)) else str(v)      # str(np.float32) is NOT repr(float(v)): left to str()
 
 
 def main(argv=None):
@@ -481,9 +481,11 @@ def main(argv=None):
         chromosome, chromosome2 = pairs[i]
         CHRM_SIZE = chrSize_in_bp["chr" + str(chromosome).replace('chr', '')] if chrSize_in_bp else False
         try:
-            return read_contacts(f, args.norm_method, CHRM_SIZE, res, distFilter, biasf, chromosome, chromosome2,
-                                 verbose=args.verbose, packed=True, part=(0, 1) if by_chromosome else (rank, _world),
-                                 device=my_device)
+            from ._lib import stage
+            with stage("read %s" % chromosome):
+                return read_contacts(f, args.norm_method, CHRM_SIZE, res, distFilter, biasf, chromosome, chromosome2,
+                                     verbose=args.verbose, packed=True, part=(0, 1) if by_chromosome else (rank, _world),
+                                     device=my_device)
         except BaseException as e:          # re-raised in the main thread, at this chromosome's turn
             return e
 
@@ -510,6 +512,13 @@ def main(argv=None):
         chromosome, chromosome2 = pairs[i]
         print("{0} loops found for chrmosome={1}, fdr<{2} in {3}sec".format(
             len(o), chromosome, args.pt, "%.2f" % (time.time() - start_time)))
+        if args.verbose:
+            # beside the reference's line (mustache.py:1075-1076): what the GPU stage did -- blocks, Mpix, the fused kernel's time
+            from .pipeline import LAST_RUN, run_summary
+            line = run_summary()
+            if line:
+                print(line)
+                LAST_RUN.clear()
         if by_chromosome:
             results[i] = o
         elif rank == 0 and (i == 0 or o):

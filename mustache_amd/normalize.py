@@ -59,6 +59,11 @@ def pinned_packed_alloc(count):
 
 _SLAB_POOL = {}
 _SLAB_POOL_CAP = 512 << 20          # page-locked bytes the streamed reads may keep (MUSTACHE_HIC_POOL_MB overrides)
+# ONE page-locked buffer serves every streamed read of the process, so the reads take turns: the pipeline's reader thread may be
+# streaming the next chromosome while the main thread re-reads the current one (band_from_packed's check / duplicate-pixel
+# fallback calls `reread` outside readers._HIC_LOCK).  Re-entrant: the raw read's own fallback to the packed read nests.
+import threading
+_SLAB_LOCK = threading.RLock()
 
 
 def _slab_pool(nbytes):
@@ -117,14 +122,16 @@ def read_hic_stream_to_device(hic, chrom, res, norm, dpx, chrom_size_bp, device,
     slab_bytes = slab_records * (8 + dist_bytes)
     if n_slabs is None:
         n_slabs = _slab_count(threads, slab_bytes)
-    pool = _slab_pool(n_slabs * slab_bytes)
-    ddt = torch.uint16 if dist_bytes == 2 else torch.int32
-    st = HicStream(hic, chrom, res, norm, int(dpx), int(chrom_size_bp), pool.data_ptr(), n_slabs, slab_records, dist_bytes,
-                   threads=threads, part=part)
     from .engine import device_streams
     side = device_streams(torch.device(device))[2]          # the process's one copy stream of this device
+    ddt = torch.uint16 if dist_bytes == 2 else torch.int32
+    _SLAB_LOCK.acquire()
+    st = None
     parts, pending = [], []
     try:
+        pool = _slab_pool(n_slabs * slab_bytes)
+        st = HicStream(hic, chrom, res, norm, int(dpx), int(chrom_size_bp), pool.data_ptr(), n_slabs, slab_records, dist_bytes,
+                       threads=threads, part=part)
         while True:
             got = st.next(2 if pending else -1)
             # slabs whose copies have completed go back to the workers
@@ -152,9 +159,11 @@ def read_hic_stream_to_device(hic, chrom, res, norm, dpx, chrom_size_bp, device,
                 ev = side.record_event()
             parts.append((xd, dd, vd, cnt))
             pending.append((ev, slab))
-        side.synchronize()
     finally:
-        st.close()
+        side.synchronize()          # also on the error path: no copy out of the pool may be in flight when the next read fills it
+        if st is not None:
+            st.close()
+        _SLAB_LOCK.release()
     torch.cuda.current_stream(device).wait_stream(side)
     pc = PackedContacts(None, None, None, st.n, res, part=part[0], n_parts=part[1], blocks_total=st.blocks_total,
                         blocks_mine=st.blocks_mine, count=st.total)
@@ -185,12 +194,14 @@ def _read_hic_raw_to_band(hic, chrom, res, norm, dpx, chrom_size_bp, device, par
     slab_bytes = max(4096, (slab_bytes + 15) // 16 * 16)
     if n_slabs is None:
         n_slabs = _slab_count(threads, slab_bytes)
-    pool = _slab_pool(n_slabs * slab_bytes)
-    st = HicRawStream(hic, chrom, res, norm, int(dpx), pool.data_ptr(), n_slabs, slab_bytes, threads=threads, part=part)
     side = device_streams(device)[2]                        # the process's one copy stream of this device
     keep = keep_raw or part[1] > 1 or bool(os.environ.get("MUSTACHE_CHECK_PACKED"))
     parts, pending = [], []
+    _SLAB_LOCK.acquire()
+    st = None
     try:
+        pool = _slab_pool(n_slabs * slab_bytes)
+        st = HicRawStream(hic, chrom, res, norm, int(dpx), pool.data_ptr(), n_slabs, slab_bytes, threads=threads, part=part)
         normv, length = st.info()
         y_limit = -(-int(chrom_size_bp) // int(res)) if chrom_size_bp and chrom_size_bp > 0 else 0
         n_alloc = max(1, -(-int(length) // int(res)))
@@ -223,17 +234,22 @@ def _read_hic_raw_to_band(hic, chrom, res, norm, dpx, chrom_size_bp, device, par
             if keep:
                 parts.append((pay, dr, rows))
             pending.append((ev, slab))
-        side.synchronize()
     finally:
-        st.close()
+        side.synchronize()          # also on the error path: no copy out of the pool may be in flight when the next read fills it
+        if st is not None:
+            st.close()
+        _SLAB_LOCK.release()
     ymax1, kept, beyond, _ = (int(a) for a in stats.cpu().numpy())
-    if beyond:
+    if beyond and part[1] == 1:
         import warnings
         warnings.warn("%s: %d record(s) lie beyond the chromosome length the file's header gives (%d bp): reading it again through "
                       "the host decoder" % (chrom, beyond, length))
         del band, parts
         return read_hic_stream_to_device(hic, chrom, res, norm, dpx, chrom_size_bp, device, part=part, threads=threads,
                                          slab_records=slab_records, raw=False)
+    # (several ranks: a rank that alone fell back here would enter all_gather_packed while the others enter all_gather_raw -- two
+    #  collectives with different payloads.  The decision is taken in _band_from_raw AFTER the exchange, where every rank has
+    #  decoded every rank's rows and therefore holds the same `beyond` count: all of them re-read, or none.)
     pc = PackedContacts(None, None, None, ymax1, res, part=part[0], n_parts=part[1], blocks_total=st.blocks_total,
                         blocks_mine=st.blocks_mine, count=kept)
     pc.device_band, pc.band_stats, pc.raw_parts, pc.raw_ctx = band, stats, parts if keep else None, ctx
@@ -364,7 +380,13 @@ def _band_from_raw(lib, pc, dpx, device, check):
                 _scatter_rows(lib, pay, dr, rows, ctx, band, stats, _stream(), verify=1)
         ymax1, kept, beyond, bad = (int(a) for a in stats.cpu().numpy())
     if beyond:
-        raise RuntimeError("records beyond the chromosome length of the file's header in another rank's share")
+        # the same count on every rank (each has decoded all shares by now): every rank reads the whole chromosome again through
+        # the host decoder -- no collective involved -- as the one-rank read does
+        import warnings
+        warnings.warn("%d record(s) lie beyond the chromosome length the file's header gives: reading the chromosome again through "
+                      "the host decoder" % beyond)
+        del band
+        return band_from_packed(ctx["reread"](), dpx, device, check=check)
     if check and bad:
         import warnings
         warnings.warn("%d record(s) of the .hic file share a pixel with another value: reading the chromosome again through the host "
@@ -374,7 +396,26 @@ def _band_from_raw(lib, pc, dpx, device, check):
         return band_from_packed(again, dpx, device, check=True)
     pc.n_all = pc.n = n = ymax1 if kept else 0
     pc.count_all = kept
-    return band if n == band.shape[1] else band[:, :n].contiguous()
+    return band if n == band.shape[1] else _trim_band_in_place(band, n)
+
+
+def _trim_band_in_place(band, n, temp_bytes=64 << 20):
+    """band [rows, n_alloc] -> [rows, n] (n < n_alloc) in the SAME allocation: the rows are moved up group by group through a
+    temporary of at most `temp_bytes` (row d goes from offset d * n_alloc to d * n, so a group's destination never reaches a row
+    that has not been moved yet), and the result is a view of the first rows * n elements.  `band[:, :n].contiguous()` would
+    hold a second band next to the first -- 4 GB + 4 GB for chr1 at 1 kb, for the handful of empty trailing bins almost every
+    chromosome has."""
+    rows = band.shape[0]
+    if n == 0:
+        return band.new_zeros((rows, 0))
+    flat = band.view(-1)
+    group = max(1, min(rows, temp_bytes // (8 * n)))
+    for d0 in range(0, rows, group):
+        g = min(group, rows - d0)
+        tmp = band[d0:d0 + g, :n].clone(memory_format=torch.contiguous_format)
+        flat[d0 * n:(d0 + g) * n].copy_(tmp.view(-1))
+        del tmp
+    return flat[:rows * n].view(rows, n)
 
 
 def band_to_coo(band, x, y, v_out, n, dpx):

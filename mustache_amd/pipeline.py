@@ -17,6 +17,22 @@ from .sharding import shard_blocks, gather_loops, world
 from .tail import batch_tail
 
 
+# what the last run_band / run_layout of this process measured: blocks, Mpix, seconds in the scale-space stage and in the tail,
+# the fused kernel's own time (HIP events) -- the command line's verbose summary prints it (mustache.main, `-v`)
+LAST_RUN = {}
+
+
+def run_summary(t=None):
+    """one line for the verbose output: blocks, Mpix, stage seconds, fused-kernel milliseconds, Mpix/s"""
+    t = LAST_RUN if t is None else t
+    if not t or not t.get("mpix"):
+        return ""
+    dev, tail = t.get("scale_space_s", 0.0), t.get("tail_s", 0.0)
+    rate = t["mpix"] / max(dev + tail, 1e-9)
+    return ("  [gpu] %d block(s) of %d x %d = %.1f Mpix: scale-space %.3f s (fused launches %.1f ms by HIP events, a first launch with its work-list set-up), tail %.3f s -> %.0f Mpix/s"
+            % (t.get("blocks", 0), t.get("chunk", 0), t.get("chunk", 0), t["mpix"], dev, t.get("kernel_ms", 0.0), tail, rate))
+
+
 def block_tiling(n, distance_in_px):
     from .mustache import block_tiling as _bt
     return _bt(n, distance_in_px)
@@ -113,7 +129,8 @@ class ChromosomePipeline:
         t_dev = t_tail = 0.0
 
         def tail(batch, group, starts_g):
-            tails = batch_tail(batch, list(range(len(group))), starts_g, pt, st, intra=True)
+            with _lib.stage("tail"):
+                tails = batch_tail(batch, list(range(len(group))), starts_g, pt, st, intra=True)
             for j, i in enumerate(group):
                 mask = block_mask_size(i, start, end, dpx)
                 for lp in tails[j]:
@@ -140,8 +157,9 @@ class ChromosomePipeline:
             groups = [mine[i:i + self.overlap_blocks] for i in range(0, len(mine), self.overlap_blocks)]
             starts = [[start[i] for i in g] for g in groups]
             t0 = time.time()
+            kev = []                               # (start, end) events of the fused kernel's launches / stages
             for group, starts_g, (found, fits, nzc) in zip(groups, starts, self.engine.sigma_loop_band_overlapped(
-                    band, n, dpx, starts, CH, skip_empty=skip_empty, with_value=False, select_below=pt)):
+                    band, n, dpx, starts, CH, skip_empty=skip_empty, with_value=False, select_below=pt, timing=kev)):
                 t1 = time.time()
                 batch = BandBatch(self.engine, band, n, dpx, starts_g, CH,
                                   nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
@@ -149,9 +167,10 @@ class ChromosomePipeline:
                 t_tail += time.time() - t1
                 del batch
             t_dev = time.time() - t0 - t_tail
+            LAST_RUN.update(kernel_ms=sum(a.elapsed_time(b) for a, b in kev))
+        LAST_RUN.update(scale_space_s=t_dev, tail_s=t_tail, blocks=len(mine), chunk=CH, mpix=len(mine) * CH * CH / 1e6)
         if timings is not None:
-            timings.update(scale_space_s=t_dev, tail_s=t_tail, blocks=len(mine), chunk=CH,
-                           mpix=len(mine) * CH * CH / 1e6)
+            timings.update(LAST_RUN)
         return gather_loops(loops, device=self.device) if (distributed and ws > 1) else loops
 
     def blocks_per_launch(self, CH):
@@ -176,13 +195,15 @@ class ChromosomePipeline:
         loops = [[] for _ in ns]
         t0 = time.time()
         t_tail = 0.0
+        kev = []
         for group, (found, fits, nzc) in zip(groups, self.engine.sigma_loop_band_overlapped(
                 gband, lay.N, dpx, [[g[3] for g in grp] for grp in groups], CH, skip_empty=skip_empty, with_value=False,
-                select_below=pt)):
+                select_below=pt, timing=kev)):
             t1 = time.time()
             batch = BandBatch(self.engine, gband, lay.N, dpx, [g[3] for g in group], CH,
                               nzc.cpu().numpy().view(np.uint32).astype(np.int64), found, fits)
-            tails = batch_tail(batch, list(range(len(group))), [g[2] for g in group], pt, st, intra=True)
+            with _lib.stage("tail"):
+                tails = batch_tail(batch, list(range(len(group))), [g[2] for g in group], pt, st, intra=True)
             for j, (c, i, s_loc, _) in enumerate(group):
                 _, start, end = lay.tiling[c]
                 mask = block_mask_size(i, start, end, dpx)
@@ -191,18 +212,22 @@ class ChromosomePipeline:
                         loops[c].append([lp[0], lp[1], lp[2], lp[3]])
             t_tail += time.time() - t1
             del batch
+        LAST_RUN.update(scale_space_s=time.time() - t0 - t_tail, tail_s=t_tail, blocks=len(lay.blocks), chunk=CH,
+                        mpix=len(lay.blocks) * CH * CH / 1e6, launches=len(groups),
+                        kernel_ms=sum(a.elapsed_time(b) for a, b in kev))
         if timings is not None:
-            timings.update(scale_space_s=time.time() - t0 - t_tail, tail_s=t_tail, blocks=len(lay.blocks), chunk=CH,
-                           mpix=len(lay.blocks) * CH * CH / 1e6, launches=len(groups))
+            timings.update(LAST_RUN)
         return loops
 
     def normalized_band_packed(self, pc, dpx, normalized=False):
         """hicfile.PackedContacts of one chromosome -> (normalised band on the device, n)."""
         from .normalize import band_from_packed
-        band = band_from_packed(pc, dpx, self.device)       # pc.n_parts > 1: the ranks exchange their shares in here
+        with _lib.stage("band from records"):
+            band = band_from_packed(pc, dpx, self.device)       # pc.n_parts > 1: the ranks exchange their shares in here
         n = int(band.shape[1])                              # = max(binY) + 1 over ALL shares (mustache.py:894)
         if not normalized and n > 0:
-            band, _, _ = normalize_band(band, n, dpx, pc.res)
+            with _lib.stage("normalise"):
+                band, _, _ = normalize_band(band, n, dpx, pc.res)
         return band, n
 
     def run_packed(self, pc, dpx, st, pt, verbose=False, skip_empty=True, distributed=True, timings=None):
@@ -229,9 +254,11 @@ class ChromosomePipeline:
         y = np.ascontiguousarray(np.asarray(y), dtype=np.int64)
         v = np.ascontiguousarray(np.asarray(v), dtype=np.float64)
         n = int(max(x.max(), y.max())) + 1
-        band = band_from_host_coo(x, y, v, n, dpx, self.device)
+        with _lib.stage("band from records"):
+            band = band_from_host_coo(x, y, v, n, dpx, self.device)
         if not normalized:
-            band, _, _ = normalize_band(band, n, dpx, res)
+            with _lib.stage("normalise"):
+                band, _, _ = normalize_band(band, n, dpx, res)
         return band, n
 
     def run(self, x, y, v, res, dpx, st, pt, normalized=False, verbose=False, skip_empty=True, distributed=True,

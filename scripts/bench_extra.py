@@ -85,16 +85,9 @@ class Extra:
         self.out["sparse_1kb"] = res
 
     def cpu_pools(self):
-        """BASELINE.md section 3: (b) the reference's default -p 4 over a stated subset of >= 8 blocks, scaled linearly;
-        (c) one process per core, capped (MST_BENCH_CPU_PROCS, default 16; 0 switches the leg off)"""
+        """one process per core, capped (MST_BENCH_CPU_PROCS, default 16; 0 switches the leg off)"""
         B, w, out, value = self.B, self.cx.w, self.out, self.value
-        bi = len(w.start) // 2
-        sub = [(bi + j) % len(w.start) for j in range(-4, 5) if j]
-        wall4 = _pool(B, w, sub, 4)
-        out["cpu_baseline_p4"] = {"value": round(len(sub) * w.CH * w.CH / 1e6 / wall4, 4), "unit": "Mpix/s", "cores": 4,
-                                  "kind": "port", "sample": "%d of the workload's %d blocks in 4 worker processes, two rounds "
-                                  "(the reference's default -p 4), wall %.1f s incl. process start-up" % (len(sub), len(w.start), wall4)}
-        out["speedup_vs_cpu_p4"] = round(value / out["cpu_baseline_p4"]["value"], 1)
+        bi = len(w.start) // 2          # (the -p 4 leg is on the default line: cpu_baseline.p4, speedup_vs_cpu_p4)
         P = min(int(os.environ.get("MST_BENCH_CPU_PROCS", "16")), len(w.start), os.cpu_count() or 1)
         if P > 0:
             wallp = _pool(B, w, [(bi + j) % len(w.start) for j in range(P)], P)

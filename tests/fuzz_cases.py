@@ -13,6 +13,57 @@ import numpy as np
 OCT = [float(t) for t in os.environ["FUZZ_OCT"].split(",")] if os.environ.get("FUZZ_OCT") else [1.6, 3.2]
 
 
+# ---- the oracle ahead of the GPU.  The CPU oracle is the slow side of every pipeline case (seconds to a minute per chromosome,
+# one core); tests/test_gpu_fuzz.py first runs its cases in PLAN mode (plan = a list: the case draws its parameters, appends
+# the oracle jobs it will need and returns), hands the jobs to worker processes (start_ahead) and then runs the cases for real
+# with the same seed -- the same draws -- picking the results up as they are needed.  Without start_ahead (scripts/fuzz_*.py)
+# the oracle runs inline, as before.
+_AHEAD = {}
+_POOL = None
+
+
+def oracle_job(args):
+    """(n, dpx, depth, seed, nloops, res, st, pt, octaves) -> the oracle's loops of that synthetic chromosome"""
+    import oracle
+    import torch
+    from mustache_amd.synth import synth_coo
+    n, dpx, depth, seed, nloops, res, st, pt, octs = args
+    torch.set_num_threads(1)
+    x, y, v = synth_coo(n, dpx, depth=depth, seed=seed, nloops=nloops)
+    return oracle.regulator_coo(x, y, v, res, dpx, list(octs), st, pt)
+
+
+def start_ahead(jobs, workers=None):
+    """run the oracle jobs (oracle_job arguments) in worker processes; _oracle() collects them"""
+    global _POOL
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    if _POOL is None:
+        _POOL = cf.ProcessPoolExecutor(max_workers=workers or max(2, min(12, (os.cpu_count() or 4) // 2)),
+                                       mp_context=mp.get_context("spawn"))
+    for j in jobs:
+        if j not in _AHEAD:
+            _AHEAD[j] = _POOL.submit(oracle_job, j)
+
+
+def stop_ahead():
+    global _POOL
+    if _POOL is not None:
+        _POOL.shutdown(wait=False, cancel_futures=True)
+        _POOL = None
+    _AHEAD.clear()
+
+
+def _oracle(job):
+    fut = _AHEAD.pop(job, None)
+    if fut is not None:
+        try:
+            return fut.result()
+        except Exception as e:            # a broken pool must not fail a parity test: the oracle runs inline instead
+            print("fuzz_cases: oracle worker failed (%r), running inline" % (e,), flush=True)
+    return oracle_job(job)
+
+
 def _same_loops(got, exp, qtol=1e-6):
     got = sorted(got, key=lambda r: (int(r[0]), int(r[1])))
     exp = sorted(exp, key=lambda r: (int(r[0]), int(r[1])))
@@ -69,7 +120,7 @@ def parity_case(rng, eng):
     return bool(ok and tail_ok), len(exp), dict(desc, found=int(f.sum()), found_ok=bool(ok), tail_ok=bool(tail_ok))
 
 
-def pipeline_case(rng, pipe, max_n=5200, share_modes=(True,), wide=False):
+def pipeline_case(rng, pipe, max_n=5200, share_modes=(True,), wide=False, plan=None):
     """One random chromosome through the whole GPU pipeline (COO -> band -> normalisation -> band-direct fused kernel -> device
     BH / selection -> batched tail -> overlap masks) against the oracle's regulator restatement.  share_modes: the values of
     engine.share_tiles to run (tiles of overlapping blocks computed once / every tile once per block) -- the oracle runs once.
@@ -87,11 +138,15 @@ def pipeline_case(rng, pipe, max_n=5200, share_modes=(True,), wide=False):
     depth = float(rng.choice([5.0, 40.0, 300.0]))
     st, pt = float(rng.choice([0.5, 0.7, 0.88])), float(rng.choice([0.05, 0.1, 0.3]))
     seed = int(rng.integers(0, 10 ** 6))
+    job = (n, dpx, depth, seed, max(n // 25, 4), res, st, pt, tuple(OCT))
+    if plan is not None:
+        plan.append(job)
+        return None
     x, y, v = synth_coo(n, dpx, depth=depth, seed=seed, nloops=max(n // 25, 4))
     import os
     if os.environ.get("FUZZ_VERBOSE"):
         print("  pipeline_case:", dict(n=n, dpx=dpx, res=res, depth=depth, st=st, pt=pt, seed=seed, wide=wide), flush=True)
-    exp = oracle.regulator_coo(x, y, v.copy(), res, dpx, OCT, st, pt) if not os.environ.get("FUZZ_SKIP_ORACLE") else []
+    exp = _oracle(job) if not os.environ.get("FUZZ_SKIP_ORACLE") else []
     ok, qerr, counts = True, 0.0, []
     keep = pipe.engine.share_tiles
     try:
@@ -108,7 +163,7 @@ def pipeline_case(rng, pipe, max_n=5200, share_modes=(True,), wide=False):
                               share_modes=list(share_modes))
 
 
-def genome_case(rng, pipe, max_n=5200, max_chroms=5):
+def genome_case(rng, pipe, max_n=5200, max_chroms=5, plan=None):
     """A random set of 2-max_chroms chromosomes (from shorter than one block up) through run_genome -- side by side in one
     band, a random number of blocks per launch so that blocks of several chromosomes share launches -- against the oracle's
     regulator restatement per chromosome."""
@@ -119,11 +174,17 @@ def genome_case(rng, pipe, max_n=5200, max_chroms=5):
     st, pt = float(rng.choice([0.5, 0.7, 0.88])), float(rng.choice([0.05, 0.1, 0.3]))
     per = int(rng.integers(1, 9))
     k = int(rng.integers(2, max_chroms + 1))
-    coos = []
+    coos, jobs = [], []
     for c in range(k):
         n = int(rng.integers(max(dpx + 50, 300), max_n))
         depth = float(rng.choice([5.0, 40.0, 300.0]))
-        coos.append(synth_coo(n, dpx, depth=depth, seed=int(rng.integers(0, 10 ** 6)), nloops=max(n // 25, 4)))
+        seed = int(rng.integers(0, 10 ** 6))
+        jobs.append((n, dpx, depth, seed, max(n // 25, 4), res, st, pt, tuple(OCT)))
+        if plan is None:
+            coos.append(synth_coo(n, dpx, depth=depth, seed=seed, nloops=max(n // 25, 4)))
+    if plan is not None:
+        plan.extend(jobs)
+        return None
     keep = pipe.__dict__.get("blocks_per_launch")
     pipe.blocks_per_launch = lambda CH, k_=per: k_
     try:
@@ -136,7 +197,7 @@ def genome_case(rng, pipe, max_n=5200, max_chroms=5):
             pipe.blocks_per_launch = keep
     ok, total, bad = True, 0, []
     for c, ((x, y, v), got) in enumerate(zip(coos, got_all)):
-        exp = oracle.regulator_coo(x, y, v.copy(), res, dpx, OCT, st, pt)
+        exp = _oracle(jobs[c])
         s, q = _same_loops(got, exp)
         total += len(exp)
         if not s:
@@ -192,12 +253,15 @@ def diff_case(rng, eng):
         kind="block pair", n=n, dpx=dpx, st=st, pt=pt, pt2=pt2, lists=[len(l) for l in exp], forms_agree=forms_agree, qerr=qe)
 
 
-def geometry_case(pipe, n, dpx, res, depth, st=0.88, pt=0.1, share_modes=(True,)):
+def geometry_case(pipe, n, dpx, res, depth, st=0.88, pt=0.1, share_modes=(True,), plan=None):
     """A fixed chromosome at a geometry beyond BASELINE's through the whole pipeline against the oracle's regulator."""
-    import oracle
     from mustache_amd.synth import synth_coo
+    job = (n, dpx, depth, n, n // 25, res, st, pt, tuple(OCT))
+    if plan is not None:
+        plan.append(job)
+        return None
     x, y, v = synth_coo(n, dpx, depth=depth, seed=n, nloops=n // 25)
-    exp = oracle.regulator_coo(x, y, v.copy(), res, dpx, OCT, st, pt)
+    exp = _oracle(job)
     ok, qerr = True, 0.0
     keep = pipe.engine.share_tiles
     try:

@@ -58,6 +58,13 @@ def test_bench_one_rank_small():
                         "--no-file"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _last_json(r.stdout)
+    # the labelled single-GPU projection of the strong split (every rank's range timed alone on this GPU)
+    rk = j["ranks"]
+    assert rk["kind"] == "single-GPU share timing, not a multi-GPU run"
+    assert set(rk["projected_step_ms_at"]) == set(rk["projected_efficiency_at"]) == {"2", "4", "8"}
+    for k in ("2", "4", "8"):
+        assert len(rk["projected_step_ms_per_rank"][k]) == int(k) and rk["projected_step_ms_at"][k] == max(rk["projected_step_ms_per_rank"][k])
+        assert 0.3 < rk["projected_efficiency_at"][k] <= 1.05
     _check_line(j, 1, 2, 1)
     assert set(j) == KEPT, sorted(set(j) ^ KEPT)
     assert j["scaling"] == "strong" and j["config"]["partition"] == "blocks" and "rank 0 = [0, 12)" in j["config"]["sharding"]

@@ -15,10 +15,36 @@ import fuzz_cases      # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
+def _chromosome_cases(pipe, plan=None):
+    rng = np.random.default_rng(20265)
+    res = [fuzz_cases.pipeline_case(rng, pipe, max_n=3600, share_modes=(True, False), plan=plan) for _ in range(8)]
+    # two cases at the 1 kb geometry in small: blocks overlap by half their edge, most tiles are shared
+    res += [fuzz_cases.pipeline_case(rng, pipe, share_modes=(True, False), wide=True, plan=plan) for _ in range(2)]
+    return res
+
+
+def _genome_cases(pipe, plan=None):
+    rng = np.random.default_rng(20266)
+    return [fuzz_cases.genome_case(rng, pipe, max_n=3200, max_chroms=4, plan=plan) for _ in range(5)]
+
+
+def _geometry_case(pipe, plan=None):
+    return fuzz_cases.geometry_case(pipe, 7000, 3011, 1000, 300.0, share_modes=(True, False), plan=plan)
+
+
 @pytest.fixture(scope="module")
 def pipe():
+    """the pipeline the cases share -- and the CPU oracle of every pipeline case of this module started AHEAD in worker
+    processes (fuzz_cases.start_ahead: the cases are first drawn in plan mode, same seeds), largest job first: the oracle is the
+    slow side (the module took 5 of the GPU suite's 10 minutes with the oracle inline)"""
     from mustache_amd.pipeline import ChromosomePipeline
-    return ChromosomePipeline(fuzz_cases.OCT)
+    plan = []
+    _geometry_case(None, plan)
+    _chromosome_cases(None, plan)
+    _genome_cases(None, plan)
+    fuzz_cases.start_ahead(sorted(plan, key=lambda j: -(j[0] * max(j[1], 400))))
+    yield ChromosomePipeline(fuzz_cases.OCT)
+    fuzz_cases.stop_ahead()
 
 
 def _report(results):
@@ -36,17 +62,13 @@ def test_fuzz_blocks_seeded_slice(pipe):
 
 
 def test_fuzz_chromosomes_seeded_slice_both_share_modes(pipe):
-    rng = np.random.default_rng(20265)
-    res = [fuzz_cases.pipeline_case(rng, pipe, max_n=3600, share_modes=(True, False)) for _ in range(8)]
-    # two cases at the 1 kb geometry in small: blocks overlap by half their edge, most tiles are shared
-    res += [fuzz_cases.pipeline_case(rng, pipe, share_modes=(True, False), wide=True) for _ in range(2)]
+    res = _chromosome_cases(pipe)
     loops = _report(res)
     assert loops > 100 and {d["branch"] for _, _, d in res} == {"A", "B"}
 
 
 def test_fuzz_genomes_seeded_slice(pipe):
-    rng = np.random.default_rng(20266)
-    loops = _report([fuzz_cases.genome_case(rng, pipe, max_n=3200, max_chroms=4) for _ in range(5)])
+    loops = _report(_genome_cases(pipe))
     assert loops > 100
 
 
@@ -59,5 +81,5 @@ def test_fuzz_block_pairs_seeded_slice(pipe):
 def test_large_geometry_odd_distance_limit(pipe):
     """dpx 3011 -> blocks of 6022 x 6022 whose overlap is not a multiple of anything (tile lattice phase differs per block),
     both share modes."""
-    ok, loops, d = fuzz_cases.geometry_case(pipe, 7000, 3011, 1000, 300.0, share_modes=(True, False))
+    ok, loops, d = _geometry_case(pipe)
     assert ok and loops >= 2, d

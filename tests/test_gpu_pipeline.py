@@ -386,13 +386,34 @@ def test_overlapped_launches_equal_one_launch():
     one, fits, nzc = pipe.engine.sigma_loop_band(band, n, dpx, start, CH)
     one = [{k: a[k].copy() for k in a} for a in one]                      # the arrays are views of reused pinned buffers
     groups = [start[0:2], start[2:3], start[3:]]
+    eng = pipe.engine
+    # staged (the default: ONE launch in a stage per group, mst_scale_space_band_stage -- tile sharing crosses the groups) and a
+    # launch per group; dense and tile list; and the staged form starting from a record capacity far too small (every stage
+    # overflows until the capacity has grown: the groups already handed out stay, the rest are launched again)
+    for staged, skip, cap in ((True, True, None), (False, True, None), (True, False, None), (True, True, 64)):
+        eng.staged_launches = staged
+        if cap:
+            eng._found_cap[CH] = cap
+        b = 0
+        for starts_g, (recs, fits_g, nzc_g) in zip(groups, eng.sigma_loop_band_overlapped(band, n, dpx, groups, CH, skip_empty=skip)):
+            assert torch.equal(nzc_g.cpu(), nzc[b:b + len(starts_g)].cpu())
+            for j in range(len(starts_g)):
+                for k in ("pixel", "level", "value", "pval", "q"):
+                    assert np.array_equal(recs[j][k], one[b + j][k]), (staged, skip, cap, b + j, k)
+                assert np.array_equal(fits_g[j][0], fits[b + j][0]) and np.array_equal(fits_g[j][1], fits[b + j][1])
+            b += len(starts_g)
+        assert b == len(start)
+        if cap:
+            assert eng._found_cap[CH] >= max(len(a["pixel"]) for a in one) > cap
+    eng.staged_launches = True
+    # the packed whole-found-set download of the bench's step (sort=False, no values, no q): same pixels, levels, p-values
     b = 0
-    for starts_g, (recs, fits_g, nzc_g) in zip(groups, pipe.engine.sigma_loop_band_overlapped(band, n, dpx, groups, CH)):
-        assert torch.equal(nzc_g.cpu(), nzc[b:b + len(starts_g)].cpu())
+    for starts_g, (recs, fits_g, nzc_g) in zip(groups, eng.sigma_loop_band_overlapped(band, n, dpx, groups, CH, skip_empty=False, sort=False,
+                                                                                     with_value=False, with_q=False)):
         for j in range(len(starts_g)):
-            for k in ("pixel", "level", "value", "pval", "q"):
-                assert np.array_equal(recs[j][k], one[b + j][k]), (b + j, k)
-            assert np.array_equal(fits_g[j][0], fits[b + j][0]) and np.array_equal(fits_g[j][1], fits[b + j][1])
+            o = np.argsort(recs[j]["pixel"], kind="stable")
+            assert np.array_equal(recs[j]["pixel"][o], one[b + j]["pixel"]) and np.array_equal(recs[j]["level"][o], one[b + j]["level"])
+            assert np.array_equal(recs[j]["pval"][o], one[b + j]["pval"])
         b += len(starts_g)
     assert b == len(start)
 

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     internal = set(name for tag, name in tagged if tag == "MST_INTERNAL")
     assert internal == {"mst_bh_select_nowait", "mst_band_scatter_packed", "mst_band_scatter_hic_rows",
                         "mst_band_verify_packed", "mst_scale_space_band_tiles", "mst_scale_space_band_items",
-                        "mst_candidate_features_band_multi", "mst_diag_means_band_multi"}
+                        "mst_candidate_features_band_multi", "mst_diag_means_band_multi", "mst_scale_space_band_stage"}
     # the five of SURVEY 8(b) and the band forms the per-chromosome driver uses are on the stable side
     for name in ("mst_normalize_band", "mst_scatter_blocks", "mst_gauss_blur", "mst_scale_space", "mst_found_pvalues",
                  "mst_found_finish", "mst_scale_space_band", "mst_bh_select", "mst_cluster_representatives", "mst_diff_dog_band"):
@@ -414,3 +414,26 @@ def test_engine_constructor_leaves_the_collector_alone(monkeypatch):
         gc.unfreeze()
     assert "settle_gc()" in inspect.getsource(mm.main) and "settle_gc()" in inspect.getsource(dm.main)
     assert "settle_gc()" not in inspect.getsource(mm.mustache) and "settle_gc()" not in inspect.getsource(mm.regulator)
+
+
+def test_trim_band_in_place_moves_rows_inside_one_allocation():
+    """normalize._trim_band_in_place: [rows, n_alloc] -> [rows, n] without a second band (groups of rows through a bounded
+    temporary; the result is a view of the same storage) -- for every group size, including overlapping source / destination rows."""
+    import torch
+    from mustache_amd.normalize import _trim_band_in_place
+    for rows, na, n, tb in ((7, 10, 9, 80), (2002, 500, 497, 8 * 497 * 50), (5, 6, 1, 8), (9, 100, 3, 64), (4, 9, 8, 8 * 8 * 4), (1, 9, 8, 1)):
+        b = torch.arange(rows * na, dtype=torch.float64).view(rows, na).clone()
+        want = b[:, :n].clone()
+        got = _trim_band_in_place(b, n, tb)
+        assert torch.equal(got, want) and got.is_contiguous() and got.data_ptr() == b.data_ptr(), (rows, na, n)
+    assert _trim_band_in_place(torch.ones(3, 4, dtype=torch.float64), 0).shape == (3, 0)
+
+
+def test_scalar_text_fast_path_is_limited_to_doubles():
+    """mustache._scalar_text: repr(float(v)) equals the reference's str(v) for Python floats and np.float64 only; a float32
+    (str() prints its own shortest repr) and everything else go through str()."""
+    from mustache_amd.mustache import _scalar_text
+    for v in (0.1, np.float64(1) / 3, np.float64(1e-300), 2.0):
+        assert _scalar_text(v) == str(v)
+    assert _scalar_text(np.float32(0.1)) == str(np.float32(0.1)) == "0.1"
+    assert _scalar_text(np.int64(7)) == "7"

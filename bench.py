@@ -59,8 +59,16 @@ def work_items(w, skip_empty, share=True):
     """(workgroups launched, tiles the blocks would run one by one, tiles computed once for two blocks, workgroups per
     launch) over the launches of one step of workload w -- asked of the library (engine.band_items)."""
     if w.pipe.engine.staged_launches:      # the groups are stages of ONE work list: sharing crosses them
-        p = w.pipe.engine.band_items([w.start[i] for g in w.groups for i in g], w.CH, w.dpx, skip_empty, share)
-        return p[0], p[1], p[2], [p[0]]
+        blocks = [w.start[i] for g in w.groups for i in g]
+        p = w.pipe.engine.band_items(blocks, w.CH, w.dpx, skip_empty, share)
+        # a stage's workgroups = the items of its blocks: the list of the first k blocks holds exactly the whole list's items
+        # of those blocks (an item shared with block k is listed once either way)
+        ends, acc = [], 0
+        for g in w.groups:
+            acc += len(g)
+            ends.append(acc)
+        pre = [0] + [w.pipe.engine.band_items(blocks[:e], w.CH, w.dpx, skip_empty, share)[0] for e in ends[:-1]] + [p[0]]
+        return p[0], p[1], p[2], [b - a for a, b in zip(pre[:-1], pre[1:])]
     per = [w.pipe.engine.band_items([w.start[i] for i in g], w.CH, w.dpx, skip_empty, share) for g in w.groups]
     return sum(p[0] for p in per), sum(p[1] for p in per), sum(p[2] for p in per), [p[0] for p in per]
 
@@ -187,8 +195,8 @@ class Workload:
                     for f in share[:-1]:
                         cuts.append(min(nb - 1, max(cuts[-1] + 1, int(round(cuts[-1] + f * nb)))))
                     cuts.append(nb)
-                elif nb < 4 or OVERLAP < 2:
-                    cuts = [0, nb]
+                elif nb < 4 or nb * self.CH * self.CH < 120e6 or OVERLAP < 2:
+                    cuts = [0, nb]                           # small launches (six blocks of 2000 x 2000): one launch, replayed as a graph
                 elif nb < 24 or OVERLAP < 3:
                     cuts = [0, nb - last, nb]
                 else:

@@ -18,7 +18,7 @@ lines = ["# rocprofv3 summary `%s`" % tag, "",
          "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu --no-file` "
          "(scripts/profile_bench.sh); PMC passes: `rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --small "
          "--steps 1 --warmup 0 --core` with `MST_BENCH_OVERLAP=1` (12 blocks of 4000x4000 in ONE launch), one pass per counter "
-         "group, all in the same session as the trace.  The traced run uses bench.py's default of 4 launches per step on alternating streams.", ""]
+         "group, all in the same session as the trace.  The traced run uses bench.py's default: ONE launch per step in three stages (mst_scale_space_band_stage: three kernel invocations over one work list), the finish of a stage under the next stage's kernel.", ""]
 
 # ---- kernel stats ------------------------------------------------------------------------------------------------
 st = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))

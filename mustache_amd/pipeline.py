@@ -17,6 +17,20 @@ from .sharding import shard_blocks, gather_loops, world
 from .tail import batch_tail
 
 
+def split_groups(items, per, px_per_item=16e6):
+    """items in groups of `per` (the stages of one fused launch, engine.sigma_loop_band_overlapped): the finish and the host tail
+    of a group run under the next group's kernel, only the LAST group's are exposed -- so a last group of six or more blocks
+    and at least ~100 Mpix gives all but 6 % of its items (at least two: their kernel has to cover the finish of the group in
+    front) to a group of their own (a stage boundary costs 0.08 ms, an exposed 4000 x 4000 block ~0.13 ms).  Smaller launches
+    stay whole: they are latency-bound and replayed as one graph."""
+    groups = [items[i:i + per] for i in range(0, len(items), per)]
+    if groups and len(groups[-1]) >= 6 and len(groups[-1]) * px_per_item >= 96e6:
+        last = groups.pop()
+        t = max(2, int(round(0.06 * len(last))))
+        groups += [last[:-t], last[-t:]]
+    return groups
+
+
 # what the last run_band / run_layout of this process measured: blocks, Mpix, seconds in the scale-space stage and in the tail,
 # the fused kernel's own time (HIP events) -- the command line's verbose summary prints it (mustache.main, `-v`)
 LAST_RUN = {}
@@ -154,7 +168,7 @@ class ChromosomePipeline:
         else:
             # default: blocks are windows of the band, cut inside the fused kernel.  The blocks go through it in groups of
             # `overlap_blocks`; BH + selection + download AND the host tail of one group run under the kernel of the next
-            groups = [mine[i:i + self.overlap_blocks] for i in range(0, len(mine), self.overlap_blocks)]
+            groups = split_groups(mine, self.overlap_blocks, float(CH) * CH)
             starts = [[start[i] for i in g] for g in groups]
             t0 = time.time()
             kev = []                               # (start, end) events of the fused kernel's launches / stages
@@ -191,7 +205,7 @@ class ChromosomePipeline:
         """run_genome's body on a prepared layout + genome band."""
         CH, dpx, ns = lay.CH, lay.dpx, lay.ns
         per = self.blocks_per_launch(CH)
-        groups = [lay.blocks[i:i + per] for i in range(0, len(lay.blocks), per)]
+        groups = split_groups(lay.blocks, per, float(CH) * CH)
         loops = [[] for _ in ns]
         t0 = time.time()
         t_tail = 0.0

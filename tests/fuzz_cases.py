@@ -33,17 +33,27 @@ def oracle_job(args):
     return oracle.regulator_coo(x, y, v, res, dpx, list(octs), st, pt)
 
 
+def _oracle_on_coo(x, y, v, res, dpx, octs, st, pt):
+    """what a worker process runs: NumPy / SciPy only (no torch import: on a fresh box that alone takes a minute per process)"""
+    import oracle
+    return oracle.regulator_coo(x, y, v, res, dpx, list(octs), st, pt)
+
+
 def start_ahead(jobs, workers=None):
-    """run the oracle jobs (oracle_job arguments) in worker processes; _oracle() collects them"""
+    """run the oracle jobs (oracle_job arguments) in worker processes; _oracle() collects them.  The synthetic contacts are drawn
+    here, in the parent (torch is loaded already), and handed over as arrays."""
     global _POOL
     import concurrent.futures as cf
     import multiprocessing as mp
+    from mustache_amd.synth import synth_coo
     if _POOL is None:
         _POOL = cf.ProcessPoolExecutor(max_workers=workers or max(2, min(12, (os.cpu_count() or 4) // 2)),
                                        mp_context=mp.get_context("spawn"))
     for j in jobs:
         if j not in _AHEAD:
-            _AHEAD[j] = _POOL.submit(oracle_job, j)
+            n, dpx, depth, seed, nloops, res, st, pt, octs = j
+            x, y, v = synth_coo(n, dpx, depth=depth, seed=seed, nloops=nloops)
+            _AHEAD[j] = _POOL.submit(_oracle_on_coo, x, y, v, res, dpx, octs, st, pt)
 
 
 def stop_ahead():

@@ -84,10 +84,19 @@ def block_tail(c, nz, pval, scale, start, pt, st, intra=True, min_nz=10000):
         lab[x + dx, y + dy] = 2
     lab_i, nfeat = label(lab, structure=np.ones((3, 3)))
 
+    # (:843-848) per label: argwhere(label_matrix == label) -- the label's pixels in row-major order, halo included -- and the
+    # first minimum of o over them.  The reference scans the whole matrix once per label (minutes for 10^4 labels); here the
+    # labelled pixels are listed ONCE in row-major order and grouped by label with a stable sort, which leaves every label's
+    # pixels in exactly the order its own argwhere would give: the same argmin, the same representative.
+    rr, cc = np.nonzero(lab_i)
+    labs = lab_i[rr, cc]
+    order = np.argsort(labs, kind="stable")
+    rr, cc, labs = rr[order], cc[order], labs[order]
+    bounds = np.searchsorted(labs, np.arange(1, nfeat + 2))
     out = []
-    for lb in range(1, nfeat + 1):                # (:843-848)
-        idx = np.argwhere(lab_i == lb)
-        i = np.argmin(o[idx[:, 0], idx[:, 1]])
-        _x, _y = idx[i, 0], idx[i, 1]
+    for lb in range(1, nfeat + 1):
+        a, b = bounds[lb - 1], bounds[lb]
+        i = a + np.argmin(o[rr[a:b], cc[a:b]])
+        _x, _y = rr[i], cc[i]
         out.append([_x + start, _y + start, o[_x, _y], so[_x, _y]])
     return out

@@ -281,3 +281,36 @@ def test_benjamini_hochberg_against_scipy():
         for bh in (bh_oracle, bh_host):
             np.testing.assert_allclose(bh(p), want, rtol=1e-14, atol=0)
     assert bh_oracle(np.zeros(0)).size == 0
+
+
+def test_representatives_by_grouping_equal_the_per_label_scan():
+    """oracle.tail.block_tail picks every cluster's representative from ONE row-major listing of the labelled pixels grouped by
+    label (stable sort); the reference scans the whole matrix once per label, `argwhere(label_matrix == label)`
+    (mustache.py:843-848).  Same representative for every label -- ties broken by the first pixel in row-major order, halo pixels
+    included -- on random candidate sets dense enough for clusters to merge."""
+    from scipy.ndimage import label
+    rng = np.random.default_rng(77)
+    for size, ncand in ((120, 300), (300, 1500), (64, 40)):
+        o = np.round(rng.uniform(0.0, 0.1, (size, size)), 2)          # coarse values: many exact ties
+        lab = np.zeros((size, size), dtype=np.float32)
+        x, y = rng.integers(1, size - 1, ncand), rng.integers(1, size - 1, ncand)
+        lab[x, y] = o[x, y] + 1
+        for dx, dy in ((1, 0), (1, 1), (0, 1), (-1, 0), (-1, -1), (0, -1), (1, -1), (-1, 1)):
+            lab[x + dx, y + dy] = 2
+        lab_i, nfeat = label(lab, structure=np.ones((3, 3)))
+        want = []
+        for lb in range(1, nfeat + 1):
+            idx = np.argwhere(lab_i == lb)
+            i = np.argmin(o[idx[:, 0], idx[:, 1]])
+            want.append((int(idx[i, 0]), int(idx[i, 1])))
+        rr, cc = np.nonzero(lab_i)
+        labs = lab_i[rr, cc]
+        order = np.argsort(labs, kind="stable")
+        rr, cc, labs = rr[order], cc[order], labs[order]
+        bounds = np.searchsorted(labs, np.arange(1, nfeat + 2))
+        got = []
+        for lb in range(1, nfeat + 1):
+            a, b = bounds[lb - 1], bounds[lb]
+            i = a + np.argmin(o[rr[a:b], cc[a:b]])
+            got.append((int(rr[i]), int(cc[i])))
+        assert got == want and nfeat > 5

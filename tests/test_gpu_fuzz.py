@@ -17,15 +17,15 @@ pytestmark = pytest.mark.gpu
 
 def _chromosome_cases(pipe, plan=None):
     rng = np.random.default_rng(20265)
-    res = [fuzz_cases.pipeline_case(rng, pipe, max_n=3600, share_modes=(True, False), plan=plan) for _ in range(8)]
-    # two cases at the 1 kb geometry in small: blocks overlap by half their edge, most tiles are shared
-    res += [fuzz_cases.pipeline_case(rng, pipe, share_modes=(True, False), wide=True, plan=plan) for _ in range(2)]
+    res = [fuzz_cases.pipeline_case(rng, pipe, max_n=3600, share_modes=(True, False), plan=plan) for _ in range(12)]
+    # three cases at the 1 kb geometry in small: blocks overlap by half their edge, most tiles are shared
+    res += [fuzz_cases.pipeline_case(rng, pipe, share_modes=(True, False), wide=True, plan=plan) for _ in range(3)]
     return res
 
 
 def _genome_cases(pipe, plan=None):
     rng = np.random.default_rng(20266)
-    return [fuzz_cases.genome_case(rng, pipe, max_n=3200, max_chroms=4, plan=plan) for _ in range(5)]
+    return [fuzz_cases.genome_case(rng, pipe, max_n=3200, max_chroms=4, plan=plan) for _ in range(7)]
 
 
 def _geometry_case(pipe, plan=None):
@@ -55,7 +55,7 @@ def _report(results):
 
 def test_fuzz_blocks_seeded_slice(pipe):
     rng = np.random.default_rng(20264)
-    res = [fuzz_cases.parity_case(rng, pipe.engine) for _ in range(10)]
+    res = [fuzz_cases.parity_case(rng, pipe.engine) for _ in range(24)]
     loops = _report(res)
     # (small blocks call few loops; what these cases hold is the complete found set: pixels, levels, DoG values, loc, p)
     assert loops >= 5 and sum(d.get("found", 0) for _, _, d in res) > 2000
@@ -74,7 +74,7 @@ def test_fuzz_genomes_seeded_slice(pipe):
 
 def test_fuzz_block_pairs_seeded_slice(pipe):
     rng = np.random.default_rng(20267)
-    loops = _report([fuzz_cases.diff_case(rng, pipe.engine) for _ in range(10)])
+    loops = _report([fuzz_cases.diff_case(rng, pipe.engine) for _ in range(14)])
     assert loops > 100
 
 

@@ -558,7 +558,7 @@ def _band_digest_worker(rank, ws, port, hic, res, dpx, q, mode="packed"):
         else:       # streamed: raw rows decoded on the device (the default for v7-9) or packed records from the host decoder
             from mustache_amd.normalize import read_hic_stream_to_device
             pc = read_hic_stream_to_device(h, "chrB", res, "NONE", dpx, 0, torch.device("cuda", 0), part=(rank, ws), threads=3,
-                                           slab_records=8192, raw=mode == "raw")
+                                           slab_records=8192, raw=mode.startswith("raw"))
     band, n = pipe.normalized_band_packed(pc, dpx)
     loops = pipe.run_band(band, n, dpx, 0.7, 0.2, distributed=True)
     q.put((rank, n, len(pc), pc.blocks_mine, pc.blocks_total, hashlib.sha256(band.cpu().numpy().tobytes()).hexdigest(),
@@ -567,9 +567,12 @@ def _band_digest_worker(rank, ws, port, hic, res, dpx, q, mode="packed"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["packed", "raw", "stream"])
+@pytest.mark.parametrize("mode", ["packed", "raw", "stream", "raw_short_header"])
 def test_two_rank_shared_decode_gives_the_one_rank_band_bit_for_bit(tmp_path, mode):
-    """(mode: one-shot packed read / streamed raw rows, exchanged as raw slabs and decoded on the device / streamed packed records)
+    """(mode: one-shot packed read / streamed raw rows, exchanged as raw slabs and decoded on the device / streamed packed records /
+    raw rows of a MALFORMED file whose header gives the chromosome 60 bins less than its records reach: only the last rank's share
+    holds such records, yet no rank may leave the raw exchange on its own -- after it every rank has decoded every share, holds
+    the same count and all of them re-read through the host decoder together, normalize._band_from_raw)
     Two processes on this box's one GPU (gloo): each decodes ITS share of the `.hic` blocks, the shares are exchanged
     (sharding.all_gather_packed) and every rank scatters + normalises the same record set -- the normalised band's sha-256 is
     the same on both ranks and equal to the 1-rank band's, and so are the loops."""
@@ -586,11 +589,19 @@ def test_two_rank_shared_decode_gives_the_one_rank_band_bit_for_bit(tmp_path, mo
     x, y, v = synth_coo(n, dpx, depth=200.0, seed=2)
     near = (y - x) <= dpx
     hic = str(tmp_path / "b.hic")
-    write_hic(hic, [("All", 1), ("chrB", n * res)], {1: {res: (x[near], y[near], np.round(v[near]) + 1.0)}}, {}, version=8,
-              block_bin_count=256, float_counts=False)
+    write_hic(hic, [("All", 1), ("chrB", (n - 60 if mode == "raw_short_header" else n) * res)],
+              {1: {res: (x[near], y[near], np.round(v[near]) + 1.0)}}, {}, version=8, block_bin_count=256, float_counts=False)
     pipe = ChromosomePipeline(OCT)
     with HicFile(hic) as h:
         pc = read_intra_packed(h, "chrB", res, "NONE", dpx, 0)
+    if mode == "raw_short_header":
+        assert pc.n > n - 60, "the host decoder keeps the records beyond the header's length (as the one-rank raw read's fallback does)"
+        # the one-rank raw read of the same file: falls back on its own (warning) and builds the same band
+        import torch
+        from mustache_amd.normalize import band_from_packed, read_hic_stream_to_device
+        with HicFile(hic) as h, pytest.warns(UserWarning, match="beyond the chromosome length"):
+            one = read_hic_stream_to_device(h, "chrB", res, "NONE", dpx, 0, pipe.device, threads=3, slab_records=8192, raw=True)
+        assert torch.equal(band_from_packed(one, dpx, pipe.device), band_from_packed(pc, dpx, pipe.device))
     band, n1 = pipe.normalized_band_packed(pc, dpx)
     want = hashlib.sha256(band.cpu().numpy().tobytes()).hexdigest()
     loops1 = [(int(a), int(b), float(c), float(d)) for a, b, c, d in pipe.run_band(band, n1, dpx, 0.7, 0.2, distributed=False)]
@@ -609,7 +620,9 @@ def test_two_rank_shared_decode_gives_the_one_rank_band_bit_for_bit(tmp_path, mo
         assert p.exitcode == 0
     assert [g[0] for g in got] == [0, 1]
     assert all(g[1] == n1 and g[5] == want for g in got), "same n, same band digest on both ranks as in the 1-rank run"
-    assert got[0][2] + got[1][2] == len(pc) and got[0][3] + got[1][3] == got[0][4] == pc.blocks_total
+    if mode != "raw_short_header":      # (there a share's count leaves out the records beyond the header's length)
+        assert got[0][2] + got[1][2] == len(pc)
+    assert got[0][3] + got[1][3] == got[0][4] == pc.blocks_total
     assert min(got[0][2], got[1][2]) > 0
     assert len(loops1) > 10 and sorted(got[0][6]) == sorted(got[1][6]) == sorted(loops1)
 

@@ -693,26 +693,40 @@ class ScaleSpaceEngine:
             # the second one behind stage i's event, while stage i + 1 executes.  Same records as separate launches.
             ks, fs = self._side_streams
             ks.wait_event(ready)
-            cap = None
-            done_groups = 0
-            while True:
-                with torch.cuda.stream(ks), _lib.stage("scale-space launch"):
-                    sts = self._ss_launch_staged(groups, (band, int(n), int(dpx), int(CH)), skip_empty, cap, timing, fma)
-                try:
-                    for gi in range(done_groups, len(groups)):
-                        st = sts[gi]
-                        fs.wait_event(st["done"])
-                        with torch.cuda.stream(fs), _lib.stage("scale-space finish"):
-                            st2 = self._ss_finish(st, packed=select_below is None and not sort, relaunch=False)
-                            res = self._ss_results(st2, download, sort, with_value, with_q, select_below)
-                        yield res + (torch.from_numpy(st2["nz_h"].astype(np.uint32).view(np.int32)),)
-                        done_groups = gi + 1
-                    break
-                except _lib.MstOverflow:
-                    # rare (a block with an unusually dense set of local maxima): the whole launch again with four times the
-                    # record capacity; the groups already handed out stay as they are (their records were complete)
-                    ks.synchronize()
-                    cap = self._found_cap[int(CH)] = sts[0]["found_cap"] * 4
+            # (a launch's record lists, p-values and per-tile statistics are allocated for all of its blocks at once: 24 B x
+            #  CH^2 / 32 per block and ~2.6 MB of statistics per 4000 x 4000 block -- 1.9 GB for chr1 at 1 kb.  Whole genomes at fine
+            #  resolutions go through several staged launches of at most MUSTACHE_STAGED_GB, default 32, of such buffers each.)
+            per_block = 24 * self._found_cap.get(int(CH), max(4096, (int(CH) * int(CH)) // 32)) + \
+                (int(CH) // 30 + 2) * (int(CH) // 62 + 2) * (20 + 16 * self.levels.n_tested)
+            budget = float(os.environ.get("MUSTACHE_STAGED_GB", "32")) * (1 << 30)
+            chunks, acc = [[]], 0
+            for g in groups:
+                if chunks[-1] and (acc + len(g)) * per_block > budget:
+                    chunks.append([])
+                    acc = 0
+                chunks[-1].append(g)
+                acc += len(g)
+            for chunk in chunks:
+                cap = None
+                done_groups = 0
+                while True:
+                    with torch.cuda.stream(ks), _lib.stage("scale-space launch"):
+                        sts = self._ss_launch_staged(chunk, (band, int(n), int(dpx), int(CH)), skip_empty, cap, timing, fma)
+                    try:
+                        for gi in range(done_groups, len(chunk)):
+                            st = sts[gi]
+                            fs.wait_event(st["done"])
+                            with torch.cuda.stream(fs), _lib.stage("scale-space finish"):
+                                st2 = self._ss_finish(st, packed=select_below is None and not sort, relaunch=False)
+                                res = self._ss_results(st2, download, sort, with_value, with_q, select_below)
+                            yield res + (torch.from_numpy(st2["nz_h"].astype(np.uint32).view(np.int32)),)
+                            done_groups = gi + 1
+                        break
+                    except _lib.MstOverflow:
+                        # rare (a block with an unusually dense set of local maxima): the whole launch again with four times the
+                        # record capacity; the groups already handed out stay as they are (their records were complete)
+                        ks.synchronize()
+                        cap = self._found_cap[int(CH)] = sts[0]["found_cap"] * 4
             cur.wait_stream(ks)
             cur.wait_stream(fs)
             return

@@ -390,8 +390,14 @@ def test_overlapped_launches_equal_one_launch():
     # staged (the default: ONE launch in a stage per group, mst_scale_space_band_stage -- tile sharing crosses the groups) and a
     # launch per group; dense and tile list; and the staged form starting from a record capacity far too small (every stage
     # overflows until the capacity has grown: the groups already handed out stay, the rest are launched again)
-    for staged, skip, cap in ((True, True, None), (False, True, None), (True, False, None), (True, True, 64)):
+    # ... and with a buffer budget so small that every group becomes a staged launch of its own (MUSTACHE_STAGED_GB)
+    for staged, skip, cap, gb in ((True, True, None, None), (False, True, None, None), (True, False, None, None), (True, True, 64, None),
+                                  (True, True, None, "0.000001")):
         eng.staged_launches = staged
+        if gb:
+            os.environ["MUSTACHE_STAGED_GB"] = gb
+        else:
+            os.environ.pop("MUSTACHE_STAGED_GB", None)
         if cap:
             eng._found_cap[CH] = cap
         b = 0
@@ -406,6 +412,7 @@ def test_overlapped_launches_equal_one_launch():
         if cap:
             assert eng._found_cap[CH] >= max(len(a["pixel"]) for a in one) > cap
     eng.staged_launches = True
+    os.environ.pop("MUSTACHE_STAGED_GB", None)
     # the packed whole-found-set download of the bench's step (sort=False, no values, no q): same pixels, levels, p-values
     b = 0
     for starts_g, (recs, fits_g, nzc_g) in zip(groups, eng.sigma_loop_band_overlapped(band, n, dpx, groups, CH, skip_empty=False, sort=False,

@@ -437,3 +437,13 @@ def test_scalar_text_fast_path_is_limited_to_doubles():
         assert _scalar_text(v) == str(v)
     assert _scalar_text(np.float32(0.1)) == str(np.float32(0.1)) == "0.1"
     assert _scalar_text(np.int64(7)) == "7"
+
+
+def test_split_groups_keeps_order_and_makes_the_last_stage_small():
+    """pipeline.split_groups: groups of `per` items in order; a last group of six or more blocks and ~100 Mpix gives all but
+    6 % (at least two) of its items to a group in front of it -- only the last stage's finish is exposed; small launches stay whole."""
+    from mustache_amd.pipeline import split_groups
+    for n, per, px, want in ((124, 16, 16e6, [16] * 7 + [10, 2]), (6, 64, 4e6, [6]), (63, 64, 4e6, [59, 4]), (20, 64, 4e6, [20]),
+                             (16, 16, 16e6, [14, 2]), (17, 16, 16e6, [16, 1]), (5, 16, 16e6, [5]), (0, 16, 16e6, [])):
+        g = split_groups(list(range(n)), per, px)
+        assert [len(a) for a in g] == want and sum(g, []) == list(range(n)), (n, per)

@@ -55,6 +55,24 @@ def executed_flops_per_pixel():
     return per_region_px * (32 * 64) / (30.0 * 62.0)
 
 
+def stage_cuts(nb, CH, overlap=3, shares=None):
+    """Where a step's nb blocks are cut into the stages of its one launch: [0, ..., nb].  Small launches (< 4 blocks or < 120 Mpix:
+    six blocks of 2000 x 2000) stay whole and are replayed as a graph; otherwise the LAST stage is 6 % of the blocks, at least two
+    (its kernel has to cover the download of the stage before it), with two equal stages in front from 24 blocks up.
+    `shares` ("0.8,0.2": MST_BENCH_SHARES, scripts/share_split_time.py) overrides the rule."""
+    if shares:
+        cuts = [0]
+        for f in [float(x) for x in shares.split(",")][:-1]:
+            cuts.append(min(nb - 1, max(cuts[-1] + 1, int(round(cuts[-1] + f * nb)))))
+        return cuts + [nb]
+    last = max(2, int(round(0.06 * nb)))
+    if nb < 4 or nb * CH * CH < 120e6 or overlap < 2:
+        return [0, nb]
+    if nb < 24 or overlap < 3:
+        return [0, nb - last, nb]
+    return [0, (nb - last + 1) // 2, nb - last, nb]
+
+
 def work_items(w, skip_empty, share=True):
     """(workgroups launched, tiles the blocks would run one by one, tiles computed once for two blocks, workgroups per
     launch) over the launches of one step of workload w -- asked of the library (engine.band_items)."""
@@ -187,20 +205,7 @@ class Workload:
         if getattr(self, "_groups_for", None) != key:
             groups = []
             for batch in self.pipe.batches(self.mine, self.CH, dense=False):
-                nb = len(batch)
-                last = max(2, int(round(0.06 * nb)))
-                if os.environ.get("MST_BENCH_SHARES"):       # experiments (scripts/share_split_time.py): another split
-                    share = [float(x) for x in os.environ["MST_BENCH_SHARES"].split(",")]
-                    cuts = [0]
-                    for f in share[:-1]:
-                        cuts.append(min(nb - 1, max(cuts[-1] + 1, int(round(cuts[-1] + f * nb)))))
-                    cuts.append(nb)
-                elif nb < 4 or nb * self.CH * self.CH < 120e6 or OVERLAP < 2:
-                    cuts = [0, nb]                           # small launches (six blocks of 2000 x 2000): one launch, replayed as a graph
-                elif nb < 24 or OVERLAP < 3:
-                    cuts = [0, nb - last, nb]
-                else:
-                    cuts = [0, (nb - last + 1) // 2, nb - last, nb]
+                cuts = stage_cuts(len(batch), self.CH, OVERLAP, os.environ.get("MST_BENCH_SHARES"))
                 groups += [batch[a:b] for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
             self.groups = groups                             # the split of the blocks into stages is fixed between steps
             self._groups_for = key

@@ -58,14 +58,14 @@ def executed_flops_per_pixel():
 def stage_cuts(nb, CH, overlap=3, shares=None):
     """Where a step's nb blocks are cut into the stages of its one launch: [0, ..., nb].  Small launches (< 4 blocks or < 120 Mpix:
     six blocks of 2000 x 2000) stay whole and are replayed as a graph; otherwise the LAST stage is 6 % of the blocks, at least two
-    (its kernel has to cover the download of the stage before it), with two equal stages in front from 24 blocks up.
+    beyond 16 blocks (its kernel has to cover the download of the stage before it), with two equal stages in front from 24 blocks up.
     `shares` ("0.8,0.2": MST_BENCH_SHARES, scripts/share_split_time.py) overrides the rule."""
     if shares:
         cuts = [0]
         for f in [float(x) for x in shares.split(",")][:-1]:
             cuts.append(min(nb - 1, max(cuts[-1] + 1, int(round(cuts[-1] + f * nb)))))
         return cuts + [nb]
-    last = max(2, int(round(0.06 * nb)))
+    last = max(1 if nb <= 16 else 2, int(round(0.06 * nb)))    # (16 blocks: [15, 1] 14.81 ms, [14, 2] 14.86, measured)
     if nb < 4 or nb * CH * CH < 120e6 or overlap < 2:
         return [0, nb]
     if nb < 24 or overlap < 3:

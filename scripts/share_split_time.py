@@ -9,7 +9,7 @@ steps = 30
 for world in [int(a) for a in sys.argv[1:]] or (8, 4):
     w.rank, w.world = 0, world
     w.set_scaling("strong")
-    for sh in ("1", "0.6,0.4", "0.7,0.3", "0.8,0.2", "0.85,0.15", "0.9,0.1", "0.94,0.06", "0.5,0.3,0.2", "0.45,0.4,0.15", "0.5,0.44,0.06",
+    for sh in os.environ.get("SPLITS", "").split(";") if os.environ.get("SPLITS") else ("1", "0.6,0.4", "0.7,0.3", "0.8,0.2", "0.85,0.15", "0.9,0.1", "0.94,0.06", "0.5,0.3,0.2", "0.45,0.4,0.15", "0.5,0.44,0.06",
                "0.29,0.29,0.29,0.13", "0.35,0.35,0.2,0.1", "0.32,0.32,0.3,0.06"):
         os.environ["MST_BENCH_SHARES"] = sh
         for _ in range(4):

@@ -454,8 +454,8 @@ def test_bench_stage_cuts():
     finish is exposed), two equal stages in front from 24 blocks up; the driver's rank counts on the 124-block workload."""
     import bench
     assert bench.stage_cuts(124, 4000) == [0, 59, 117, 124] and bench.stage_cuts(62, 4000) == [0, 29, 58, 62]
-    assert bench.stage_cuts(31, 4000) == [0, 15, 29, 31] and bench.stage_cuts(16, 4000) == [0, 14, 16] and bench.stage_cuts(15, 4000) == [0, 13, 15]
-    assert bench.stage_cuts(6, 2000) == [0, 6] and bench.stage_cuts(3, 4000) == [0, 3] and bench.stage_cuts(12, 4000) == [0, 10, 12]
+    assert bench.stage_cuts(31, 4000) == [0, 15, 29, 31] and bench.stage_cuts(16, 4000) == [0, 15, 16] and bench.stage_cuts(15, 4000) == [0, 14, 15]
+    assert bench.stage_cuts(6, 2000) == [0, 6] and bench.stage_cuts(3, 4000) == [0, 3] and bench.stage_cuts(12, 4000) == [0, 11, 12]
     assert bench.stage_cuts(124, 4000, overlap=1) == [0, 124] and bench.stage_cuts(124, 4000, overlap=2) == [0, 117, 124]
     assert bench.stage_cuts(16, 4000, shares="0.5,0.3,0.2") == [0, 8, 13, 16]
     for nb in range(1, 130):

@@ -1,3 +1,4 @@
+"""Host -> device copy rate out of a page-locked slab pool in the slab sizes of the `.hic` read (one copy per slab, copy stream)."""
 import time, torch
 dev = torch.device("cuda:0")
 cap = 1 << 20

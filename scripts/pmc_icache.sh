@@ -1,4 +1,5 @@
 #!/bin/bash
+# Instruction-cache counters (SQ_IFETCH, SQ_IFETCH_LEVEL, ...) of the fused kernel on the small bench: does the 79 KB kernel thrash the 64 KB cache?
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/pmc_ic
 mkdir -p $OUT

@@ -1,3 +1,5 @@
+#!/bin/bash
+# A/B in one session: bench.py --core untraced and under rocprofv3 --kernel-trace, staged launches and a launch per group (profiles/r06b_trace_overhead.txt).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export PYTHONPATH=$R

@@ -981,3 +981,31 @@ def test_graph_replay_gives_identical_records():
     for it in range(3):
         same(step(sub), want[1], all_blocks[1:])
     same(step(start), want[1], all_blocks)               # and back to the first graph
+
+
+def test_run_band_in_stages_equals_a_launch_per_group():
+    """pipeline.run_band on a chromosome of 40 blocks: its groups of 16 blocks are the stages of ONE launch (tile sharing
+    across the groups, the tail of one group under the next stage's kernel) -- the loops are those of the launch-per-group form
+    (engine.staged_launches = False), which earlier rounds held to the oracle, with and without the tile list."""
+    import torch
+    from mustache_amd.normalize import normalize_band
+    from mustache_amd.pipeline import ChromosomePipeline, block_tiling, split_groups
+    from mustache_amd.synth import band_counts
+    dpx, res = 400, 5000
+    n = 2000 + 39 * 1600
+    pipe = ChromosomePipeline(OCT)
+    band, _, _ = normalize_band(band_counts(n, dpx, 200.0, 1500, 3, device=pipe.device), n, dpx, res)
+    CH, start, end = block_tiling(n, dpx)
+    assert len(start) == 40 and [len(g) for g in split_groups(list(range(40)), pipe.overlap_blocks, float(CH) * CH)] == [16, 16, 8]
+    out = {}
+    for staged in (True, False):
+        for skip in (True, False):
+            pipe.engine.staged_launches = staged
+            out[(staged, skip)] = pipe.run_band(band, n, dpx, 0.8, 0.1, skip_empty=skip, distributed=False)
+    pipe.engine.staged_launches = True
+    ref = out[(False, True)]
+    assert len(ref) > 200
+    for key, loops in out.items():
+        assert len(loops) == len(ref), key
+        for a, b in zip(loops, ref):
+            assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and a[3] == b[3], (key, a, b)

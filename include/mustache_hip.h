@@ -314,7 +314,7 @@ MST_STABLE int mst_scale_space_band_pair(const double *band1, const double *band
                               const int64_t *starts, int32_t B, int32_t CH, const mst_levels *lv, mst_found *found,
                               uint32_t found_cap, uint32_t *found_count, double *level_stats, uint32_t *nz_count, int32_t flags,
                               void *workspace, uint64_t workspace_bytes, void *stream);
-/* mst_scale_space_band in STAGES (this package's engine; identical results): cuts[0 .. n_cuts) are ascending block indices in
+/* mst_scale_space_band (mustache.py:919-924 + :699-706 + :714-772) in STAGES (this package's engine; identical results): cuts[0 .. n_cuts) are ascending block indices in
  * (0, B); stage i (0 <= i <= n_cuts) enqueues the work items of blocks [cuts[i-1], cuts[i]) of the launch's ONE work list -- tile
  * sharing crosses the cuts, which separate launches over the same ranges would lose -- followed by the level statistics of
  * those blocks.  Call the stages in ascending order on one stream with identical arguments; stage 0 also uploads the tables

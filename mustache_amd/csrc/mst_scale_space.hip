@@ -47,7 +47,6 @@
 
 #include "mst_fir.h"
 
-
 namespace {
 
 __device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }

@@ -41,7 +41,7 @@ def main():
         torch.cuda.synchronize()
         t2 = time.time()
         if it:
-            rows.append(dict(normalize_ms=(t1 - t0) * 1e3, run_band_ms=(t2 - t1) * 1e3, scale_space_ms=tm["scale_space_s"] * 1e3,
+            rows.append(dict(normalize_ms=(t1 - t0) * 1e3, run_band_ms=(t2 - t1) * 1e3, scale_space_ms=tm["scale_space_s"] * 1e3, fused_launches_ms=tm.get("kernel_ms", 0.0),
                              tail_ms=tm["tail_s"] * 1e3, loops=len(loops), blocks=tm["blocks"]))
     rows.sort(key=lambda r: r["run_band_ms"])
     print("E2E " + json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in rows[len(rows) // 2].items()}))

@@ -656,7 +656,11 @@ class ScaleSpaceEngine:
                                    sort=True, with_value=True, with_q=True, select_below=None):
         """sigma_loop_band over several groups of blocks with copy/compute overlap: the groups' fused kernels run back
         to back on two alternating side streams, and the p-values / BH / selection / download of group i run while the
-        kernel of group i + 1 is executing.  Yields, per group, what sigma_loop_band returns."""
+        kernel of group i + 1 is executing.  Yields, per group, what sigma_loop_band returns.
+        LIFETIME of the host results: the record arrays of a group are views of two alternating page-locked staging sets
+        (_pinned) -- valid until the group AFTER NEXT is fetched.  Consume each group as it is yielded (the pipeline's tail does)
+        and copy what has to outlive that; `list(...)` over three or more groups leaves the first group's views showing the
+        third group's bytes (scripts/staged_stress.py checks the path that way)."""
         if len(groups) == 1:
             # nothing to overlap: run on the caller's stream, without the side streams' events (a small launch -- six blocks of
             # 2000 x 2000 are 1.75 ms of kernel -- pays for every host-side call)
